@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""Freeze golden vectors from the REAL reference (build container only).
+
+Imports microsoft/vision-longformer read-only from /root/reference/src (with
+stub modules for the two missing third-party imports, timm.models.layers and
+torchvision.models), runs it in fp64 on the cases of tests/golden_cases.py,
+asserts that oracle/vil_oracle.py reproduces every result, and writes the
+reference's outputs to tests/golden/*.npz.  The reference never travels: the
+fixtures hold data only (outputs; inputs are regenerated from seeds).
+
+    python tools/gen_golden.py            # regenerate + verify
+"""
+import os
+import sys
+import types
+import random
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = "/root/reference/src"
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not present: golden vectors can only be generated in the build container")
+    timm = types.ModuleType("timm")
+    timm_models = types.ModuleType("timm.models")
+    timm_layers = types.ModuleType("timm.models.layers")
+
+    def trunc_normal_(t, std=1.0, mean=0.0, a=-2.0, b=2.0):
+        return torch.nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
+
+    class DropPath(torch.nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+            self.p = p
+
+        def forward(self, x):
+            if self.p == 0.0 or not self.training:
+                return x
+            keep = 1 - self.p
+            mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+            return x.div(keep) * mask
+
+    timm_layers.trunc_normal_ = trunc_normal_
+    timm_layers.DropPath = DropPath
+    timm_layers.to_2tuple = lambda v: v if isinstance(v, tuple) else (v, v)
+    timm.models = timm_models
+    timm_models.layers = timm_layers
+    sys.modules.setdefault("timm", timm)
+    sys.modules.setdefault("timm.models", timm_models)
+    sys.modules.setdefault("timm.models.layers", timm_layers)
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tv.models = tvm
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.models", tvm)
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings("ignore")
+    from models.layers import slidingchunk_2d as ref_sc
+    from models.layers import longformer2d as ref_l2d
+    return ref_sc, ref_l2d
+
+
+def main():
+    from oracle import vil_oracle as O
+    import golden_cases as GC
+    ref_sc, ref_l2d = import_reference()
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    torch.set_grad_enabled(True)
+
+    # ---------------- relative position index ----------------
+    rpi = {}
+    for W in (2, 3, 4, 6, 7, 8, 12):
+        mod = ref_l2d.Long2DSCSelfAttention(8, num_heads=2, w=W, nglo=1, rpe=True)
+        ref = mod.relative_position_index
+        mine = O.relative_position_index(W)
+        assert torch.equal(ref, mine), f"rel index W={W}"
+        rpi[f"W{W}"] = ref.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(outdir, "rel_index.npz"), **rpi)
+    print("rel_index ok")
+
+    # ---------------- masks ----------------
+    masks = {}
+    for (mx, my, padx, pady, W) in GC.MASK_GRIDS:
+        for exact, fn in ((0, ref_sc._get_invalid_locations_mask_zero),
+                          (-1, ref_sc._get_invalid_locations_mask_cyclic),
+                          (1, ref_sc._get_invalid_locations_mask_exact)):
+            ref_mask, _ = fn(mx, my, padx, pady, W, "cpu")
+            for mode in GC.MODES:
+                if exact == 1 and mode != 0:
+                    continue
+                W2 = W * W
+                kv = {0: 9 * W2, -1: W2}.get(mode, 2 * W2)
+                t = torch.zeros(1, mx, my, W2, kv, dtype=torch.float64)
+                ni = ref_sc.mask_invalid_locations(t, mx, my, padx, pady, W, exact, mode)
+                ref_full = torch.isinf(t[0])                       # (mx,my,W2,kv)
+                m, ni2 = O.invalid_mask(mx, my, padx, pady, W, exact, mode)
+                mine_full = (m.view(mx, my, W2, kv) if m.dim() == 3 else
+                             m.view(mx, my, 1, kv).expand(mx, my, W2, kv))
+                assert torch.equal(ref_full, mine_full), (mx, my, padx, pady, W, exact, mode)
+                assert int(ni) == int(ni2), (int(ni), int(ni2), mx, my, padx, pady, W, exact, mode)
+                key = f"g{mx}x{my}p{padx}x{pady}w{W}e{exact}m{mode}"
+                masks[key] = np.packbits(ref_full.numpy().reshape(-1))
+                masks[key + "_n"] = np.int64(int(ni))
+    np.savez_compressed(os.path.join(outdir, "masks.npz"), **masks)
+    print("masks ok:", len(masks) // 2)
+
+    # ---------------- operator level ----------------
+    ops = {}
+    worst = 0.0
+    for case in GC.OP_CASES:
+        name, BH, M, mx, my, W = case
+        for mode in GC.MODES:
+            q, k, v = GC.op_inputs(case)
+            g = torch.Generator().manual_seed(GC.SEED + 1)
+            gout = torch.randn(q.shape, generator=g, dtype=torch.float64)
+            res = {}
+            for tag, sc, msk in (("ref", ref_sc.slidingchunk_2d, ref_sc.mask_invalid_locations),
+                                 ("ora", O.slidingchunk_2d, O.mask_invalid_locations)):
+                qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+                attn = sc(qq, kk, False, mode)
+                a2 = attn.clone()
+                msk(a2, mx, my, 0, 0, W, 0, mode)
+                p = torch.softmax(a2, dim=-1)
+                out = sc(p, vv, True, mode)
+                (out * gout).sum().backward()
+                res[tag] = (attn.detach(), out.detach(), qq.grad, kk.grad, vv.grad)
+            for a, b in zip(res["ref"], res["ora"]):
+                worst = max(worst, float((a - b).abs().max()))
+            pre = f"{name}_m{mode}_"
+            for nm, t in zip(("attn", "out", "dq", "dk", "dv"), res["ref"]):
+                ops[pre + nm] = t.numpy().astype(np.float32)   # fp32 storage keeps the fixture small
+    assert worst < 1e-12, worst
+    np.savez_compressed(os.path.join(outdir, "op_cases.npz"), **ops)
+    print("operator cases ok, max |ref-oracle| =", worst)
+
+    # ---------------- module level ----------------
+    mods = {}
+    worst_out = worst_g = 0.0
+    for c in GC.MODULE_CASES:
+        params, x, dout = GC.module_inputs(c)
+        mod = ref_l2d.Long2DSCSelfAttention(
+            c["dim"], num_heads=c["H"], qkv_bias=True, w=c["W"], sharew=c["sharew"],
+            nglo=c["G"], only_glo=c["only_glo"], exact=c["exact"], autograd=False,
+            rpe=c["rpe"], mode=(1 if c["mode"] > 0 else c["mode"])).double()
+        sd = {k: v for k, v in params.items()}
+        if c["rpe"]:
+            sd["relative_position_index"] = mod.relative_position_index
+        if c["G"] == 0:
+            sd = {k: v for k, v in sd.items() if "_global" not in k}
+        mod.load_state_dict(sd)
+        mod.train()
+        orig = random.randrange
+        random.randrange = (lambda a, b=None, _m=c["mode"]: _m)
+        try:
+            xr = x.clone().requires_grad_(True)
+            out = mod(xr, c["nx"], c["ny"])
+            (out * dout).sum().backward()
+        finally:
+            random.randrange = orig
+        ref_grads = {n: p.grad for n, p in mod.named_parameters()}
+        # oracle on the same inputs
+        op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        if c["G"] >= 1 and c["sharew"]:
+            for nm in ("query", "kv", "proj"):
+                op[nm + "_global.weight"] = op[nm + ".weight"]
+                op[nm + "_global.bias"] = op[nm + ".bias"]
+        xo = x.clone().requires_grad_(True)
+        out_o = O.long2dsc_forward(op, xo, c["nx"], c["ny"], num_heads=c["H"], w=c["W"],
+                                   nglo=c["G"], rpe=c["rpe"], exact=c["exact"], mode=c["mode"],
+                                   only_glo=c["only_glo"])
+        (out_o * dout).sum().backward()
+        worst_out = max(worst_out, float((out - out_o).abs().max()))
+        worst_g = max(worst_g, float((xr.grad - xo.grad).abs().max()))
+        for n, gref in ref_grads.items():
+            if gref is None:      # e.g. g2g bias unused when... keep explicit
+                continue
+            go = op[n].grad
+            worst_g = max(worst_g, float((gref - go).abs().max()))
+        pre = c["name"] + "/"
+        items = [("out", out.detach()), ("dx", xr.grad)] + [("d_" + n, g) for n, g in ref_grads.items() if g is not None]
+        for nm, t in items:
+            if t.numel() > 4096:
+                s, sums = GC.sample_big(t)
+                mods[pre + nm + "@sample"] = s.numpy()
+                mods[pre + nm + "@sums"] = sums.numpy()
+            else:
+                mods[pre + nm] = t.numpy()
+        print(f"  module {c['name']}: ok")
+    assert worst_out < 1e-11 and worst_g < 1e-10, (worst_out, worst_g)
+    np.savez_compressed(os.path.join(outdir, "module_cases.npz"), **mods)
+    print("module cases ok, max |ref-oracle| out/grads =", worst_out, worst_g)
+
+    # exact=1 with mode != 0 raises ValueError in the reference
+    try:
+        t = torch.zeros(1, 2, 2, 16, 32, dtype=torch.float64)
+        ref_sc.mask_invalid_locations(t, 2, 2, 0, 0, 4, 1, 3)
+        raise AssertionError("reference did not raise")
+    except ValueError:
+        pass
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
