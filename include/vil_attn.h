@@ -1,0 +1,131 @@
+/* vil_attn.h -- C ABI of libvilattn.so: MI355X (gfx950) kernels for Vision
+ * Longformer's 2-D sliding-chunk local+global attention (the `longformerhand`
+ * path of microsoft/vision-longformer).
+ *
+ * The reference has no native code and no FFI (it is pure PyTorch), so this ABI
+ * is build-defined.  Each entry point names the reference Python it replaces
+ * (paths relative to the reference repository):
+ *
+ *   vil_attn_fwd   replaces, for the local-query rows of
+ *                  Long2DSCSelfAttention.forward (src/models/layers/longformer2d.py:134-204):
+ *                  chunk/pad/unfold (:134-149), local->global scores (:152-153),
+ *                  slidingchunk_2d QK^T (:157 -> slidingchunk_2d.py:26-79), bias add
+ *                  (:159-178), mask_invalid_locations (:180 -> slidingchunk_2d.py:321-357),
+ *                  concat+softmax (:183-186), slidingchunk_2d attn.V (:195 ->
+ *                  slidingchunk_2d.py:82-130), global-V term (:197-200), un-chunk+crop (:201-204).
+ *   vil_attn_bwd   replaces SlidingChunk2D.backward (slidingchunk_2d.py:234-246,
+ *                  slidingchunk_agrad :132-200) plus the autograd of the softmax /
+ *                  bias gather / mask in between.
+ *
+ * Conventions: plain pointers and sizes only; all device buffers (inputs,
+ * outputs, workspace) are caller-owned; calls are asynchronous on `stream`
+ * (a hipStream_t passed as void*), never allocate, never synchronise, keep no
+ * global mutable state.  Return value: 0 = success, negative = argument error
+ * (VIL_E_*), positive = hipError_t of the failing launch.
+ *
+ * Tensor layout: q is addressed as q[b*q_sb + i*q_st + h*q_sh + d] with
+ * i in [0, nx*ny) the local token (row-major r*ny+c), d in [0, M) contiguous.
+ * k and v are addressed with token j in [0, G + nx*ny): the G global tokens
+ * come first (rows 0..G-1), locals follow -- i.e. the views of the reference's
+ * `kv(x)` output are passed without copies.  Strides are in elements.
+ */
+#ifndef VIL_ATTN_H
+#define VIL_ATTN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIL_ATTN_ABI_VERSION 1
+
+enum { VIL_DTYPE_F32 = 0, VIL_DTYPE_BF16 = 1 };
+
+enum {
+  VIL_OK = 0,
+  VIL_E_NULL = -1,        /* required pointer is NULL                      */
+  VIL_E_SHAPE = -2,       /* non-positive / inconsistent sizes             */
+  VIL_E_HEAD_DIM = -3,    /* head_dim M not supported by any kernel        */
+  VIL_E_WINDOW = -4,      /* W not supported                               */
+  VIL_E_MODE = -5,        /* mode not in [-1, 8]                           */
+  VIL_E_EXACT = -6,       /* exact not in {-1,0,1}, or exact==1 with mode!=0
+                             (the reference raises ValueError there,
+                             slidingchunk_2d.py:331-343)                    */
+  VIL_E_DTYPE = -7,
+  VIL_E_ALIGN = -8,       /* pointer/stride alignment unusable             */
+  VIL_E_WORKSPACE = -9,   /* workspace NULL although bytes > 0             */
+  VIL_E_BACKEND = -10     /* requested kernel family cannot run this desc  */
+};
+
+/* kernel family selection (desc.backend) */
+enum { VIL_BACKEND_AUTO = 0, VIL_BACKEND_SCALAR = 1, VIL_BACKEND_MFMA = 2 };
+
+typedef struct VilAttnDesc {
+  int32_t B, H, M;          /* images, heads, head_dim                                   */
+  int32_t nx, ny;           /* local token grid (rows, cols)                             */
+  int32_t W;                /* one-sided window = chunk side (arch flag f)               */
+  int32_t G;                /* number of global tokens = leading rows of k/v             */
+  int32_t mode;             /* 0: 3x3 chunks, -1: own chunk, 1..8: own + one neighbour   */
+  int32_t exact;            /* 0 zero-pad chunks, -1 cyclic chunks, 1 exact window       */
+  int32_t dtype;            /* VIL_DTYPE_* of q/k/v/out/dout/dq/dk/dv                    */
+  int32_t only_glo;         /* local rows attend the global tokens only                  */
+  int32_t backend;          /* VIL_BACKEND_*                                             */
+  float   scale;            /* softmax scale; scores = scale*q.k + bias                  */
+  int32_t reserved;
+  int64_t q_sb, q_st, q_sh; /* element strides (batch, token, head)                      */
+  int64_t k_sb, k_st, k_sh;
+  int64_t v_sb, v_st, v_sh;
+  int64_t o_sb, o_st, o_sh;       /* out                                                 */
+  int64_t do_sb, do_st, do_sh;    /* dout                                                */
+  int64_t dq_sb, dq_st, dq_sh;
+  int64_t dk_sb, dk_st, dk_sh;
+  int64_t dv_sb, dv_st, dv_sh;
+} VilAttnDesc;
+
+int vil_attn_abi_version(void);
+const char* vil_attn_strerror(int code);
+
+/* 0 if the descriptor can be run (by desc->backend, or by any backend for
+ * AUTO), else the VIL_E_* the launch would return. */
+int vil_attn_check(const VilAttnDesc* d);
+
+/* bytes of scratch the forward (pass=0) / backward (pass=1) needs */
+size_t vil_attn_workspace_bytes(const VilAttnDesc* d, int pass);
+
+/* out[b,i,h,:] = softmax_j(scale*q_i.k_j + bias_ij | allowed keys) v_j ;
+ * lse[(b*H+h)*Nloc + i] = natural-log-sum-exp of row i (float32).
+ * bias_table: float32 ((4W-1)^2, H) row-major or NULL (rpe off);
+ * g2l: float32 (H, G) = g2l_relative_position_bias[1] or NULL. */
+int vil_attn_fwd(const VilAttnDesc* d, const void* q, const void* k, const void* v,
+                 const float* bias_table, const float* g2l,
+                 void* out, float* lse, void* workspace, void* stream);
+
+/* dq/dk/dv are fully overwritten (every row of dk/dv, including the G global
+ * rows, which receive the local rows' contribution).  dbias_table ((4W-1)^2,H)
+ * and dg2l (H,G) are float32, overwritten; they may be NULL when bias_table /
+ * g2l are NULL. */
+int vil_attn_bwd(const VilAttnDesc* d, const void* q, const void* k, const void* v,
+                 const void* out, const void* dout, const float* lse,
+                 const float* bias_table, const float* g2l,
+                 void* dq, void* dk, void* dv, float* dbias_table, float* dg2l,
+                 void* workspace, void* stream);
+
+/* ---- host-side geometry helpers (pure CPU, used by the tests to pin the
+ * kernels' index/mask logic against the golden masks without a GPU) -------- */
+
+/* Fills mask[(m*my+n)*W2*kv + l*kv + s] (1 = key slot s is NOT attended by
+ * query l of chunk (m,n)) for the given grid; kv = 9W^2 / W^2 / 2W^2 by mode,
+ * slots in the reference's order.  Mirrors mask_invalid_locations
+ * (slidingchunk_2d.py:321-357).  Returns kv, or a VIL_E_* code. */
+int vil_geom_mask(int nx, int ny, int W, int exact, int mode, uint8_t* mask);
+
+/* rel[l*kv + s] = index into the ((4W-1)^2) bias table used by query l for
+ * key slot s (longformer2d.py:67-100 with the mode's column subset :164-173). */
+int vil_geom_bias_index(int W, int mode, int32_t* rel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIL_ATTN_H */

@@ -1,0 +1,134 @@
+"""CPU: the C-ABI library loads, exports every symbol include/vil_attn.h declares,
+validates arguments like the reference does, and its host-side geometry helpers
+(the SAME inline functions the kernels use for masks / bias indices) reproduce
+the golden masks and the reference's relative_position_index bit for bit.
+No compute call is made here (no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as GC
+from vision_longformer_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "vil_attn.h")).read()
+    declared = set(re.findall(r"\b(vil_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.vil_attn_abi_version() == 1
+    assert L.vil_attn_strerror(0) == b"ok"
+    assert b"exact" in L.vil_attn_strerror(-6)
+
+
+def test_desc_struct_matches_header_size():
+    # 12 int32 + float + int32 + 24 int64
+    assert ctypes.sizeof(_lib.VilAttnDesc) == 14 * 4 + 24 * 8
+
+
+def _desc(**kw):
+    d = _lib.VilAttnDesc()
+    base = dict(B=2, H=2, M=16, nx=8, ny=8, W=4, G=1, mode=0, exact=0, dtype=_lib.DTYPE_F32, only_glo=0,
+                backend=_lib.BACKEND_AUTO, scale=0.25)
+    base.update(kw)
+    for k, v in base.items():
+        setattr(d, k, v)
+    return d
+
+
+def test_argument_validation():
+    L = _lib.lib()
+    assert L.vil_attn_check(ctypes.byref(_desc())) == 0
+    assert L.vil_attn_check(ctypes.byref(_desc(mode=9))) == -5
+    assert L.vil_attn_check(ctypes.byref(_desc(exact=2))) == -6
+    # exact=1 with mode!=0: the reference raises ValueError (slidingchunk_2d.py:331-343)
+    assert L.vil_attn_check(ctypes.byref(_desc(exact=1, mode=3))) == -6
+    assert L.vil_attn_check(ctypes.byref(_desc(M=7, backend=_lib.BACKEND_SCALAR))) == -3
+    assert L.vil_attn_check(ctypes.byref(_desc(dtype=5))) == -7
+    assert L.vil_attn_check(ctypes.byref(_desc(B=0))) == -2
+    # NULL pointers are rejected before any launch
+    d = _desc()
+    assert L.vil_attn_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None, None) == -1
+    assert L.vil_attn_workspace_bytes(ctypes.byref(d), 1) > 0
+
+
+@pytest.mark.parametrize("grid", GC.MASK_GRIDS, ids=lambda g: "g%dx%dp%dx%dw%d" % g)
+def test_geometry_masks_bit_exact(golden_dir, grid):
+    L = _lib.lib()
+    gold = np.load(os.path.join(golden_dir, "masks.npz"))
+    mx, my, padx, pady, W = grid
+    nx, ny = mx * W - padx, my * W - pady
+    W2 = W * W
+    for exact in (0, -1, 1):
+        for mode in GC.MODES:
+            if exact == 1 and mode != 0:
+                assert L.vil_geom_mask(nx, ny, W, exact, mode, ctypes.c_void_p(1)) == -6
+                continue
+            kv = {0: 9 * W2, -1: W2}.get(mode, 2 * W2)
+            buf = np.zeros(mx * my * W2 * kv, dtype=np.uint8)
+            assert L.vil_geom_mask(nx, ny, W, exact, mode, buf.ctypes.data_as(ctypes.c_void_p)) == kv
+            key = f"g{mx}x{my}p{padx}x{pady}w{W}e{exact}m{mode}"
+            ref = np.unpackbits(gold[key])[:buf.size]
+            assert np.array_equal(ref, buf), key
+
+
+@pytest.mark.parametrize("W", [2, 3, 4, 6, 7, 8, 12])
+def test_geometry_bias_index(golden_dir, W):
+    L = _lib.lib()
+    gold = np.load(os.path.join(golden_dir, "rel_index.npz"))[f"W{W}"]
+    W2 = W * W
+    for mode in GC.MODES:
+        kv = {0: 9 * W2, -1: W2}.get(mode, 2 * W2)
+        buf = np.zeros(W2 * kv, dtype=np.int32)
+        assert L.vil_geom_bias_index(W, mode, buf.ctypes.data_as(ctypes.c_void_p)) == kv
+        if mode == 0:
+            cols = np.arange(9 * W2)
+        elif mode == -1:
+            cols = np.arange(4 * W2, 5 * W2)
+        else:
+            cid = mode if mode > 4 else mode - 1
+            cols = np.concatenate([np.arange(4 * W2, 5 * W2), np.arange(cid * W2, (cid + 1) * W2)])
+        assert np.array_equal(buf.reshape(W2, kv), gold[:, cols]), (W, mode)
+
+
+def test_module_state_dict_contract(golden_dir):
+    """Parameter / buffer names and shapes of the drop-in module."""
+    from vision_longformer_amd.longformer2d import Long2DSCSelfAttention, build_relative_position_index
+    m = Long2DSCSelfAttention(96, num_heads=3, qkv_bias=True, w=7, sharew=True, nglo=1, rpe=True)
+    sd = m.state_dict()
+    expect = {
+        "query.weight": (96, 96), "query.bias": (96,), "kv.weight": (192, 96), "kv.bias": (192,),
+        "proj.weight": (96, 96), "proj.bias": (96,),
+        "query_global.weight": (96, 96), "query_global.bias": (96,), "kv_global.weight": (192, 96),
+        "kv_global.bias": (192,), "proj_global.weight": (96, 96), "proj_global.bias": (96,),
+        "local_relative_position_bias_table": (729, 3), "g2l_relative_position_bias": (2, 3, 1),
+        "g2g_relative_position_bias": (3, 1, 1), "relative_position_index": (49, 441),
+    }
+    assert {k: tuple(v.shape) for k, v in sd.items()} == expect
+    assert sd["relative_position_index"].dtype == torch.int64
+    # sharew aliases are de-duplicated in parameters()
+    assert len(list(m.parameters())) == 9
+    m2 = Long2DSCSelfAttention(32, num_heads=2, qkv_bias=True, w=4, sharew=False, nglo=1, rpe=True)
+    assert len(list(m2.parameters())) == 15
+    gold = np.load(os.path.join(golden_dir, "rel_index.npz"))
+    for W in (2, 3, 4, 6, 7, 8, 12):
+        assert np.array_equal(build_relative_position_index(W).numpy(), gold[f"W{W}"].astype(np.int64))
+    for attr in ("mode", "Nglo", "num_heads", "head_dim", "attention_window", "only_glo", "exact", "rpe", "scale"):
+        assert hasattr(m, attr)
+
+
+def test_product_path_has_no_cpu_fallback():
+    from vision_longformer_amd.longformer2d import Long2DSCSelfAttention
+    m = Long2DSCSelfAttention(32, num_heads=2, qkv_bias=True, w=4, nglo=1, rpe=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(1, 65, 32), 8, 8)
+    with pytest.raises(AssertionError):
+        m(torch.randn(1, 64, 32), 8, 8)   # "Global dimension does not match!"

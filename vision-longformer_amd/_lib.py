@@ -1,0 +1,70 @@
+"""ctypes binding of libvilattn.so (C ABI: include/vil_attn.h).
+
+The product path has no CPU fallback: if the shared library has not been built
+(``python -c 'import __graft_entry__ as g; g.build()'``) every entry point
+raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvilattn.so")
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+BACKEND_AUTO, BACKEND_SCALAR, BACKEND_MFMA = 0, 1, 2
+ABI_VERSION = 1
+
+EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_attn_workspace_bytes",
+           "vil_attn_fwd", "vil_attn_bwd", "vil_geom_mask", "vil_geom_bias_index")
+
+
+class VilAttnDesc(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_int32) for n in
+                 ("B", "H", "M", "nx", "ny", "W", "G", "mode", "exact", "dtype", "only_glo", "backend")] +
+                [("scale", ctypes.c_float), ("reserved", ctypes.c_int32)] +
+                [(t + s, ctypes.c_int64) for t in ("q", "k", "v", "o", "do", "dq", "dk", "dv")
+                 for s in ("_sb", "_st", "_sh")])
+
+
+class VilAttnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvilattn error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run __graft_entry__.build()).  There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, fp = ctypes.c_void_p, ctypes.c_void_p
+        dp = ctypes.POINTER(VilAttnDesc)
+        L.vil_attn_abi_version.restype = ctypes.c_int
+        L.vil_attn_strerror.restype = ctypes.c_char_p
+        L.vil_attn_strerror.argtypes = [ctypes.c_int]
+        L.vil_attn_check.restype = ctypes.c_int
+        L.vil_attn_check.argtypes = [dp]
+        L.vil_attn_workspace_bytes.restype = ctypes.c_size_t
+        L.vil_attn_workspace_bytes.argtypes = [dp, ctypes.c_int]
+        L.vil_attn_fwd.restype = ctypes.c_int
+        L.vil_attn_fwd.argtypes = [dp, vp, vp, vp, fp, fp, vp, fp, vp, vp]
+        L.vil_attn_bwd.restype = ctypes.c_int
+        L.vil_attn_bwd.argtypes = [dp, vp, vp, vp, vp, vp, fp, fp, fp, vp, vp, vp, fp, fp, vp, vp]
+        L.vil_geom_mask.restype = ctypes.c_int
+        L.vil_geom_mask.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p]
+        L.vil_geom_bias_index.restype = ctypes.c_int
+        L.vil_geom_bias_index.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        if L.vil_attn_abi_version() != ABI_VERSION:
+            raise RuntimeError("libvilattn.so ABI version mismatch; rebuild it")
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise VilAttnError(code, lib().vil_attn_strerror(code).decode())

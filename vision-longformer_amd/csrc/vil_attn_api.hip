@@ -1,0 +1,148 @@
+// vil_attn_api.hip -- the C ABI of libvilattn.so (see include/vil_attn.h):
+// argument validation, kernel-family dispatch, and the host-side geometry
+// helpers the CPU tests use to pin the kernels' mask / bias-index logic.
+#include "vil_internal.h"
+#include <string.h>
+
+extern "C" int vil_attn_abi_version(void) { return VIL_ATTN_ABI_VERSION; }
+
+extern "C" const char* vil_attn_strerror(int code) {
+  switch (code) {
+    case VIL_OK: return "ok";
+    case VIL_E_NULL: return "required pointer is NULL";
+    case VIL_E_SHAPE: return "invalid or inconsistent sizes";
+    case VIL_E_HEAD_DIM: return "unsupported head_dim";
+    case VIL_E_WINDOW: return "unsupported window size";
+    case VIL_E_MODE: return "mode must be in [-1, 8]";
+    case VIL_E_EXACT: return "longsc exact should be in [0,1,-1] (exact=1 requires mode 0)";
+    case VIL_E_DTYPE: return "unsupported dtype";
+    case VIL_E_ALIGN: return "pointer or stride alignment not supported";
+    case VIL_E_WORKSPACE: return "workspace is NULL but workspace_bytes > 0";
+    case VIL_E_BACKEND: return "requested backend cannot run this descriptor";
+    default: break;
+  }
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "unknown error";
+}
+
+static int check_common(const VilAttnDesc* d) {
+  if (!d) return VIL_E_NULL;
+  if (d->B <= 0 || d->H <= 0 || d->M <= 0 || d->nx <= 0 || d->ny <= 0 || d->W <= 0 || d->G < 0)
+    return VIL_E_SHAPE;
+  if (d->only_glo && d->G < 1) return VIL_E_SHAPE;
+  if (d->mode < -1 || d->mode > 8) return VIL_E_MODE;
+  if (d->exact < -1 || d->exact > 1) return VIL_E_EXACT;
+  if (d->exact == 1 && d->mode != 0 && !d->only_glo) return VIL_E_EXACT;
+  if (d->dtype != VIL_DTYPE_F32 && d->dtype != VIL_DTYPE_BF16) return VIL_E_DTYPE;
+  return VIL_OK;
+}
+
+static int pick_backend(const VilAttnDesc* d, int pass) {
+  const int want = d->backend;
+  if (want == VIL_BACKEND_SCALAR) return vil_scalar_supported(d) == VIL_OK ? VIL_BACKEND_SCALAR : 0;
+  if (want == VIL_BACKEND_MFMA) return vil_mfma_supported(d, pass) == VIL_OK ? VIL_BACKEND_MFMA : 0;
+  if (vil_mfma_supported(d, pass) == VIL_OK) return VIL_BACKEND_MFMA;
+  if (vil_scalar_supported(d) == VIL_OK) return VIL_BACKEND_SCALAR;
+  return 0;
+}
+
+extern "C" int vil_attn_check(const VilAttnDesc* d) {
+  int e = check_common(d);
+  if (e) return e;
+  if (d->backend == VIL_BACKEND_SCALAR) return vil_scalar_supported(d);
+  if (d->backend == VIL_BACKEND_MFMA) {
+    e = vil_mfma_supported(d, 0);
+    return e ? e : vil_mfma_supported(d, 1);
+  }
+  if (d->backend != VIL_BACKEND_AUTO) return VIL_E_BACKEND;
+  return vil_scalar_supported(d) == VIL_OK ? VIL_OK : vil_mfma_supported(d, 0);
+}
+
+extern "C" size_t vil_attn_workspace_bytes(const VilAttnDesc* d, int pass) {
+  if (check_common(d)) return 0;
+  // the union of both families, so the caller may switch backend per call
+  size_t a = vil_scalar_supported(d) == VIL_OK ? vil_scalar_workspace(d, pass) : 0;
+  size_t b = vil_mfma_supported(d, pass) == VIL_OK ? vil_mfma_workspace(d, pass) : 0;
+  return a > b ? a : b;
+}
+
+extern "C" int vil_attn_fwd(const VilAttnDesc* d, const void* q, const void* k, const void* v,
+                            const float* bias_table, const float* g2l,
+                            void* out, float* lse, void* workspace, void* stream) {
+  int e = check_common(d);
+  if (e) return e;
+  if (!q || !k || !v || !out || !lse) return VIL_E_NULL;
+  const int be = pick_backend(d, 0);
+  if (!be) return d->backend == VIL_BACKEND_AUTO ? vil_scalar_supported(d) : VIL_E_BACKEND;
+  if (!workspace && vil_attn_workspace_bytes(d, 0) > 0) return VIL_E_WORKSPACE;
+  VilParams p; memset(&p, 0, sizeof(p));
+  vil_fill_params(p, d);
+  p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse;
+  p.table = bias_table; p.g2l = g2l;
+  p.has_bias = bias_table != nullptr; p.has_g2l = (g2l != nullptr) && d->G > 0;
+  p.delta = (float*)workspace;
+  return be == VIL_BACKEND_MFMA ? vil_mfma_fwd(d, p, (hipStream_t)stream)
+                                : vil_scalar_fwd(d, p, (hipStream_t)stream);
+}
+
+extern "C" int vil_attn_bwd(const VilAttnDesc* d, const void* q, const void* k, const void* v,
+                            const void* out, const void* dout, const float* lse,
+                            const float* bias_table, const float* g2l,
+                            void* dq, void* dk, void* dv, float* dbias_table, float* dg2l,
+                            void* workspace, void* stream) {
+  int e = check_common(d);
+  if (e) return e;
+  if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv) return VIL_E_NULL;
+  if (bias_table && !dbias_table) return VIL_E_NULL;
+  if (g2l && d->G > 0 && !dg2l) return VIL_E_NULL;
+  const int be = pick_backend(d, 1);
+  if (!be) return d->backend == VIL_BACKEND_AUTO ? vil_scalar_supported(d) : VIL_E_BACKEND;
+  if (!workspace && vil_attn_workspace_bytes(d, 1) > 0) return VIL_E_WORKSPACE;
+  VilParams p; memset(&p, 0, sizeof(p));
+  vil_fill_params(p, d);
+  p.q = q; p.k = k; p.v = v; p.out = out; p.dout = dout; p.lse = (float*)lse;
+  p.table = bias_table; p.g2l = g2l;
+  p.has_bias = bias_table != nullptr; p.has_g2l = (g2l != nullptr) && d->G > 0;
+  p.dq = dq; p.dk = dk; p.dv = dv; p.dtable = dbias_table; p.dg2l = dg2l;
+  p.delta = (float*)workspace;
+  return be == VIL_BACKEND_MFMA ? vil_mfma_bwd(d, p, (hipStream_t)stream)
+                                : vil_scalar_bwd(d, p, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------ host geometry helpers
+extern "C" int vil_geom_mask(int nx, int ny, int W, int exact, int mode, uint8_t* mask) {
+  if (!mask) return VIL_E_NULL;
+  if (nx <= 0 || ny <= 0 || W <= 0) return VIL_E_SHAPE;
+  if (mode < -1 || mode > 8) return VIL_E_MODE;
+  if (exact < -1 || exact > 1 || (exact == 1 && mode != 0)) return VIL_E_EXACT;
+  VilGeom g; vil_geom_init(g, nx, ny, W, exact, mode);
+  const int kv = g.nact * g.W2;
+  for (int m = 0; m < g.mx; ++m)
+    for (int n = 0; n < g.my; ++n)
+      for (int l = 0; l < g.W2; ++l) {
+        const int qr = m * W + l / W, qc = n * W + l % W;
+        uint8_t* row = mask + ((size_t)(m * g.my + n) * g.W2 + l) * kv;
+        for (int a = 0; a < g.nact; ++a)
+          for (int t = 0; t < g.W2; ++t) {
+            int kr, kc;
+            int st = vil_key_state(g, m, n, g.adr[a], g.adc[a], t / W, t % W, kr, kc);
+            if (st != VIL_KEY_MASKED && exact == 1 && !vil_exact_window(W, qr, qc, kr, kc))
+              st = VIL_KEY_MASKED;
+            row[a * g.W2 + t] = st == VIL_KEY_MASKED;
+          }
+      }
+  return kv;
+}
+
+extern "C" int vil_geom_bias_index(int W, int mode, int32_t* rel) {
+  if (!rel) return VIL_E_NULL;
+  if (W <= 0) return VIL_E_SHAPE;
+  if (mode < -1 || mode > 8) return VIL_E_MODE;
+  VilGeom g; vil_geom_init(g, W, W, W, 0, mode);
+  const int kv = g.nact * g.W2;
+  for (int l = 0; l < g.W2; ++l)
+    for (int a = 0; a < g.nact; ++a)
+      for (int t = 0; t < g.W2; ++t)
+        rel[l * kv + a * g.W2 + t] = vil_bias_index(W, l / W, l % W, g.adr[a], g.adc[a], t / W, t % W);
+  return kv;
+}

@@ -1,0 +1,446 @@
+// vil_attn_mfma.hip -- the MFMA kernel family (bf16 I/O, fp32 accumulate) for
+// gfx950 / CDNA4.  Forward: QK^T-within-window, relative-position bias, mask,
+// online softmax and .V fused in one pass; nothing but q/k/v/out/lse touches HBM.
+//
+// Work decomposition.  One 64-lane wavefront owns one query chunk of one
+// (image, head) -- W*W queries in 64 "query slots" -- and walks the key slots
+// of its 3x3 chunk neighbourhood (+ the G global keys) in steps of 32 keys.
+// Waves never synchronise with each other after the workgroup's bias table
+// is in LDS: each wave has private LDS for its slot table and its V tile.
+//
+//   S^T tile (16 keys x 16 queries)  = mfma_16x16x32_bf16(A = K rows, B = Q rows, C = bias)
+//        K and Q fragments are loaded straight from HBM/L2 (8 contiguous head
+//        dims per lane = the natural row layout, 16-byte loads); the bias (and
+//        the -inf of masked / out-of-image keys, and the exact-window mask) enters
+//        as the accumulator's initial value, gathered from an LDS copy of this
+//        head's bias table: one ds_read_b128 returns the bias of one key for the
+//        lane's four y-consecutive queries, so bias + mask cost 3 VALU per 4 scores.
+//   softmax: a lane holds 8 keys x 1 query per step; the row maximum is
+//        deferred (only when a score exceeds the running maximum by > 8 nats
+//        does the wave re-synchronise maxima across its four lane groups and
+//        rescale), p = exp2(fma(s, c, -m c)).
+//   O^T tile (16 dims x 16 queries) += mfma(A = V^T, B = P^T): P^T is the S^T
+//        accumulator itself (bf16-packed, no cross-lane movement: the key
+//        permutation it implies is applied to V^T instead); V^T comes from the
+//        wave's LDS V tile through ds_read_b64_tr_b16.  The row sums come from a
+//        third MFMA against a constant ones-row, so the VALU never adds them.
+//
+// Reference semantics: src/models/layers/longformer2d.py:134-204 (see include/vil_attn.h).
+#include "vil_internal.h"
+#include <string.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define VIL_MASK_VAL (-1.0e30f)
+#define VIL_M_INIT (-1.0e20f)
+#define LOG2E 1.4426950408889634f
+
+struct MfmaCfg {
+  int P;             // row pitch (floats) of the LDS bias table
+  int copysize;      // floats per table copy (multiple of 4)
+  int cstride_b;     // (copysize - 1) * 4: byte offset between consecutive shifted copies
+  int guard0;        // start (floats) of the all-masked region
+  int glo0;          // start of the per-global-token constant regions
+  int gsz;           // size of one such region (Aq range + 4)
+  int aconst;        // (2W-1)*(P+1)
+  unsigned magicW, magicW2;
+  int HQ;            // query quads per chunk row = ceil(W/4)
+  int NWP;           // waves per chunk = ceil(W*HQ/16)
+  int NS;            // real key slots = G + nact*W2
+  int NSP;           // padded to a multiple of 32
+  int units_bh;      // mx*my*NWP
+  int wg_per_bh, gpw;
+  int wave_lds;      // bytes of private LDS per wave
+  int no_tr;         // debug: read V^T with scalar LDS loads instead of ds_read_b64_tr_b16
+  const float* tabws;  // (H, 4*copysize) prepared bias tables
+};
+
+__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned magic) { return __umulhi(n, magic); }
+
+// ------------------------------------------------------------------ table prologue
+// Logical table of one head, stored 4 times, copy c shifted by c floats so that any
+// 4-float run starts 16-byte aligned in copy (start & 3):
+//   [ (4W-1) rows x P : bias/scale (exact==1: -inf outside the (2W+1)^2 window) |
+//     gsz x -inf (masked / padded key slots) | G x gsz x g2l[h][g]/scale ]
+__global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out) {
+  const int h = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * c.copysize) return;
+  const int cp = i / c.copysize, pos = i % c.copysize;
+  const int e = pos + cp;
+  const int tbl = p.g.tbl, W = p.g.W;
+  const float inv = 1.0f / p.scale;
+  float v = 0.f;
+  if (e < tbl * c.P) {
+    const int row = e / c.P, col = e % c.P;
+    if (col < tbl) {
+      if (p.has_bias) v = p.table[(int64_t)(row * tbl + col) * p.H + h] * inv;
+      const int dx = row - (2 * W - 1), dy = col - (2 * W - 1);
+      if (p.g.exact == 1 && (dx > W || dx < -W || dy > W || dy < -W)) v = VIL_MASK_VAL;
+    }
+  } else if (e < c.glo0) {
+    v = VIL_MASK_VAL;
+  } else {
+    const int g = (e - c.glo0) / c.gsz;
+    if (g < p.G && p.has_g2l) v = p.g2l[h * p.G + g] * inv;
+  }
+  out[(int64_t)h * 4 * c.copysize + i] = v;
+}
+
+// ------------------------------------------------------------------ forward
+template <int MD>
+__global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
+  constexpr int M = 16 * MD;
+  constexpr int MK = (MD + 1) / 2;            // 32-wide K steps over the head dim
+  constexpr int VCH = 2 * MD;                 // 16-byte chunks per V row
+  constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;  // V tile XOR swizzle needs rows that are multiples of 64 B
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const VilGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lj = lane & 15, lg = lane >> 4;
+
+  // XCD-aware bijective remap: consecutive logical workgroups (same image/head,
+  // neighbouring chunks -> shared K/V) land on the same XCD's L2
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bh = logical / c.wg_per_bh, wgi = logical % c.wg_per_bh;
+  const int b = bh / p.H, h = bh % p.H;
+
+  float* tab = (float*)smem;
+  {
+    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * 4 * c.copysize);
+    for (int i = tid; i < c.copysize; i += 256) ((f32x4*)tab)[i] = src[i];
+  }
+  __syncthreads();
+
+  char* wbase = smem + (size_t)c.copysize * 16 + (size_t)wave * c.wave_lds;
+  int* s_koff = (int*)wbase;                       // [NSP] token offset (elements) of each key slot
+  int* s_akey = s_koff + c.NSP;                    // [NSP] bias-table address term (bytes)
+  __bf16* s_v = (__bf16*)(s_akey + c.NSP);         // [32][M] V tile of the current step
+
+  const __bf16* qb = (const __bf16*)p.q + b * p.q_sb + h * p.q_sh;
+  const __bf16* kb = (const __bf16*)p.k + b * p.k_sb + h * p.k_sh;
+  const __bf16* vb = (const __bf16*)p.v + b * p.v_sb + h * p.v_sh;
+  __bf16* ob = (__bf16*)p.o + b * p.o_sb + h * p.o_sh;
+  const int Nloc = g.nx * g.ny;
+  const float c1 = p.scale * LOG2E;               // scores are kept unscaled: s*c1 is log2-domain
+  const float thr = 8.0f / p.scale;               // deferred-max threshold (8 nats)
+  const int W = g.W, W2 = g.W2;
+
+  // constant A operand whose row 0 is all ones: D[0][j] = sum_k P^T[k][j]
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)(lj == 0 ? 1.0f : 0.0f);
+
+  for (int gi = 0; gi < c.gpw; ++gi) {
+    const int unit = (wgi * c.gpw + gi) * 4 + wave;
+    if (unit >= c.units_bh) break;
+    const int wp = unit % c.NWP, ch = unit / c.NWP;
+    const int cn = ch % g.my, cm = ch / g.my;
+
+    // ---- key slot table (wave-private LDS)
+    const int own_tok = p.G + (cm * W) * g.ny + cn * W;     // always a real token
+    for (int s = lane; s < c.NSP; s += 64) {
+      int tok = own_tok, ak = -c.guard0;
+      if (s < p.G) {
+        tok = s; ak = -(c.glo0 + s * c.gsz);
+      } else if (s < c.NS) {
+        const unsigned sl = s - p.G;
+        const int a = fdiv(sl, c.magicW2), t = sl - a * W2;
+        const int xt = fdiv(t, c.magicW), yt = t - xt * W;
+        // neighbour offset of active slot a, without a divergent lookup into the kernarg arrays
+        const int a3 = (a * 11) >> 5;                       // a / 3 for a in [0, 9)
+        const int dr = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : g.adr[1]);
+        const int dc = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : g.adc[1]);
+        int kr, kc;
+        if (vil_key_state(g, cm, cn, dr, dc, xt, yt, kr, kc) == VIL_KEY_REAL) {
+          tok = p.G + kr * g.ny + kc;
+          ak = (dr * W + xt) * c.P + (dc * W + yt) - c.aconst;
+        }
+      }
+      s_koff[s] = tok; s_akey[s] = ak * 4;
+    }
+
+    // ---- query slots of this lane: column j of q-tile qt is query (x, y = 4*hq + qt)
+    const int jj = wp * 16 + lj;
+    const int qx = jj / c.HQ, qhq = jj % c.HQ;
+    const int aq0b = (min(qx, W - 1) * c.P + 4 * qhq) * 4;   // bytes; + 4*qt per q-tile
+    int qtok[4];
+    bool qreal[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const int qy = 4 * qhq + qt;
+      const int qr = cm * W + qx, qc = cn * W + qy;
+      qreal[qt] = qx < W && qy < W && qr < g.nx && qc < g.ny;
+      qtok[qt] = qreal[qt] ? qr * g.ny + qc : own_tok - p.G;
+    }
+    bf16x8 qf[MK][4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int ks = 0; ks < MK; ++ks) {
+        const int d0 = ks * 32 + lg * 8;
+        bf16x8 z = {};
+        qf[ks][qt] = d0 < M ? *(const bf16x8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
+      }
+
+    f32x4 o[MD][4], lacc[4];
+    float mrow[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      mrow[qt] = VIL_M_INIT;
+      lacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dt = 0; dt < MD; ++dt) o[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const int nsteps = c.NSP >> 5;
+    // prefetch registers for step 0
+    bf16x8 kf[2][MK];
+    u32x4 vr[MD];
+    auto load_step = [&](int st) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int tok = s_koff[st * 32 + hf * 16 + lj];
+#pragma unroll
+        for (int ks = 0; ks < MK; ++ks) {
+          const int d0 = ks * 32 + lg * 8;
+          bf16x8 z = {};
+          kf[hf][ks] = d0 < M ? *(const bf16x8*)(kb + (int64_t)tok * p.k_st + d0) : z;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < MD; ++it) {
+        const int cid = it * 64 + lane;
+        const int row = cid / VCH, chn = cid % VCH;
+        const int tok = s_koff[st * 32 + row];
+        vr[it] = *(const u32x4*)(vb + (int64_t)tok * p.v_st + chn * 8);
+      }
+    };
+    load_step(0);
+
+    for (int st = 0; st < nsteps; ++st) {
+      // ---- this step's operands: K fragments (registers), V tile (LDS), bias addresses
+      bf16x8 kc_[2][MK];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int ks = 0; ks < MK; ++ks) kc_[hf][ks] = kf[hf][ks];
+#pragma unroll
+      for (int it = 0; it < MD; ++it) {
+        const int cid = it * 64 + lane;
+        const int row = cid / VCH, chn = cid % VCH;
+        *(u32x4*)((char*)s_v + row * (M * 2) + ((chn * 16) ^ (SWZ * (((row >> 2) & 1) << 5)))) = vr[it];
+      }
+      int ak[2][4];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const i32x4 a4 = *(const i32x4*)(s_akey + st * 32 + hf * 16 + lg * 4);
+        ak[hf][0] = a4[0]; ak[hf][1] = a4[1]; ak[hf][2] = a4[2]; ak[hf][3] = a4[3];
+      }
+      if (st + 1 < nsteps) load_step(st + 1);
+
+      // ---- S^T = K Q^T + bias   (accumulator initialised with the gathered bias)
+      f32x4 sc[2][4];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        f32x4 bq[4];            // bq[r] = bias of key r for the lane's 4 q-tiles
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned i0 = (unsigned)(aq0b - ak[hf][r]);
+          const unsigned addr = i0 + ((i0 >> 2) & 3u) * (unsigned)c.cstride_b;
+          bq[r] = *(const f32x4*)((const char*)tab + addr);
+        }
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+          f32x4 acc = {bq[0][qt], bq[1][qt], bq[2][qt], bq[3][qt]};
+#pragma unroll
+          for (int ks = 0; ks < MK; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_[hf][ks], qf[ks][qt], acc, 0, 0, 0);
+          sc[hf][qt] = acc;
+        }
+      }
+
+      // ---- online softmax, deferred max
+      bf16x8 pb[4];
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        float pm = fmaxf(fmaxf(fmaxf(sc[0][qt][0], sc[0][qt][1]), fmaxf(sc[0][qt][2], sc[0][qt][3])),
+                         fmaxf(fmaxf(sc[1][qt][0], sc[1][qt][1]), fmaxf(sc[1][qt][2], sc[1][qt][3])));
+        if (__any(pm > mrow[qt] + thr)) {
+          pm = fmaxf(pm, __shfl_xor(pm, 16, 64));
+          pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
+          const float mn = fmaxf(mrow[qt], pm);
+          const float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mn) * c1);
+          mrow[qt] = mn;
+          lacc[qt] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < MD; ++dt) o[dt][qt] *= alpha;
+        }
+        const float mc = mrow[qt] * c1;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            pb[qt][hf * 4 + r] = (__bf16)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[hf][qt][r], c1, -mc));
+      }
+
+      // ---- O^T += V^T P^T ; row sums via the ones-row
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int dt = 0; dt < MD; ++dt) {
+        bf16x8 vt;
+        if (!c.no_tr) {
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int row = hf * 16 + lg * 4 + (lj >> 2);
+            const int off = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
+            const s16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)((char*)s_v + off));
+            const bf16x4 tb = __builtin_bit_cast(bf16x4, t4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vt[hf * 4 + e] = tb[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int row = (e >> 2) * 16 + lg * 4 + (e & 3);
+            const int bcol = (dt * 16 + lj) * 2;
+            const int off = row * (M * 2) + (bcol ^ (SWZ * (((row >> 2) & 1) << 5)));
+            vt[e] = *(const __bf16*)((const char*)s_v + off);
+          }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+          o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[qt], o[dt][qt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+        lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qt], lacc[qt], 0, 0, 0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- epilogue: normalise, store O (4 dims x 8 bytes per d-tile) and LSE
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const float l = __shfl(lacc[qt][0], lj, 64);      // row 0 lives in lane group 0
+      const float inv = 1.0f / l;
+      if (qreal[qt]) {
+#pragma unroll
+        for (int dt = 0; dt < MD; ++dt) {
+          bf16x4 w;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w[r] = (__bf16)(o[dt][qt][r] * inv);
+          *(bf16x4*)(ob + (int64_t)qtok[qt] * p.o_st + dt * 16 + lg * 4) = w;
+        }
+        if (lg == 0)
+          p.lse[(int64_t)bh * Nloc + qtok[qt]] = mrow[qt] * p.scale + __logf(l);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ===================================================================== host side
+static bool mfma_cfg(const VilAttnDesc* d, MfmaCfg& c) {
+  memset(&c, 0, sizeof(c));
+  VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
+  const int W = d->W;
+  c.HQ = (W + 3) / 4;
+  c.NWP = (W * c.HQ + 15) / 16;
+  // row pitch: >= (4W-1)+3 so that a 4-float run never reaches the next row, and == 8 mod 32 so
+  // that the 16 query columns of a wave spread over distinct 16-byte LDS slots
+  int P = 4 * W + 2;
+  while ((P & 31) != 8) ++P;
+  c.P = P;
+  const int aqmax = (W - 1) * P + 4 * (c.HQ - 1);
+  c.gsz = ((aqmax + 4 + 3) / 4) * 4;
+  c.guard0 = ((g.tbl * P + 3) / 4) * 4;
+  c.glo0 = c.guard0 + c.gsz;
+  c.copysize = ((c.glo0 + d->G * c.gsz + 4 + 3) / 4) * 4;
+  c.cstride_b = (c.copysize - 1) * 4;
+  c.aconst = (2 * W - 1) * (P + 1);
+  c.magicW = (unsigned)(0x100000000ull / (unsigned)W) + 1;
+  c.magicW2 = (unsigned)(0x100000000ull / (unsigned)(W * W)) + 1;
+  c.NS = d->G + g.nact * g.W2;
+  c.NSP = (c.NS + 31) & ~31;
+  c.units_bh = g.mx * g.my * c.NWP;
+  const int groups = (c.units_bh + 3) / 4;
+  int gpw = (int)(((int64_t)d->B * d->H * groups) / 2048);
+  if (gpw < 1) gpw = 1;
+  if (gpw > groups) gpw = groups;
+  c.gpw = gpw;
+  c.wg_per_bh = (groups + gpw - 1) / gpw;
+  c.wave_lds = ((c.NSP * 8 + 32 * d->M * 2 + 15) / 16) * 16;
+  c.no_tr = d->reserved & 1;
+  return true;
+}
+
+static size_t mfma_lds_bytes(const MfmaCfg& c) { return (size_t)c.copysize * 16 + 4 * (size_t)c.wave_lds; }
+
+int vil_mfma_supported(const VilAttnDesc* d, int pass) {
+  if (pass != 0) return VIL_E_BACKEND;                 // backward: scalar family for now
+  if (d->dtype != VIL_DTYPE_BF16) return VIL_E_DTYPE;
+  if (d->M != 16 && d->M != 32 && d->M != 48 && d->M != 64) return VIL_E_HEAD_DIM;
+  if (d->W < 1 || d->W > 16) return VIL_E_WINDOW;
+  if (d->exact == -1 || d->only_glo) return VIL_E_BACKEND;   // cyclic padding / only-global: scalar family
+  if (d->G > 16) return VIL_E_BACKEND;
+  // 16-byte row loads: token/batch/head strides and M must keep rows 16-byte aligned
+  if ((d->q_st | d->k_st | d->v_st | d->q_sb | d->k_sb | d->v_sb | d->q_sh | d->k_sh | d->v_sh) & 7) return VIL_E_ALIGN;
+  if ((d->o_st | d->o_sb | d->o_sh) & 3) return VIL_E_ALIGN;
+  MfmaCfg c; mfma_cfg(d, c);
+  if (mfma_lds_bytes(c) > 160 * 1024) return VIL_E_BACKEND;
+  return VIL_OK;
+}
+
+size_t vil_mfma_workspace(const VilAttnDesc* d, int pass) {
+  if (pass != 0) return 0;
+  MfmaCfg c; mfma_cfg(d, c);
+  return (size_t)d->H * 4 * c.copysize * sizeof(float);
+}
+
+int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
+  MfmaCfg c; mfma_cfg(d, c);
+  float* tabws = (float*)p.delta;          // workspace base
+  c.tabws = tabws;
+  if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)tabws) & 15) return VIL_E_ALIGN;
+  if ((uintptr_t)p.o & 7) return VIL_E_ALIGN;
+  k_mfma_table<<<dim3((4 * c.copysize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  const unsigned grid = (unsigned)(p.B * p.H * c.wg_per_bh);
+  const size_t lds = mfma_lds_bytes(c);
+#define LAUNCH_FWD(MD_)                                                                              \
+  {                                                                                                  \
+    if (lds > 64 * 1024) {                                                                           \
+      hipError_t he = hipFuncSetAttribute((const void*)k_mfma_fwd<MD_>,                               \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+      if (he != hipSuccess) return (int)he;                                                          \
+    }                                                                                                \
+    k_mfma_fwd<MD_><<<dim3(grid), dim3(256), lds, s>>>(p, c);                                        \
+  }
+  switch (d->M) {
+    case 16: LAUNCH_FWD(1); break;
+    case 32: LAUNCH_FWD(2); break;
+    case 48: LAUNCH_FWD(3); break;
+    case 64: LAUNCH_FWD(4); break;
+    default: return VIL_E_HEAD_DIM;
+  }
+  return (int)hipGetLastError();
+}
+
+int vil_mfma_bwd(const VilAttnDesc*, VilParams&, hipStream_t) { return VIL_E_BACKEND; }

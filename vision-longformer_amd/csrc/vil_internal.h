@@ -1,0 +1,63 @@
+// vil_internal.h -- launch parameters shared by the kernel families of libvilattn.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vil_attn.h"
+#include "vil_geom.h"
+
+struct VilParams {
+  VilGeom g;
+  int B, H, M, G;
+  int only_glo, has_bias, has_g2l;
+  int parts;                 // backward: workgroups per (b,h) in the dQ pass
+  int part_stride;           // floats per partial record
+  float scale;
+  int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh;
+  int64_t do_sb, do_st, do_sh, dq_sb, dq_st, dq_sh, dk_sb, dk_st, dk_sh, dv_sb, dv_st, dv_sh;
+  const void* q; const void* k; const void* v;
+  const void* out; const void* dout;
+  const float* table; const float* g2l;
+  float* lse;                // fwd: written; bwd: read
+  void* o;                   // fwd output
+  void* dq; void* dk; void* dv;
+  float* dtable; float* dg2l;
+  float* delta;              // workspace: rowsum(dO*O), (B*H*Nloc)
+  float* partials;           // workspace: per-workgroup partial reductions
+};
+
+static inline void vil_fill_params(VilParams& p, const VilAttnDesc* d) {
+  vil_geom_init(p.g, d->nx, d->ny, d->W, d->exact, d->mode);
+  p.B = d->B; p.H = d->H; p.M = d->M; p.G = d->G; p.only_glo = d->only_glo;
+  p.scale = d->scale;
+  p.q_sb = d->q_sb; p.q_st = d->q_st; p.q_sh = d->q_sh;
+  p.k_sb = d->k_sb; p.k_st = d->k_st; p.k_sh = d->k_sh;
+  p.v_sb = d->v_sb; p.v_st = d->v_st; p.v_sh = d->v_sh;
+  p.o_sb = d->o_sb; p.o_st = d->o_st; p.o_sh = d->o_sh;
+  p.do_sb = d->do_sb; p.do_st = d->do_st; p.do_sh = d->do_sh;
+  p.dq_sb = d->dq_sb; p.dq_st = d->dq_st; p.dq_sh = d->dq_sh;
+  p.dk_sb = d->dk_sb; p.dk_st = d->dk_st; p.dk_sh = d->dk_sh;
+  p.dv_sb = d->dv_sb; p.dv_st = d->dv_st; p.dv_sh = d->dv_sh;
+}
+
+// ---- bf16 <-> f32 (raw bits; round-to-nearest-even on store) ----
+typedef uint16_t vil_bf16;
+__host__ __device__ __forceinline__ float vil_bf2f(vil_bf16 h) {
+  union { uint32_t u; float f; } c; c.u = (uint32_t)h << 16; return c.f;
+}
+__host__ __device__ __forceinline__ vil_bf16 vil_f2bf(float f) {
+  union { uint32_t u; float f; } c; c.f = f;
+  if ((c.u & 0x7fffffffu) > 0x7f800000u) return (vil_bf16)((c.u >> 16) | 0x40);  // quiet NaN
+  c.u += 0x7fffu + ((c.u >> 16) & 1u);
+  return (vil_bf16)(c.u >> 16);
+}
+
+// kernel families (each returns 0 or a hipError_t / VIL_E_*)
+int vil_scalar_supported(const VilAttnDesc* d);
+size_t vil_scalar_workspace(const VilAttnDesc* d, int pass);
+int vil_scalar_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s);
+int vil_scalar_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s);
+
+int vil_mfma_supported(const VilAttnDesc* d, int pass);
+size_t vil_mfma_workspace(const VilAttnDesc* d, int pass);
+int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s);
+int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s);

@@ -1,0 +1,141 @@
+"""Drop-in ``Long2DSCSelfAttention`` for MsViT blocks (ATTN_TYPE='longformerhand').
+
+Same constructor signature, ``forward(x, nx, ny)`` contract, public attributes,
+parameter / buffer names and random-shift RNG draw as the reference module
+(src/models/layers/longformer2d.py:12-229), so checkpoints load unchanged and
+``MsViT.reset_vil_mode`` keeps working.  The local-attention core is one call
+into the HIP kernels (ops.vil_local_attention) instead of the reference's
+chunk / roll / einsum / mask / softmax / einsum pipeline.
+
+Differences by design (all numerically neutral):
+  * with ``sharew=True`` the reference runs the kv GEMM twice on identical
+    weights (longformer2d.py:127,211); here the first result is reused;
+  * ``relative_position_index`` is still registered (state-dict compatibility)
+    but the kernels compute the index arithmetically and never read it.
+"""
+import random
+
+import torch
+from torch import nn
+
+from .ops import vil_local_attention
+
+
+def _trunc_normal_(t, std):
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+def build_relative_position_index(w):
+    """(w^2, 9w^2) int64: for query l=(xl,yl) of the centre chunk and key t=(xt,yt)
+    of neighbour nb=(dr+1)*3+(dc+1): (xl-dr*w-xt+2w-1)*(4w-1) + (yl-dc*w-yt+2w-1)
+    (longformer2d.py:67-100)."""
+    side = 4 * w - 1
+    pos = torch.arange(w * w)
+    px, py = pos // w, pos % w
+    blocks = []
+    for nb in range(9):
+        dr, dc = nb // 3 - 1, nb % 3 - 1
+        rx = px[:, None] - (dr * w + px)[None, :] + 2 * w - 1
+        ry = py[:, None] - (dc * w + py)[None, :] + 2 * w - 1
+        blocks.append(rx * side + ry)
+    return torch.cat(blocks, dim=1)
+
+
+class Long2DSCSelfAttention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., w=7, d=1,
+                 autoregressive=False, sharew=False, nglo=1, only_glo=False, exact=0, autograd=False, rpe=False,
+                 mode=0):
+        super().__init__()
+        assert d == 1, "Dilation is not supported!"
+        assert not autoregressive, "Autoregressive is not supported yet!"
+        if only_glo:
+            assert nglo >= 1, "Nglo == 0 in the only global mode!"
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = qk_scale or self.head_dim ** -0.5
+        self.Nglo = nglo
+        self.only_glo = only_glo
+        self.attention_window = w
+        self.attention_dilation = d
+        self.autoregressive = autoregressive
+        self.exact = exact
+        self.autograd = autograd          # accepted for API parity; the fused kernels have one backward
+        self.rpe = rpe
+        self.mode = mode                  # 0: 3x3 chunks; -1: own chunk; >0: random-shift training
+        self.backend = None               # kernel family override ("scalar" / "mfma"); None = library default
+
+        self.query = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        if nglo >= 1:
+            if sharew:
+                self.query_global, self.kv_global, self.proj_global = self.query, self.kv, self.proj
+            else:
+                self.query_global = nn.Linear(dim, dim, bias=qkv_bias)
+                self.kv_global = nn.Linear(dim, dim * 2, bias=qkv_bias)
+                self.proj_global = nn.Linear(dim, dim)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+        if rpe:
+            self.local_relative_position_bias_table = nn.Parameter(torch.zeros((4 * w - 1) ** 2, num_heads))
+            _trunc_normal_(self.local_relative_position_bias_table, .02)
+            if nglo >= 1:
+                self.g2l_relative_position_bias = nn.Parameter(torch.zeros(2, num_heads, nglo))
+                self.g2g_relative_position_bias = nn.Parameter(torch.zeros(num_heads, nglo, nglo))
+                _trunc_normal_(self.g2l_relative_position_bias, .02)
+                _trunc_normal_(self.g2g_relative_position_bias, .02)
+            self.register_buffer("relative_position_index", build_relative_position_index(w))
+
+    def _resolve_mode(self):
+        """longformer2d.py:114-123: one draw from Python's global `random` per
+        training forward when mode > 0; evaluation always uses the full 3x3."""
+        if self.mode > 0:
+            return random.randrange(1, 9) if self.training else 0
+        return self.mode
+
+    def forward(self, x, nx, ny):
+        B, N, C = x.shape
+        G, H, M = self.Nglo, self.num_heads, self.head_dim
+        Nloc = nx * ny
+        assert G + Nloc == N, "Global dimension does not match!"
+        mode = self._resolve_mode()
+
+        q = self.query(x[:, G:])                  # (B, Nloc, C), unscaled: the kernel applies `scale`
+        kv = self.kv(x)                           # (B, N, 2C): [..., :C] keys, [..., C:] values
+        table = self.local_relative_position_bias_table if self.rpe else None
+        g2l_loc = self.g2l_relative_position_bias[1] if (self.rpe and G >= 1) else None
+        x1 = vil_local_attention(q, kv, table, g2l_loc, nx=nx, ny=ny, w=self.attention_window, nglo=G,
+                                 num_heads=H, mode=mode, exact=self.exact, scale=self.scale,
+                                 only_glo=self.only_glo, backend=self.backend)
+        x1 = self.proj(x1)
+        if G == 0:
+            return self.proj_drop(x1)
+
+        # global-token rows: full attention over all N keys (longformer2d.py:210-227)
+        qg = (self.scale * self.query_global(x[:, :G])).view(B, G, H, M)
+        kvg = kv if self.kv_global is self.kv else self.kv_global(x)
+        kvg = kvg.view(B, N, 2, H, M)
+        a0 = torch.einsum('bghm,bnhm->bhgn', qg, kvg[:, :, 0])
+        if self.rpe:
+            gbias = torch.cat([self.g2g_relative_position_bias,
+                               self.g2l_relative_position_bias[0].unsqueeze(-1).expand(-1, -1, Nloc)], dim=-1)
+            a0 = a0 + gbias.unsqueeze(0)
+        a0 = torch.softmax(a0.float(), dim=-1).to(kvg.dtype)
+        a0 = self.attn_drop(a0)
+        x0 = torch.einsum('bhgn,bnhm->bghm', a0, kvg[:, :, 1]).reshape(B, G, C)
+        x0 = self.proj_global(x0)
+        return self.proj_drop(torch.cat((x0, x1.to(x0.dtype)), dim=1))
+
+    @staticmethod
+    def compute_macs(module, input, output):
+        """MACs of one forward, same accounting as the reference hook body
+        (longformer2d.py:231-279): attention products + projections."""
+        _, T, C = input[0].shape
+        G, W = module.Nglo, module.attention_window
+        kq = (C - G) * G * C if module.only_glo else (C - G) * (9 * W ** 2) * C + (C - G) * G * C
+        kq += G * T * C
+        macs = 2 * kq
+        for lin in (module.query, module.kv, module.proj):
+            macs += sum(p.numel() for p in lin.parameters()) * T
+        module.__flops__ += macs

@@ -1,0 +1,148 @@
+"""Fused local attention of Vision Longformer as a torch.autograd.Function over
+the C ABI of libvilattn.so (include/vil_attn.h).
+
+Replaces, for the local-query rows, everything between the q/kv projections and
+the output projection of the reference module
+(src/models/layers/longformer2d.py:134-204 and the SlidingChunk2D autograd
+function, src/models/layers/slidingchunk_2d.py:202-246): no chunk/pad/roll
+copies, no score tensor; the backward recomputes probabilities from the saved
+log-sum-exp.
+
+PyTorch is plumbing here (device memory, the current HIP stream); the compute
+is the HIP kernels.  There is no eager fallback: CPU tensors or a missing
+library raise."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16}
+_BACKENDS = {"auto": _lib.BACKEND_AUTO, "scalar": _lib.BACKEND_SCALAR, "mfma": _lib.BACKEND_MFMA}
+
+# process-wide default kernel family ("auto" | "scalar" | "mfma"); tests override per call
+DEFAULT_BACKEND = "auto"
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _strides(t, M):
+    """(batch, token, head) element strides of a (B, T, H*M) tensor whose last
+    dim is contiguous: heads are M apart inside a token row."""
+    return t.stride(0), t.stride(1), M
+
+
+def _last_contig(t):
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def _make_desc(q, k, v, out, cfg, backend):
+    B, Nloc, C = q.shape
+    H, M = cfg["H"], C // cfg["H"]
+    d = _lib.VilAttnDesc()
+    d.B, d.H, d.M = B, H, M
+    d.nx, d.ny, d.W, d.G = cfg["nx"], cfg["ny"], cfg["W"], cfg["G"]
+    d.mode, d.exact = cfg["mode"], cfg["exact"]
+    d.dtype = _DT[q.dtype]
+    d.only_glo = int(cfg["only_glo"])
+    d.backend = _BACKENDS[backend]
+    d.scale = float(cfg["scale"])
+    d.reserved = int(cfg.get("debug", 0))
+    d.q_sb, d.q_st, d.q_sh = _strides(q, M)
+    d.k_sb, d.k_st, d.k_sh = _strides(k, M)
+    d.v_sb, d.v_st, d.v_sh = _strides(v, M)
+    d.o_sb, d.o_st, d.o_sh = _strides(out, M)
+    return d
+
+
+def _workspace(d, pass_, device):
+    n = _lib.lib().vil_attn_workspace_bytes(ctypes.byref(d), pass_)
+    return torch.empty(max(int(n), 4) // 4 + 1, dtype=torch.float32, device=device)
+
+
+class _VilLocalAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, kv, table, g2l, cfg, backend):
+        if not q.is_cuda:
+            raise RuntimeError("vil_local_attention needs device tensors: the product path is the HIP "
+                               "kernels (libvilattn.so); there is no CPU fallback")
+        if q.dtype not in _DT or kv.dtype != q.dtype:
+            raise TypeError(f"vil_local_attention supports float32/bfloat16 q,kv of one dtype; got {q.dtype}, {kv.dtype}")
+        L = _lib.lib()
+        q = _last_contig(q)
+        kv = _last_contig(kv)
+        B, Nloc, C = q.shape
+        assert kv.shape[0] == B and kv.shape[2] == 2 * C and kv.shape[1] == cfg["G"] + Nloc
+        assert Nloc == cfg["nx"] * cfg["ny"]
+        k, v = kv[..., :C], kv[..., C:]
+        out = torch.empty(B, Nloc, C, dtype=q.dtype, device=q.device)
+        lse = torch.empty(B, cfg["H"], Nloc, dtype=torch.float32, device=q.device)
+        tab = table.detach().float().contiguous() if table is not None else None
+        g2 = g2l.detach().float().contiguous() if g2l is not None else None
+        d = _make_desc(q, k, v, out, cfg, backend)
+        ws = _workspace(d, 0, q.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+        with torch.cuda.device(q.device):
+            _lib.check(L.vil_attn_fwd(ctypes.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(tab), _ptr(g2),
+                                      _ptr(out), _ptr(lse), _ptr(ws), stream))
+        ctx.save_for_backward(q, kv, out, lse, tab, g2)
+        ctx.cfg, ctx.backend = cfg, backend
+        ctx.table_dtype = table.dtype if table is not None else None
+        ctx.g2l_dtype = g2l.dtype if g2l is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, lse, tab, g2 = ctx.saved_tensors
+        cfg = ctx.cfg
+        L = _lib.lib()
+        B, Nloc, C = q.shape
+        dout = _last_contig(dout)
+        if dout.dtype != q.dtype:
+            dout = dout.to(q.dtype)
+        k, v = kv[..., :C], kv[..., C:]
+        dq = torch.empty(B, Nloc, C, dtype=q.dtype, device=q.device)
+        dkv = torch.empty(B, kv.shape[1], 2 * C, dtype=q.dtype, device=q.device)
+        dk, dv = dkv[..., :C], dkv[..., C:]
+        dtab = torch.empty_like(tab) if tab is not None else None
+        dg2 = torch.empty_like(g2) if g2 is not None else None
+        M = C // cfg["H"]
+        d = _make_desc(q, k, v, out, cfg, ctx.backend)
+        d.do_sb, d.do_st, d.do_sh = _strides(dout, M)
+        d.dq_sb, d.dq_st, d.dq_sh = _strides(dq, M)
+        d.dk_sb, d.dk_st, d.dk_sh = _strides(dk, M)
+        d.dv_sb, d.dv_st, d.dv_sh = _strides(dv, M)
+        ws = _workspace(d, 1, q.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+        with torch.cuda.device(q.device):
+            _lib.check(L.vil_attn_bwd(ctypes.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout),
+                                      _ptr(lse), _ptr(tab), _ptr(g2), _ptr(dq), _ptr(dk), _ptr(dv),
+                                      _ptr(dtab), _ptr(dg2), _ptr(ws), stream))
+        if dtab is not None and ctx.table_dtype != dtab.dtype:
+            dtab = dtab.to(ctx.table_dtype)
+        if dg2 is not None and ctx.g2l_dtype != dg2.dtype:
+            dg2 = dg2.to(ctx.g2l_dtype)
+        return dq, dkv, dtab, dg2, None, None
+
+
+def vil_local_attention(q, kv, bias_table, g2l_bias, *, nx, ny, w, nglo, num_heads, mode=0, exact=0,
+                        scale=None, only_glo=False, backend=None, _debug=0):
+    """Local-query rows of Vision Longformer attention.
+
+    q:  (B, nx*ny, C)       unscaled local queries (output of the `query` Linear)
+    kv: (B, nglo+nx*ny, 2C) output of the `kv` Linear: [..., :C] keys, [..., C:] values,
+                            global tokens first
+    bias_table: ((4w-1)^2, H) or None (rpe off); g2l_bias: (H, nglo) or None.
+    Returns (B, nx*ny, C), heads concatenated, ready for the `proj` Linear."""
+    if exact not in (0, 1, -1) or (exact == 1 and mode != 0 and not only_glo):
+        # the reference raises from mask_invalid_locations (slidingchunk_2d.py:331-343)
+        raise ValueError("longsc exact should be in [0,1,-1]!")
+    C = q.shape[-1]
+    cfg = dict(nx=int(nx), ny=int(ny), W=int(w), G=int(nglo), H=int(num_heads), mode=int(mode),
+               exact=int(exact), only_glo=bool(only_glo),
+               scale=float(scale) if scale is not None else (C // num_heads) ** -0.5, debug=int(_debug))
+    if nglo == 0:
+        g2l_bias = None
+    return _VilLocalAttention.apply(q, kv, bias_table, g2l_bias, cfg, backend or DEFAULT_BACKEND)
