@@ -1,0 +1,293 @@
+"""Host model: multi-scale Vision Longformer (MsViT) assembled from stock
+PyTorch-ROCm blocks (GEMMs -> hipBLASLt) around the HIP hot path.
+
+Only what the `longformerhand` path needs to be exercised end to end is here:
+the arch-string parser, PatchEmbed, the dense `Attention` of the `s0` stages,
+MlpBlock, AttnBlock (the drop-in boundary: ``x + drop_path(attn(norm(x), nx, ny))``,
+reference src/models/msvit.py:313-316) and the MsViT container with
+``reset_vil_mode``.  Module / parameter names follow the reference
+(src/models/msvit.py) so that its checkpoints load unchanged; other attention
+types of the reference (linformer, performer, srformer) are out of scope.
+"""
+from functools import partial
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .longformer2d import Long2DSCSelfAttention, _trunc_normal_
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = torch.empty((x.shape[0],) + (1,) * (x.dim() - 1), dtype=x.dtype, device=x.device).bernoulli_(keep)
+        return x * (mask / keep)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+class Attention(nn.Module):
+    """Dense multi-head attention with optional relative position bias over an
+    (nglo + wx*wy)-token sequence: the `s0` stages (reference msvit.py:37-120)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.,
+                 rpe=False, wx=14, wy=14, nglo=1):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.rpe = rpe
+        if rpe:
+            self.wx, self.wy, self.nglo = wx, wy, nglo
+            self.local_relative_position_bias_table = nn.Parameter(torch.zeros((2 * wx - 1) * (2 * wy - 1), num_heads))
+            _trunc_normal_(self.local_relative_position_bias_table, .02)
+            if nglo >= 1:
+                self.g2l_relative_position_bias = nn.Parameter(torch.zeros(2, num_heads, nglo))
+                self.g2g_relative_position_bias = nn.Parameter(torch.zeros(num_heads, nglo, nglo))
+                _trunc_normal_(self.g2l_relative_position_bias, .02)
+                _trunc_normal_(self.g2g_relative_position_bias, .02)
+            ix, iy = torch.meshgrid(torch.arange(wx), torch.arange(wy), indexing="ij")
+            ix, iy = ix.reshape(-1), iy.reshape(-1)
+            rel = (ix[:, None] - ix[None, :] + wx - 1) * (2 * wy - 1) + (iy[:, None] - iy[None, :] + wy - 1)
+            self.register_buffer("relative_position_index", rel)
+
+    def _bias(self, N):
+        """(H, N, N) additive bias: [g2g | g2l[0]] rows for global queries,
+        [g2l[1] | table gather] rows for local ones (msvit.py:88-111)."""
+        L = self.wx * self.wy
+        assert N == self.nglo + L, "For relative position, N != self.nglo + self.wx*self.wy!"
+        loc = self.local_relative_position_bias_table[self.relative_position_index.reshape(-1)]
+        loc = loc.view(L, L, -1).permute(2, 0, 1)
+        if self.nglo == 0:
+            return loc
+        top = torch.cat([self.g2g_relative_position_bias,
+                         self.g2l_relative_position_bias[0].unsqueeze(-1).expand(-1, -1, L)], dim=-1)
+        bot = torch.cat([self.g2l_relative_position_bias[1].unsqueeze(1).expand(-1, L, -1), loc], dim=-1)
+        return torch.cat([top, bot], dim=1)
+
+    def forward(self, x, nx=None, ny=None):
+        B, N, C = x.shape
+        H = self.num_heads
+        q, k, v = self.qkv(x).view(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
+        mask = self._bias(N).unsqueeze(0).to(q.dtype) if self.rpe else None
+        p = self.attn_drop.p if self.training else 0.0
+        x = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=p, scale=self.scale)
+        x = x.transpose(1, 2).reshape(B, N, C)
+        return self.proj_drop(self.proj(x))
+
+
+class PatchEmbed(nn.Module):
+    """Strided-conv patch embedding + optional LayerNorm, global (cls) tokens
+    prepended, optional absolute 2-D position embedding (msvit.py:159-224)."""
+
+    def __init__(self, patch_size, nx, ny, in_chans=3, embed_dim=768, nglo=1, norm_layer=nn.LayerNorm,
+                 norm_embed=True, drop_rate=0.0, ape=True):
+        super().__init__()
+        ps = patch_size if isinstance(patch_size, tuple) else (patch_size, patch_size)
+        self.patch_size = ps
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=ps, stride=ps)
+        self.norm_embed = norm_layer(embed_dim) if norm_embed else None
+        self.nx, self.ny, self.Nglo = nx, ny, nglo
+        if nglo >= 1:
+            self.cls_token = nn.Parameter(torch.zeros(1, nglo, embed_dim))
+            _trunc_normal_(self.cls_token, .02)
+        else:
+            self.cls_token = None
+        self.ape = ape
+        if ape:
+            self.cls_pos_embed = nn.Parameter(torch.zeros(1, nglo, embed_dim))
+            self.x_pos_embed = nn.Parameter(torch.zeros(1, nx, embed_dim // 2))
+            self.y_pos_embed = nn.Parameter(torch.zeros(1, ny, embed_dim // 2))
+            for t in (self.cls_pos_embed, self.x_pos_embed, self.y_pos_embed):
+                _trunc_normal_(t, .02)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+
+    def forward(self, xtuple):
+        x = self.proj(xtuple[0])
+        B, _, nx, ny = x.shape
+        assert nx == self.nx and ny == self.ny, "Fix input size!"
+        x = x.flatten(2).transpose(1, 2)
+        if self.norm_embed is not None:
+            x = self.norm_embed(x)
+        if self.cls_token is not None:
+            x = torch.cat((self.cls_token.expand(B, -1, -1).to(x.dtype), x), dim=1)
+        if self.ape:
+            grid = torch.cat([self.x_pos_embed.unsqueeze(2).expand(-1, -1, ny, -1),
+                              self.y_pos_embed.unsqueeze(1).expand(-1, nx, -1, -1)], dim=-1).flatten(1, 2)
+            x = x + torch.cat([self.cls_pos_embed, grid], dim=1)
+        return self.pos_drop(x), nx, ny
+
+
+class AttnBlock(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias=False, qk_scale=None, drop=0., attn_drop=0., drop_path=0.,
+                 norm_layer=nn.LayerNorm, attn_type='full', w=7, d=1, sharew=False, nglo=1, only_glo=False,
+                 seq_len=None, num_feats=256, share_kv=False, sw_exact=0, rratio=2, rpe=False, wx=14, wy=14,
+                 mode=0):
+        super().__init__()
+        self.norm = norm_layer(dim)
+        if attn_type == 'full':
+            self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                  attn_drop=attn_drop, proj_drop=drop, rpe=rpe, wx=wx, wy=wy, nglo=nglo)
+        elif attn_type in ('longformerhand', 'longformerauto'):
+            self.attn = Long2DSCSelfAttention(
+                dim, exact=sw_exact, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                attn_drop=attn_drop, proj_drop=drop, w=w, d=d, sharew=sharew, nglo=nglo, only_glo=only_glo,
+                autograd=(attn_type == 'longformerauto'), rpe=rpe, mode=mode)
+        else:
+            raise ValueError("Not supported attention type {}".format(attn_type))
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+
+    def forward(self, xtuple):
+        x, nx, ny = xtuple
+        return x + self.drop_path(self.attn(self.norm(x), nx, ny)), nx, ny
+
+
+class MlpBlock(nn.Module):
+    def __init__(self, dim, out_dim=None, mlp_ratio=4., drop=0., drop_path=0., act_layer=nn.GELU,
+                 norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), out_dim, act_layer=act_layer, drop=drop)
+        self.shortcut = nn.Identity()
+        if out_dim is not None and out_dim != dim:
+            self.shortcut = nn.Sequential(nn.Linear(dim, out_dim), nn.Dropout(drop))
+
+    def forward(self, xtuple):
+        x, nx, ny = xtuple
+        return self.shortcut(x) + self.drop_path(self.mlp(self.norm(x))), nx, ny
+
+
+def parse_arch(arch):
+    """'l1,h3,d96,n1,s1,g1,p4,f7,a0_l2,...' -> list of per-stage dicts
+    (l stage id, h heads, d dim, n blocks, s sparse(1)/full(0), g global tokens,
+    p patch size, f window, a absolute(1)/relative(0) position; msvit.py:402-410)."""
+    stages = []
+    for part in arch.split('_'):
+        cfg = dict(l=1, h=3, d=192, n=1, s=1, g=1, p=2, f=7, a=1)
+        for tok in part.split(','):
+            cfg[tok[0]] = int(tok[1:])
+        stages.append(cfg)
+    return stages
+
+
+class MsViT(nn.Module):
+    def __init__(self, arch, img_size=512, in_chans=3, num_classes=1000, qkv_bias=True, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                 norm_embed=False, w=7, d=1, sharew=False, only_glo=False, share_kv=False,
+                 attn_type='longformerhand', sw_exact=0, mode=0, **args):
+        super().__init__()
+        self.num_classes = num_classes
+        self.drop_path_rate = drop_path_rate
+        self.attn_type = attn_type
+        self.layer_cfgs = parse_arch(arch)
+        self.num_layers = len(self.layer_cfgs)
+        if self.num_layers not in (3, 4):
+            raise ValueError("Numer of layers {} not implemented yet!".format(self.num_layers))
+        self.depth = sum(c['n'] for c in self.layer_cfgs)
+        self.out_planes = self.layer_cfgs[-1]['d']
+        self.Nglos = [c['g'] for c in self.layer_cfgs]
+        self.avg_pool = args.get('avg_pool', False)
+
+        attn_args = dict(attn_type=attn_type, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
+                         attn_drop=attn_drop_rate, w=w, d=d, sharew=sharew, only_glo=only_glo,
+                         share_kv=share_kv, sw_exact=sw_exact, norm_layer=norm_layer, mode=mode)
+        dprs = torch.linspace(0, drop_path_rate, self.depth).split([c['n'] for c in self.layer_cfgs])
+        side = img_size
+        in_dim = in_chans
+        for i, cfg in enumerate(self.layer_cfgs):
+            assert cfg['l'] == i + 1, "Error in _make_layer: layerid {} does not equal to layer_id {}".format(i + 1, cfg['l'])
+            side //= cfg['p']
+            attn_args.update(nglo=cfg['g'], num_feats=cfg['f'], rratio=cfg['f'], w=cfg['f'])
+            if cfg['s'] == 0:
+                attn_args['attn_type'] = 'full'          # sticky, as in the reference (msvit.py:460-461)
+            blocks = [PatchEmbed(cfg['p'], side, side, in_chans=in_dim, embed_dim=cfg['d'], ape=bool(cfg['a']),
+                                 nglo=cfg['g'], norm_layer=norm_layer, norm_embed=norm_embed, drop_rate=drop_rate)]
+            for dpr in dprs[i]:
+                blocks.append(AttnBlock(cfg['d'], cfg['h'], drop_path=float(dpr), seq_len=side * side + cfg['g'],
+                                        rpe=not cfg['a'], wx=side, wy=side, **attn_args))
+                blocks.append(MlpBlock(cfg['d'], drop_path=float(dpr), mlp_ratio=4.0, norm_layer=norm_layer,
+                                       act_layer=nn.GELU, drop=drop_rate))
+            setattr(self, "layer%d" % (i + 1), nn.Sequential(*blocks))
+            in_dim = cfg['d']
+        if self.num_layers == 3:
+            self.layer4 = None
+        self.norm = norm_layer(self.out_planes)
+        self.head = nn.Linear(self.out_planes, num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            _trunc_normal_(m.weight, .02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token', 'norm.weight', 'norm.bias', 'norm_embed', 'head.bias', 'relative_position'}
+
+    def get_classifier(self):
+        return self.head
+
+    def forward_features(self, x):
+        B = x.shape[0]
+        nx = ny = None
+        for i in range(self.num_layers):
+            layer = getattr(self, "layer%d" % (i + 1))
+            if i > 0:   # drop the previous stage's global tokens, back to an image
+                x = x[:, self.Nglos[i - 1]:].transpose(-2, -1).reshape(B, -1, nx, ny)
+            x, nx, ny = layer((x, nx, ny))
+        x = self.norm(x)
+        if self.Nglos[-1] > 0 and not self.avg_pool:
+            return x[:, 0]
+        return torch.mean(x, dim=1)
+
+    def reset_vil_mode(self, mode):
+        """Switch every sliding-chunk layer between random-shift and full mode
+        (msvit.py:532-541)."""
+        for m in self.modules():
+            if isinstance(m, Long2DSCSelfAttention) and m.mode != mode:
+                m.mode = mode
+
+    def forward(self, x):
+        return self.head(self.forward_features(x))
+
+
+# arch strings of the published ViL models (reference README.md:63-67), relative-position (a0) variants
+def vil_arch(name, f1=7, f2=7):
+    n = {"tiny": (1, 1, 9, 1), "small": (1, 2, 8, 1), "medium_deep": (1, 4, 16, 1), "base_deep": (1, 8, 24, 1)}[name]
+    dims = {"tiny": ((1, 48), (3, 96), (3, 192), (6, 384)), "small": ((3, 96), (3, 192), (6, 384), (12, 768)),
+            "medium_deep": ((3, 96), (3, 192), (6, 384), (12, 768)),
+            "base_deep": ((3, 96), (3, 192), (6, 384), (12, 768))}[name]
+    ps = (4, 2, 2, 2)
+    ss = (1, 1, 0, 0)
+    gs = (1, 1, 1, 0)
+    fs = (f1, f2, 7, 7)
+    return "_".join("l%d,h%d,d%d,n%d,s%d,g%d,p%d,f%d,a0" % (i + 1, dims[i][0], dims[i][1], n[i], ss[i], gs[i], ps[i], fs[i])
+                    for i in range(4))
