@@ -112,6 +112,16 @@ int vil_attn_bwd(const VilAttnDesc* d, const void* q, const void* k, const void*
                  void* dq, void* dk, void* dv, float* dbias_table, float* dg2l,
                  void* workspace, void* stream);
 
+/* ---- optional profiling sink (a measurement aid for bench.py; the ONLY state the
+ * library keeps: process-global, not thread-safe).  Between _begin and _end every
+ * kernel the library launches is bracketed by hipEventRecord on its launch stream.
+ * _end synchronises on the recorded events and returns, per launch in order, the
+ * kernel id (name via vil_attn_kernel_name), its duration in ms and the algorithmic
+ * HBM bytes / flops of that launch.  Returns the count. */
+int vil_attn_profile_begin(int capacity);
+int vil_attn_profile_end(int capacity, int* kernel_id, float* ms, double* bytes, double* flops);
+const char* vil_attn_kernel_name(int kernel_id);
+
 /* ---- host-side geometry helpers (pure CPU, used by the tests to pin the
  * kernels' index/mask logic against the golden masks without a GPU) -------- */
 

@@ -307,3 +307,46 @@ def test_full_size_properties(name, c, dev):
     ref = run_oracle(c1, q[:1], kv[:1], table, g2l, dout[:1])
     got = run_hip(c1, q[:1], kv[:1], table, g2l, dout[:1], torch.bfloat16, "auto", dev)
     compare("full " + name, got, ref, BF16_TOL)
+
+
+# ---------------------------------------------------------------- model level (BASELINE config 1)
+def test_model_vil_tiny_vs_reference_logits(dev, golden_dir):
+    """ViL-Tiny 224, B=2: the build's MsViT (HIP hot path, fp32) against logits / loss /
+    gradient norms produced by the REFERENCE MsViT loaded with the same state dict."""
+    from vision_longformer_amd.engine import build_vil
+    gold = np.load(os.path.join(golden_dir, "model_tiny.npz"))
+    torch.manual_seed(0)
+    model = build_vil("vil_tiny_224", drop_path_rate=0.0).double()
+    with torch.no_grad():
+        for n, p_ in model.named_parameters():
+            if "relative_position" in n:
+                p_.normal_(0, 0.3)
+    model = model.float().to(dev).train()
+    for m in model.modules():
+        if hasattr(m, "backend"):
+            m.backend = "scalar"
+    g = torch.Generator().manual_seed(GC.SEED)
+    img = torch.randn(2, 3, 224, 224, generator=g, dtype=torch.float64).float().to(dev)
+    tgt = torch.tensor([3, 977], device=dev)
+    logits = model(img)
+    loss = torch.nn.functional.cross_entropy(logits, tgt)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(gold["logits"])
+    err = (logits.detach().double().cpu() - ref).abs().max().item()
+    _report(f"     model ViL-Tiny fp32: max|logit err| = {err:.3e}, loss {loss.item():.6f} vs {float(gold['loss']):.6f}")
+    assert err < 2e-3
+    assert abs(loss.item() - float(gold["loss"])) < 1e-4
+    gn = dict(zip([str(s) for s in gold["grad_names"]], gold["grad_norms"]))
+    for n, p_ in model.named_parameters():
+        if n in gn:
+            assert abs(p_.grad.norm().item() - gn[n]) < 2e-3 * max(1.0, gn[n]), n
+    # bf16 autocast, MFMA forward
+    for m in model.modules():
+        if hasattr(m, "backend"):
+            m.backend = None
+    with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+        lb = model(img)
+    errb = (lb.double().cpu() - ref).abs().max().item()
+    _report(f"     model ViL-Tiny bf16 autocast: max|logit err| = {errb:.3e} (logit range {ref.abs().max():.2f})")
+    assert errb < 0.1

@@ -198,6 +198,38 @@ def main():
     np.savez_compressed(os.path.join(outdir, "module_cases.npz"), **mods)
     print("module cases ok, max |ref-oracle| out/grads =", worst_out, worst_g)
 
+    # ---------------- model level (BASELINE config 1): ViL-Tiny 224, B=2 ----------------
+    # The build's own MsViT provides the weights (seeded); the REFERENCE MsViT must accept
+    # that state dict as is (drop-in contract: same parameter/buffer names and shapes).
+    from models import msvit as ref_msvit
+    from vision_longformer_amd.engine import build_vil
+    from vision_longformer_amd.msvit import vil_arch
+    torch.manual_seed(0)
+    mine = build_vil("vil_tiny_224", drop_path_rate=0.0).double()
+    with torch.no_grad():
+        for n, p_ in mine.named_parameters():
+            if "relative_position" in n:
+                p_.normal_(0, 0.3)
+    refm = ref_msvit.MsViT(vil_arch("tiny"), img_size=224, num_classes=1000, drop_path_rate=0.0,
+                           norm_embed=True, sharew=True, attn_type="longformerhand").double()
+    missing = refm.load_state_dict(mine.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(GC.SEED)
+    img = torch.randn(2, 3, 224, 224, generator=g, dtype=torch.float64)
+    tgt = torch.tensor([3, 977])
+    refm.train()
+    logits = refm(img)
+    loss = torch.nn.functional.cross_entropy(logits, tgt)
+    loss.backward()
+    gn = {n: float(p_.grad.norm()) for n, p_ in refm.named_parameters() if p_.grad is not None}
+    pick = ["layer1.1.attn.query.weight", "layer1.1.attn.kv.weight", "layer1.1.attn.local_relative_position_bias_table",
+            "layer1.1.attn.g2l_relative_position_bias", "layer2.1.attn.proj.weight", "layer1.0.proj.weight",
+            "layer3.1.attn.qkv.weight", "head.weight"]
+    np.savez_compressed(os.path.join(outdir, "model_tiny.npz"), logits=logits.detach().numpy(),
+                        loss=np.float64(loss.item()), grad_names=np.array(pick),
+                        grad_norms=np.array([gn[n] for n in pick]),
+                        state_keys=np.array(sorted(refm.state_dict().keys())))
+    print("model-level ViL-Tiny ok: loss", loss.item(), "n_state_keys", len(refm.state_dict()))
+
     # exact=1 with mode != 0 raises ValueError in the reference
     try:
         t = torch.zeros(1, 2, 2, 16, 32, dtype=torch.float64)

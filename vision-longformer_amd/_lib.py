@@ -14,7 +14,8 @@ BACKEND_AUTO, BACKEND_SCALAR, BACKEND_MFMA = 0, 1, 2
 ABI_VERSION = 1
 
 EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_attn_workspace_bytes",
-           "vil_attn_fwd", "vil_attn_bwd", "vil_geom_mask", "vil_geom_bias_index")
+           "vil_attn_fwd", "vil_attn_bwd", "vil_geom_mask", "vil_geom_bias_index",
+           "vil_attn_profile_begin", "vil_attn_profile_end", "vil_attn_kernel_name")
 
 
 class VilAttnDesc(ctypes.Structure):
@@ -59,6 +60,12 @@ def lib():
         L.vil_geom_mask.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p]
         L.vil_geom_bias_index.restype = ctypes.c_int
         L.vil_geom_bias_index.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.vil_attn_profile_begin.restype = ctypes.c_int
+        L.vil_attn_profile_begin.argtypes = [ctypes.c_int]
+        L.vil_attn_profile_end.restype = ctypes.c_int
+        L.vil_attn_profile_end.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
+        L.vil_attn_kernel_name.restype = ctypes.c_char_p
+        L.vil_attn_kernel_name.argtypes = [ctypes.c_int]
         if L.vil_attn_abi_version() != ABI_VERSION:
             raise RuntimeError("libvilattn.so ABI version mismatch; rebuild it")
         _lib = L
@@ -68,3 +75,20 @@ def lib():
 def check(code):
     if code != 0:
         raise VilAttnError(code, lib().vil_attn_strerror(code).decode())
+
+
+def profile_begin(capacity=8192):
+    check(lib().vil_attn_profile_begin(int(capacity)))
+
+
+def profile_end(capacity=8192):
+    """Returns a list of (kernel_name, ms, algorithmic_bytes, algorithmic_flops), one per launch."""
+    import numpy as np
+    kid = np.zeros(capacity, dtype=np.int32)
+    ms = np.zeros(capacity, dtype=np.float32)
+    by = np.zeros(capacity, dtype=np.float64)
+    fl = np.zeros(capacity, dtype=np.float64)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    L = lib()
+    n = L.vil_attn_profile_end(int(capacity), vp(kid), vp(ms), vp(by), vp(fl))
+    return [(L.vil_attn_kernel_name(int(kid[i])).decode(), float(ms[i]), float(by[i]), float(fl[i])) for i in range(n)]

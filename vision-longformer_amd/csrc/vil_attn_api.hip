@@ -3,6 +3,7 @@
 // helpers the CPU tests use to pin the kernels' mask / bias-index logic.
 #include "vil_internal.h"
 #include <string.h>
+#include <vector>
 
 extern "C" int vil_attn_abi_version(void) { return VIL_ATTN_ABI_VERSION; }
 
@@ -145,4 +146,61 @@ extern "C" int vil_geom_bias_index(int W, int mode, int32_t* rel) {
       for (int t = 0; t < g.W2; ++t)
         rel[l * kv + a * g.W2 + t] = vil_bias_index(W, l / W, l % W, g.adr[a], g.adc[a], t / W, t % W);
   return kv;
+}
+
+// ------------------------------------------------------------ profiling sink
+// Process-global and not thread-safe by design: a measurement aid for bench.py, the
+// only state the library keeps.  Events are created once and reused.
+struct ProfRec { int kid; double bytes, flops; };
+static std::vector<hipEvent_t> g_ev;
+static std::vector<ProfRec> g_rec;
+static bool g_on = false;
+static size_t g_cap = 0;
+static bool g_open = false;
+
+void vil_prof_begin(int kid, hipStream_t s, double bytes, double flops) {
+  if (!g_on || g_rec.size() >= g_cap) return;
+  g_rec.push_back({kid, bytes, flops});
+  g_open = true;
+  (void)hipEventRecord(g_ev[2 * (g_rec.size() - 1)], s);
+}
+void vil_prof_end(hipStream_t s) {
+  if (!g_on || !g_open) return;
+  g_open = false;
+  (void)hipEventRecord(g_ev[2 * (g_rec.size() - 1) + 1], s);
+}
+
+extern "C" const char* vil_attn_kernel_name(int kid) {
+  static const char* names[VIL_K_COUNT] = {"k_mfma_table", "k_mfma_fwd", "k_scalar_fwd", "k_delta", "k_scalar_bwd_dq",
+                                           "k_scalar_bwd_dkdv", "k_reduce_glo", "k_reduce_bias", "k_mfma_bwd_dq",
+                                           "k_mfma_bwd_dkdv"};
+  return (kid >= 0 && kid < VIL_K_COUNT) ? names[kid] : "?";
+}
+
+extern "C" int vil_attn_profile_begin(int capacity) {
+  if (capacity <= 0) return VIL_E_SHAPE;
+  while (g_ev.size() < 2 * (size_t)capacity) {
+    hipEvent_t e;
+    hipError_t he = hipEventCreate(&e);
+    if (he != hipSuccess) return (int)he;
+    g_ev.push_back(e);
+  }
+  g_rec.clear(); g_cap = (size_t)capacity; g_on = true;
+  return VIL_OK;
+}
+
+extern "C" int vil_attn_profile_end(int cap, int* kid, float* ms, double* bytes, double* flops) {
+  g_on = false;
+  const int n = (int)(g_rec.size() < (size_t)cap ? g_rec.size() : (size_t)cap);
+  for (int i = 0; i < n; ++i) {
+    (void)hipEventSynchronize(g_ev[2 * i + 1]);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, g_ev[2 * i], g_ev[2 * i + 1]);
+    if (kid) kid[i] = g_rec[i].kid;
+    if (ms) ms[i] = t;
+    if (bytes) bytes[i] = g_rec[i].bytes;
+    if (flops) flops[i] = g_rec[i].flops;
+  }
+  g_rec.clear();
+  return n;
 }

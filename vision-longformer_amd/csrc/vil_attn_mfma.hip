@@ -419,9 +419,13 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   c.tabws = tabws;
   if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)tabws) & 15) return VIL_E_ALIGN;
   if ((uintptr_t)p.o & 7) return VIL_E_ALIGN;
+  const VilWork w(d);
+  vil_prof_begin(VIL_K_TABLE, s, 0, 0);
   k_mfma_table<<<dim3((4 * c.copysize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
+  vil_prof_end(s);
   int e = (int)hipGetLastError();
   if (e) return e;
+  vil_prof_begin(VIL_K_MFMA_FWD, s, w.fwd_bytes(), w.fwd_flops());
   const unsigned grid = (unsigned)(p.B * p.H * c.wg_per_bh);
   const size_t lds = mfma_lds_bytes(c);
 #define LAUNCH_FWD(MD_)                                                                              \
@@ -440,6 +444,7 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     case 64: LAUNCH_FWD(4); break;
     default: return VIL_E_HEAD_DIM;
   }
+  vil_prof_end(s);
   return (int)hipGetLastError();
 }
 

@@ -453,6 +453,8 @@ size_t vil_scalar_workspace(const VilAttnDesc* d, int pass) {
 
 int vil_scalar_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   const VilGeom& g = p.g;
+  const VilWork w(d);
+  vil_prof_begin(VIL_K_SCALAR_FWD, s, w.fwd_bytes(), w.fwd_flops());
   const int nq = (g.W2 + 63) / 64;
   const unsigned grid = (unsigned)(p.B * p.H * g.mx * g.my * nq);
   if (d->dtype == VIL_DTYPE_F32) {
@@ -460,6 +462,7 @@ int vil_scalar_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   } else {
     DISPATCH_M(d->M, k_scalar_fwd<vil_bf16, MM><<<dim3(grid), dim3(64), 0, s>>>(p));
   }
+  vil_prof_end(s);
   return (int)hipGetLastError();
 }
 
@@ -475,28 +478,36 @@ int vil_scalar_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   const unsigned gk = (unsigned)(p.B * p.H * g.mx * g.my * nq);
   const size_t accb = (size_t)p.part_stride * sizeof(float);
   int e;
-  if (d->dtype == VIL_DTYPE_F32) {
-    DISPATCH_M(d->M, k_delta<float, MM><<<dim3(gd), dim3(256), 0, s>>>(p));
-    if ((e = (int)hipGetLastError())) return e;
-    DISPATCH_M(d->M, k_scalar_bwd_dq<float, MM><<<dim3(gq), dim3(64), accb, s>>>(p));
-    if ((e = (int)hipGetLastError())) return e;
-    DISPATCH_M(d->M, k_scalar_bwd_dkdv<float, MM><<<dim3(gk), dim3(64), 0, s>>>(p));
-    if ((e = (int)hipGetLastError())) return e;
-    if (p.G > 0)
-      hipLaunchKernelGGL((k_reduce_glo<float>), dim3((p.B * p.H * p.G * p.M + 255) / 256), dim3(256), 0, s, p);
-  } else {
-    DISPATCH_M(d->M, k_delta<vil_bf16, MM><<<dim3(gd), dim3(256), 0, s>>>(p));
-    if ((e = (int)hipGetLastError())) return e;
-    DISPATCH_M(d->M, k_scalar_bwd_dq<vil_bf16, MM><<<dim3(gq), dim3(64), accb, s>>>(p));
-    if ((e = (int)hipGetLastError())) return e;
-    DISPATCH_M(d->M, k_scalar_bwd_dkdv<vil_bf16, MM><<<dim3(gk), dim3(64), 0, s>>>(p));
-    if ((e = (int)hipGetLastError())) return e;
-    if (p.G > 0)
-      hipLaunchKernelGGL((k_reduce_glo<vil_bf16>), dim3((p.B * p.H * p.G * p.M + 255) / 256), dim3(256), 0, s, p);
-  }
+  const VilWork w(d);
+  const bool f32 = d->dtype == VIL_DTYPE_F32;
+  vil_prof_begin(VIL_K_DELTA, s, w.delta_bytes(), 0);
+  if (f32) { DISPATCH_M(d->M, k_delta<float, MM><<<dim3(gd), dim3(256), 0, s>>>(p)); }
+  else { DISPATCH_M(d->M, k_delta<vil_bf16, MM><<<dim3(gd), dim3(256), 0, s>>>(p)); }
+  vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
+  vil_prof_begin(VIL_K_SCALAR_DQ, s, w.dq_bytes(), w.dq_flops());
+  if (f32) { DISPATCH_M(d->M, k_scalar_bwd_dq<float, MM><<<dim3(gq), dim3(64), accb, s>>>(p)); }
+  else { DISPATCH_M(d->M, k_scalar_bwd_dq<vil_bf16, MM><<<dim3(gq), dim3(64), accb, s>>>(p)); }
+  vil_prof_end(s);
+  if ((e = (int)hipGetLastError())) return e;
+  vil_prof_begin(VIL_K_SCALAR_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
+  if (f32) { DISPATCH_M(d->M, k_scalar_bwd_dkdv<float, MM><<<dim3(gk), dim3(64), 0, s>>>(p)); }
+  else { DISPATCH_M(d->M, k_scalar_bwd_dkdv<vil_bf16, MM><<<dim3(gk), dim3(64), 0, s>>>(p)); }
+  vil_prof_end(s);
+  if ((e = (int)hipGetLastError())) return e;
+  if (p.G > 0) {
+    vil_prof_begin(VIL_K_REDUCE_GLO, s, 0, 0);
+    const unsigned gg = (unsigned)((p.B * p.H * p.G * p.M + 255) / 256);
+    if (f32) hipLaunchKernelGGL((k_reduce_glo<float>), dim3(gg), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_reduce_glo<vil_bf16>), dim3(gg), dim3(256), 0, s, p);
+    vil_prof_end(s);
+    if ((e = (int)hipGetLastError())) return e;
+  }
   const int nb = ((p.has_bias ? g.tbl * g.tbl : 0) + p.G) * p.H;
-  if (nb > 0 && (p.dtable || p.dg2l))
+  if (nb > 0 && (p.dtable || p.dg2l)) {
+    vil_prof_begin(VIL_K_REDUCE_BIAS, s, 0, 0);
     hipLaunchKernelGGL(k_reduce_bias, dim3((nb + 127) / 128), dim3(128), 0, s, p);
+    vil_prof_end(s);
+  }
   return (int)hipGetLastError();
 }

@@ -51,6 +51,31 @@ __host__ __device__ __forceinline__ vil_bf16 vil_f2bf(float f) {
   return (vil_bf16)(c.u >> 16);
 }
 
+// ---- optional profiling sink (vil_attn_profile_begin/_end): brackets every kernel
+// launch with hipEvents on the launch stream and records its algorithmic bytes/flops
+enum { VIL_K_TABLE = 0, VIL_K_MFMA_FWD, VIL_K_SCALAR_FWD, VIL_K_DELTA, VIL_K_SCALAR_DQ, VIL_K_SCALAR_DKDV,
+       VIL_K_REDUCE_GLO, VIL_K_REDUCE_BIAS, VIL_K_MFMA_DQ, VIL_K_MFMA_DKDV, VIL_K_COUNT };
+void vil_prof_begin(int kid, hipStream_t s, double bytes, double flops);
+void vil_prof_end(hipStream_t s);
+
+// algorithmic (minimum) HBM bytes / flops of one launch over the whole batch; SURVEY.md 8(d)
+struct VilWork {
+  double nloc, n, c, e, k, h, b, tbl;
+  explicit VilWork(const VilAttnDesc* d) {
+    VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
+    nloc = (double)d->nx * d->ny; n = nloc + d->G; c = (double)d->H * d->M;
+    e = d->dtype == VIL_DTYPE_BF16 ? 2 : 4; h = d->H; b = d->B;
+    k = d->only_glo ? d->G : (double)g.nact * g.W2 + d->G; tbl = (double)g.tbl * g.tbl;
+  }
+  double fwd_bytes() const { return b * ((2 * nloc + 2 * n) * c * e + 4 * h * nloc + 4 * h * tbl); }
+  double fwd_flops() const { return b * 4 * nloc * k * c; }
+  double delta_bytes() const { return b * (2 * nloc * c * e + 4 * h * nloc); }
+  double dq_bytes() const { return b * ((3 * nloc + 2 * n) * c * e + 8 * h * nloc); }
+  double dq_flops() const { return b * 6 * nloc * k * c; }
+  double dkdv_bytes() const { return b * ((2 * nloc + 4 * n) * c * e + 8 * h * nloc); }
+  double dkdv_flops() const { return b * 8 * nloc * k * c; }
+};
+
 // kernel families (each returns 0 or a hipError_t / VIL_E_*)
 int vil_scalar_supported(const VilAttnDesc* d);
 size_t vil_scalar_workspace(const VilAttnDesc* d, int pass);

@@ -1,0 +1,116 @@
+"""Data-parallel training step for ViL on synthetic ImageNet-shape batches.
+
+Counterpart of the reference's loop (src/engine.py:60-195 driven by
+src/run_experiment.py:142-262) reduced to what the throughput metric needs, and
+MI355X-first: one process per GPU, `torch.distributed` backend "nccl" (= RCCL
+over xGMI on ROCm), DistributedDataParallel with `broadcast_buffers=False` (the
+reference re-broadcasts the constant int64 relative_position_index buffers every
+step: 3-66 MB of pure waste) and `gradient_as_bucket_view=True`,
+bf16 autocast with fp32 master weights (no GradScaler needed), and no per-step
+host synchronisation (the reference's meters call .item() every step).
+The hot path has no collective of its own: (image, head, chunk) units are
+independent, so the batch is simply sharded across ranks."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .msvit import MsViT, vil_arch
+
+CONFIGS = {
+    # name: (arch family, image size, per-GPU batch, stage-1 window, stage-2 window, random-shift mode)
+    "vil_tiny_224": ("tiny", 224, 2, 7, 7, 0),
+    "vil_small_224": ("small", 224, 128, 7, 7, 0),
+    "vil_medium_deep_384": ("medium_deep", 384, 32, 7, 7, 0),
+    "vil_medium_deep_384_f8f12": ("medium_deep", 384, 32, 8, 12, 0),
+    "vil_base_deep_384_rs": ("base_deep", 384, 32, 6, 8, 1),
+}
+
+
+def init_distributed():
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun / torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available()
+    device = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if use_cuda:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, local_rank, world, device
+
+
+def build_vil(config, drop_path_rate=0.1, num_classes=1000, **overrides):
+    fam, img, _, f1, f2, mode = CONFIGS[config]
+    kw = dict(img_size=img, num_classes=num_classes, drop_path_rate=drop_path_rate, norm_embed=True,
+              sharew=True, attn_type="longformerhand", mode=mode)
+    kw.update(overrides)
+    return MsViT(vil_arch(fam, f1, f2), **kw)
+
+
+def param_groups(model, weight_decay):
+    """No weight decay on the substrings MsViT.no_weight_decay() lists
+    (reference optim/__init__.py:14-64 behaviour)."""
+    skip = model.no_weight_decay()
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (p.ndim <= 1 or any(s in n for s in skip)) else decay).append(p)
+    return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
+
+
+def make_optimizer(model, lr=1e-3, weight_decay=0.05):
+    fused = next(model.parameters()).is_cuda
+    return torch.optim.AdamW(param_groups(model, weight_decay), lr=lr, betas=(0.9, 0.999), fused=fused)
+
+
+def wrap_ddp(model, device, world):
+    if world <= 1:
+        return model
+    ids = [device.index] if device.type == "cuda" else None
+    return torch.nn.parallel.DistributedDataParallel(
+        model, device_ids=ids, broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=32)
+
+
+class SyntheticBatches:
+    """ImageNet-shape batches resident on the device: N(0,1) images, label-smoothed
+    one-hot soft targets (what the reference's mixup path feeds the loss)."""
+
+    def __init__(self, batch, img_size, device, rank=0, num_classes=1000, n_distinct=2, smoothing=0.1):
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.items = []
+        for _ in range(n_distinct):
+            x = torch.randn(batch, 3, img_size, img_size, generator=g)
+            y = torch.randint(0, num_classes, (batch,), generator=g)
+            t = torch.full((batch, num_classes), smoothing / num_classes)
+            t.scatter_(1, y[:, None], 1.0 - smoothing + smoothing / num_classes)
+            self.items.append((x.to(device), t.to(device)))
+        self.i = 0
+
+    def next(self):
+        self.i = (self.i + 1) % len(self.items)
+        return self.items[self.i]
+
+
+def soft_target_cross_entropy(logits, target):
+    return torch.sum(-target * F.log_softmax(logits.float(), dim=-1), dim=-1).mean()
+
+
+def train_step(model, optimizer, images, targets, amp_dtype=torch.bfloat16):
+    """forward + backward (DDP all-reduce overlaps) + optimizer step; returns the
+    loss tensor without synchronising."""
+    dev_type = images.device.type
+    with torch.autocast(dev_type, dtype=amp_dtype, enabled=amp_dtype is not None):
+        loss = soft_target_cross_entropy(model(images), targets)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    optimizer.step()
+    return loss.detach()
