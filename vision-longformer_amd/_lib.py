@@ -6,6 +6,11 @@ raises."""
 import ctypes
 import os
 
+# torch must be imported BEFORE the library is dlopen'ed: PyTorch-ROCm ships its own
+# libamdhip64; loading ours first would bind libvilattn.so to a second HIP runtime
+# (/opt/rocm) that does not share torch's device context and streams.
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvilattn.so")
 
