@@ -159,11 +159,11 @@ MFMA_CASES = [c for c in SMALL if c["exact"] != -1 and not c["only_glo"] and c["
 
 @pytest.mark.parametrize("c", MFMA_CASES, ids=_cid)
 def test_mfma_bf16_vs_oracle(c, dev):
-    """MFMA forward (+ whatever backward family AUTO picks) on bf16 I/O."""
+    """MFMA forward AND backward (backend forced: unsupported shapes would raise) on bf16 I/O."""
     inp = make_inputs(c, torch.bfloat16)
     ref = run_oracle(c, *inp)
-    got = run_hip(c, *inp, torch.bfloat16, "auto", dev)
-    compare("auto(mfma fwd)/bf16 " + _cid(c), got, ref, BF16_TOL)
+    got = run_hip(c, *inp, torch.bfloat16, "mfma", dev)
+    compare("mfma/bf16 " + _cid(c), got, ref, BF16_TOL)
 
 
 @pytest.mark.parametrize("c", [MFMA_CASES[0], MFMA_CASES[10], MFMA_CASES[11]], ids=_cid)
@@ -185,7 +185,7 @@ def test_mfma_forced_rescale_branch(dev):
     ki = 1 + 13 * 14 + 13
     kv[:, ki, :C] = (q[:, qi] * 6).bfloat16().float()
     ref = run_oracle(c, q, kv, table, g2l, dout)
-    got = run_hip(c, q, kv, table, g2l, dout, torch.bfloat16, "auto", dev)
+    got = run_hip(c, q, kv, table, g2l, dout, torch.bfloat16, "mfma", dev)
     compare("mfma spike " + _cid(c), got, ref, BF16_TOL)
 
 
@@ -305,7 +305,7 @@ def test_full_size_properties(name, c, dev):
         assert d < 3e-2
     c1 = dict(c, B=1)
     ref = run_oracle(c1, q[:1], kv[:1], table, g2l, dout[:1])
-    got = run_hip(c1, q[:1], kv[:1], table, g2l, dout[:1], torch.bfloat16, "auto", dev)
+    got = run_hip(c1, q[:1], kv[:1], table, g2l, dout[:1], torch.bfloat16, "mfma", dev)
     compare("full " + name, got, ref, BF16_TOL)
 
 

@@ -26,41 +26,7 @@
 //        third MFMA against a constant ones-row, so the VALU never adds them.
 //
 // Reference semantics: src/models/layers/longformer2d.py:134-204 (see include/vil_attn.h).
-#include "vil_internal.h"
-#include <string.h>
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-#define VIL_MASK_VAL (-1.0e30f)
-#define VIL_M_INIT (-1.0e20f)
-#define LOG2E 1.4426950408889634f
-
-struct MfmaCfg {
-  int P;             // row pitch (floats) of the LDS bias table
-  int copysize;      // floats per table copy (multiple of 4)
-  int cstride_b;     // (copysize - 1) * 4: byte offset between consecutive shifted copies
-  int guard0;        // start (floats) of the all-masked region
-  int glo0;          // start of the per-global-token constant regions
-  int gsz;           // size of one such region (Aq range + 4)
-  int aconst;        // (2W-1)*(P+1)
-  unsigned magicW, magicW2;
-  int HQ;            // query quads per chunk row = ceil(W/4)
-  int NWP;           // waves per chunk = ceil(W*HQ/16)
-  int NS;            // real key slots = G + nact*W2
-  int NSP;           // padded to a multiple of 32
-  int units_bh;      // mx*my*NWP
-  int wg_per_bh, gpw;
-  int wave_lds;      // bytes of private LDS per wave
-  int no_tr;         // debug: read V^T with scalar LDS loads instead of ds_read_b64_tr_b16
-  const float* tabws;  // (H, 4*copysize) prepared bias tables
-};
-
-__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned magic) { return __umulhi(n, magic); }
+#include "vil_mfma_common.h"
 
 // ------------------------------------------------------------------ table prologue
 // Logical table of one head, stored 4 times, copy c shifted by c floats so that any
@@ -356,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
 }
 
 // ===================================================================== host side
-static bool mfma_cfg(const VilAttnDesc* d, MfmaCfg& c) {
+bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   memset(&c, 0, sizeof(c));
   VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
   const int W = d->W;
@@ -392,8 +358,10 @@ static bool mfma_cfg(const VilAttnDesc* d, MfmaCfg& c) {
 
 static size_t mfma_lds_bytes(const MfmaCfg& c) { return (size_t)c.copysize * 16 + 4 * (size_t)c.wave_lds; }
 
+int vil_mfma_bwd_supported(const VilAttnDesc* d);
+size_t vil_mfma_bwd_workspace(const VilAttnDesc* d);
+
 int vil_mfma_supported(const VilAttnDesc* d, int pass) {
-  if (pass != 0) return VIL_E_BACKEND;                 // backward: scalar family for now
   if (d->dtype != VIL_DTYPE_BF16) return VIL_E_DTYPE;
   if (d->M != 16 && d->M != 32 && d->M != 48 && d->M != 64) return VIL_E_HEAD_DIM;
   if (d->W < 1 || d->W > 16) return VIL_E_WINDOW;
@@ -402,19 +370,19 @@ int vil_mfma_supported(const VilAttnDesc* d, int pass) {
   // 16-byte row loads: token/batch/head strides and M must keep rows 16-byte aligned
   if ((d->q_st | d->k_st | d->v_st | d->q_sb | d->k_sb | d->v_sb | d->q_sh | d->k_sh | d->v_sh) & 7) return VIL_E_ALIGN;
   if ((d->o_st | d->o_sb | d->o_sh) & 3) return VIL_E_ALIGN;
-  MfmaCfg c; mfma_cfg(d, c);
+  MfmaCfg c; vil_mfma_make_cfg(d, c);
   if (mfma_lds_bytes(c) > 160 * 1024) return VIL_E_BACKEND;
-  return VIL_OK;
+  return pass == 0 ? VIL_OK : vil_mfma_bwd_supported(d);
 }
 
 size_t vil_mfma_workspace(const VilAttnDesc* d, int pass) {
-  if (pass != 0) return 0;
-  MfmaCfg c; mfma_cfg(d, c);
+  if (pass != 0) return vil_mfma_bwd_workspace(d);
+  MfmaCfg c; vil_mfma_make_cfg(d, c);
   return (size_t)d->H * 4 * c.copysize * sizeof(float);
 }
 
 int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
-  MfmaCfg c; mfma_cfg(d, c);
+  MfmaCfg c; vil_mfma_make_cfg(d, c);
   float* tabws = (float*)p.delta;          // workspace base
   c.tabws = tabws;
   if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)tabws) & 15) return VIL_E_ALIGN;
@@ -447,5 +415,3 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   vil_prof_end(s);
   return (int)hipGetLastError();
 }
-
-int vil_mfma_bwd(const VilAttnDesc*, VilParams&, hipStream_t) { return VIL_E_BACKEND; }

@@ -1,0 +1,727 @@
+// vil_attn_mfma_bwd.hip -- MFMA backward of the fused local attention (bf16 I/O,
+// fp32 accumulate), FlashAttention-2 style: probabilities are recomputed from the
+// saved log-sum-exp, no score tensor exists.  Two passes, no atomics on dQ/dK/dV:
+//
+//   k_mfma_bwd_dq    one wave per QUERY chunk, same traversal as the forward:
+//                    S^T = K Q^T + bias, P^T = exp2(S^T c - lse), dP^T = V dO^T,
+//                    dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T.  K is staged once per
+//                    step in the wave's LDS tile and read both ways (ds_read_b128 rows for
+//                    the S^T product, ds_read_b64_tr_b16 for K^T).  dS is also accumulated
+//                    into a per-workgroup LDS histogram over the bias-table layout, which
+//                    yields d(bias table) and d(g2l) after a small cross-workgroup reduce.
+//   k_mfma_bwd_dkdv  one wave per KEY chunk (the mirror of slidingchunk_agrad's reverse
+//                    rolls, slidingchunk_2d.py:156-190): streams the <= 9 query chunks that
+//                    attend it, S = Q K^T + bias, P, dP = dO V^T, dS; dV^T += dO^T P,
+//                    dK^T += Q^T dS.  The G global keys (attended by every local query) are
+//                    extra owner units that stream all query chunks in splits and leave
+//                    fp32 partials for a tiny reduce.
+//
+// Reference semantics: SlidingChunk2D.backward (src/models/layers/slidingchunk_2d.py:234-246)
+// plus the autograd of bias gather / mask / softmax in longformer2d.py:152-200.
+#include "vil_mfma_common.h"
+
+#define LSE_PAD 1.0e30f
+
+struct BwdCfg {
+  int nch;            // query/key chunks per (image, head) = mx*my
+  int nsplit;         // global-key owner units per (image, head)
+  int units_kv_bh;    // nch*NWP + (G ? nsplit : 0)
+  int kv_wg_per_bh, kv_gpw;
+  int nqs;            // streamed query slots per owner unit (padded to 32)
+  int kv_wave_lds, dq_wave_lds;
+  int do_hist;
+  float* hist_parts;  // (dq workgroups, copysize)
+  float* glo_parts;   // (B*H, nsplit, G, 2, M)
+  int dq_nwg;
+};
+
+// ===================================================================== dQ pass
+template <int MD>
+__global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, BwdCfg bc) {
+  constexpr int M = 16 * MD;
+  constexpr int MK = (MD + 1) / 2;
+  constexpr int VCH = 2 * MD;
+  constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const VilGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lj = lane & 15, lg = lane >> 4;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bh = logical / c.wg_per_bh, wgi = logical % c.wg_per_bh;
+  const int b = bh / p.H, h = bh % p.H;
+
+  float* tab = (float*)smem;
+  float* hist = tab + 4 * c.copysize;
+  {
+    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * 4 * c.copysize);
+    for (int i = tid; i < c.copysize; i += 256) ((f32x4*)tab)[i] = src[i];
+    for (int i = tid; i < c.copysize; i += 256) hist[i] = 0.f;
+  }
+  __syncthreads();
+
+  char* wbase = smem + (size_t)c.copysize * 20 + (size_t)wave * bc.dq_wave_lds;
+  int* s_koff = (int*)wbase;
+  int* s_akey = s_koff + c.NSP;
+  __bf16* s_k = (__bf16*)(s_akey + c.NSP);          // [32][M] K tile of the current step
+
+  const __bf16* qb = (const __bf16*)p.q + b * p.q_sb + h * p.q_sh;
+  const __bf16* kb = (const __bf16*)p.k + b * p.k_sb + h * p.k_sh;
+  const __bf16* vb = (const __bf16*)p.v + b * p.v_sb + h * p.v_sh;
+  const __bf16* dob = (const __bf16*)p.dout + b * p.do_sb + h * p.do_sh;
+  __bf16* dqb = (__bf16*)p.dq + b * p.dq_sb + h * p.dq_sh;
+  const int Nloc = g.nx * g.ny;
+  const float c1 = p.scale * LOG2E;
+  const int W = g.W, W2 = g.W2;
+
+  for (int gi = 0; gi < c.gpw; ++gi) {
+    const int unit = (wgi * c.gpw + gi) * 4 + wave;
+    if (unit < c.units_bh) {
+      const int wp = unit % c.NWP, ch = unit / c.NWP;
+      const int cn = ch % g.my, cm = ch / g.my;
+      const int own_tok = p.G + (cm * W) * g.ny + cn * W;
+      for (int s = lane; s < c.NSP; s += 64) {
+        int tok = own_tok, ak = -c.guard0;
+        if (s < p.G) {
+          tok = s; ak = -(c.glo0 + s * c.gsz);
+        } else if (s < c.NS) {
+          const unsigned sl = s - p.G;
+          const int a = fdiv(sl, c.magicW2), t = sl - a * W2;
+          const int xt = fdiv(t, c.magicW), yt = t - xt * W;
+          const int a3 = (a * 11) >> 5;
+          const int dr = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : g.adr[1]);
+          const int dc = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : g.adc[1]);
+          int kr, kc;
+          if (vil_key_state(g, cm, cn, dr, dc, xt, yt, kr, kc) == VIL_KEY_REAL) {
+            tok = p.G + kr * g.ny + kc;
+            ak = (dr * W + xt) * c.P + (dc * W + yt) - c.aconst;
+          }
+        }
+        s_koff[s] = tok; s_akey[s] = ak * 4;
+      }
+      const int jj = wp * 16 + lj;
+      const int qx = jj / c.HQ, qhq = jj % c.HQ;
+      const int aq0b = (min(qx, W - 1) * c.P + 4 * qhq) * 4;
+      int qtok[4];
+      bool qreal[4];
+      float lse2[4], dlt[4];
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        const int qy = 4 * qhq + qt;
+        const int qr = cm * W + qx, qc = cn * W + qy;
+        qreal[qt] = qx < W && qy < W && qr < g.nx && qc < g.ny;
+        qtok[qt] = qreal[qt] ? qr * g.ny + qc : own_tok - p.G;
+        // a non-existent query slot gets lse = +big: its probabilities (hence dS) are exactly 0
+        lse2[qt] = qreal[qt] ? p.lse[(int64_t)bh * Nloc + qtok[qt]] * LOG2E : LSE_PAD;
+        dlt[qt] = qreal[qt] ? p.delta[(int64_t)bh * Nloc + qtok[qt]] : 0.f;
+      }
+      bf16x8 qf[MK][4], dof[MK][4];
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < MK; ++ks) {
+          const int d0 = ks * 32 + lg * 8;
+          bf16x8 z = {};
+          qf[ks][qt] = d0 < M ? *(const bf16x8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
+          dof[ks][qt] = d0 < M ? *(const bf16x8*)(dob + (int64_t)qtok[qt] * p.do_st + d0) : z;
+        }
+      f32x4 dq[MD][4];
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < MD; ++dt) dq[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      const int nsteps = c.NSP >> 5;
+      bf16x8 vf[2][MK];
+      u32x4 kr_[MD];
+      auto load_step = [&](int st) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int tok = s_koff[st * 32 + hf * 16 + lj];
+#pragma unroll
+          for (int ks = 0; ks < MK; ++ks) {
+            const int d0 = ks * 32 + lg * 8;
+            bf16x8 z = {};
+            vf[hf][ks] = d0 < M ? *(const bf16x8*)(vb + (int64_t)tok * p.v_st + d0) : z;
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < MD; ++it) {
+          const int cid = it * 64 + lane;
+          const int row = cid / VCH, chn = cid % VCH;
+          const int tok = s_koff[st * 32 + row];
+          kr_[it] = *(const u32x4*)(kb + (int64_t)tok * p.k_st + chn * 8);
+        }
+      };
+      load_step(0);
+
+      for (int st = 0; st < nsteps; ++st) {
+        bf16x8 vc[2][MK];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int ks = 0; ks < MK; ++ks) vc[hf][ks] = vf[hf][ks];
+#pragma unroll
+        for (int it = 0; it < MD; ++it) {
+          const int cid = it * 64 + lane;
+          const int row = cid / VCH, chn = cid % VCH;
+          *(u32x4*)((char*)s_k + row * (M * 2) + ((chn * 16) ^ (SWZ * (((row >> 2) & 1) << 5)))) = kr_[it];
+        }
+        int ak[2][4];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const i32x4 a4 = *(const i32x4*)(s_akey + st * 32 + hf * 16 + lg * 4);
+          ak[hf][0] = a4[0]; ak[hf][1] = a4[1]; ak[hf][2] = a4[2]; ak[hf][3] = a4[3];
+        }
+        if (st + 1 < nsteps) load_step(st + 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        bf16x8 dsb[4];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          // K rows of this half as the A operand (natural layout, from the LDS tile)
+          bf16x8 kc_[MK];
+#pragma unroll
+          for (int ks = 0; ks < MK; ++ks) {
+            const int d0 = ks * 32 + lg * 8;
+            const int row = hf * 16 + lj;
+            bf16x8 z = {};
+            kc_[ks] = d0 < M ? *(const bf16x8*)((const char*)s_k + row * (M * 2) +
+                                                ((d0 * 2) ^ (SWZ * (((row >> 2) & 1) << 5)))) : z;
+          }
+          unsigned i0[4];
+          f32x4 bq[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            i0[r] = (unsigned)(aq0b - ak[hf][r]);
+            const unsigned addr = i0[r] + ((i0[r] >> 2) & 3u) * (unsigned)c.cstride_b;
+            bq[r] = *(const f32x4*)((const char*)tab + addr);
+          }
+#pragma unroll
+          for (int qt = 0; qt < 4; ++qt) {
+            f32x4 acc = {bq[0][qt], bq[1][qt], bq[2][qt], bq[3][qt]};
+            f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < MK; ++ks) {
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_[ks], qf[ks][qt], acc, 0, 0, 0);
+              dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc[hf][ks], dof[ks][qt], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], c1, -lse2[qt]));
+              const float ds = pr * (dp[r] - dlt[qt]);
+              dsb[qt][hf * 4 + r] = (__bf16)ds;
+              if (bc.do_hist) atomicAdd((float*)((char*)hist + i0[r]) + qt, ds);
+            }
+          }
+        }
+        // dQ^T += K^T dS^T
+#pragma unroll
+        for (int dt = 0; dt < MD; ++dt) {
+          bf16x8 kt_;
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int row = hf * 16 + lg * 4 + (lj >> 2);
+            const int off = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
+            const s16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)((char*)s_k + off));
+            const bf16x4 tb = __builtin_bit_cast(bf16x4, t4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kt_[hf * 4 + e] = tb[e];
+          }
+#pragma unroll
+          for (int qt = 0; qt < 4; ++qt)
+            dq[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsb[qt], dq[dt][qt], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+        if (qreal[qt]) {
+#pragma unroll
+          for (int dt = 0; dt < MD; ++dt) {
+            bf16x4 w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = (__bf16)(dq[dt][qt][r] * p.scale);
+            *(bf16x4*)(dqb + (int64_t)qtok[qt] * p.dq_st + dt * 16 + lg * 4) = w;
+          }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (bc.do_hist) {
+    __syncthreads();
+    float* out = bc.hist_parts + (int64_t)logical * c.copysize;
+    for (int i = tid; i < c.copysize; i += 256) out[i] = hist[i];
+  }
+}
+
+// d(table)[idx*H+h] and d(g2l)[h*G+g] from the per-workgroup histograms.
+// grid (ceil(copysize/64), H), block 256 = 64 bins x 4 partial groups.
+__global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
+  __shared__ float red[4][64];
+  const int h = blockIdx.y;
+  const int bin = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  float s = 0.f;
+  if (bin < c.copysize) {
+    // workgroups of head h: logical = (b*H + h)*wg_per_bh + w
+    const int per = c.wg_per_bh;
+    for (int i = grp; i < p.B * per; i += 4) {
+      const int b = i / per, w = i % per;
+      s += bc.hist_parts[((int64_t)(b * p.H + h) * per + w) * c.copysize + bin];
+    }
+  }
+  red[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp == 0 && bin < c.copysize) {
+    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    const int tbl = p.g.tbl;
+    if (bin < tbl * c.P) {
+      const int row = bin / c.P, col = bin % c.P;
+      if (col < tbl && p.dtable) p.dtable[(int64_t)(row * tbl + col) * p.H + h] = s;
+    } else if (bin >= c.glo0 && p.dg2l) {
+      const int gg = (bin - c.glo0) / c.gsz;
+      if (gg < p.G) atomicAdd(&p.dg2l[h * p.G + gg], s);
+    }
+  }
+}
+
+// ===================================================================== dK/dV pass
+template <int MD>
+__global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
+  constexpr int M = 16 * MD;
+  constexpr int MK = (MD + 1) / 2;
+  constexpr int VCH = 2 * MD;
+  constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const VilGeom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lj = lane & 15, lg = lane >> 4;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bh = logical / bc.kv_wg_per_bh, wgi = logical % bc.kv_wg_per_bh;
+  const int b = bh / p.H, h = bh % p.H;
+
+  float* tab = (float*)smem;
+  {
+    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * 4 * c.copysize);
+    for (int i = tid; i < c.copysize; i += 256) ((f32x4*)tab)[i] = src[i];
+  }
+  __syncthreads();
+
+  char* wbase = smem + (size_t)c.copysize * 16 + (size_t)wave * bc.kv_wave_lds;
+  int* s_tok = (int*)wbase;                       // [nqs] local token of each streamed query slot
+  int* s_aq = s_tok + bc.nqs;                     // [nqs] bias-table address term (bytes)
+  float* s_lse = (float*)(s_aq + bc.nqs);         // [nqs] lse * log2(e)   (+big for padding slots)
+  float* s_dlt = s_lse + bc.nqs;                  // [nqs] delta
+  __bf16* s_q = (__bf16*)(s_dlt + bc.nqs);        // [32][M] Q tile
+  __bf16* s_do = s_q + 32 * M;                    // [32][M] dO tile
+
+  const __bf16* qb = (const __bf16*)p.q + b * p.q_sb + h * p.q_sh;
+  const __bf16* kb = (const __bf16*)p.k + b * p.k_sb + h * p.k_sh;
+  const __bf16* vb = (const __bf16*)p.v + b * p.v_sb + h * p.v_sh;
+  const __bf16* dob = (const __bf16*)p.dout + b * p.do_sb + h * p.do_sh;
+  __bf16* dkb = (__bf16*)p.dk + b * p.dk_sb + h * p.dk_sh;
+  __bf16* dvb = (__bf16*)p.dv + b * p.dv_sb + h * p.dv_sh;
+  const int Nloc = g.nx * g.ny;
+  const float c1 = p.scale * LOG2E;
+  const int W = g.W, W2 = g.W2;
+  const int nown = bc.nch * c.NWP;
+
+  for (int gi = 0; gi < bc.kv_gpw; ++gi) {
+    const int unit = (wgi * bc.kv_gpw + gi) * 4 + wave;
+    if (unit >= bc.units_kv_bh) break;
+    const bool glo = unit >= nown;                 // global-key owner unit
+    const int split = unit - nown;
+    const int wp = glo ? 0 : unit % c.NWP, ch = glo ? 0 : unit / c.NWP;
+    const int kn = ch % g.my, km = ch / g.my;
+
+    // ---- streamed query slot table
+    for (int s = lane; s < bc.nqs; s += 64) {
+      const int ci = fdiv(s, c.magicW2), l = s - ci * W2;
+      const int xl = fdiv(l, c.magicW), yl = l - xl * W;
+      int qm = -1, qn = -1, dr = 0, dc = 0;
+      if (glo) {
+        const int qch = split + ci * bc.nsplit;
+        if (qch < bc.nch) { qm = qch / g.my; qn = qch % g.my; }
+      } else {
+        int cnt = 0;
+        for (int a = 0; a < g.nact; ++a) {
+          const int a3 = (a * 11) >> 5;
+          const int ar = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : g.adr[1]);
+          const int ac = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : g.adc[1]);
+          const int m_ = km - ar, n_ = kn - ac;
+          const bool ok = m_ >= 0 && m_ < g.mx && n_ >= 0 && n_ < g.my;
+          if (ok && cnt == ci) { qm = m_; qn = n_; dr = ar; dc = ac; }
+          cnt += ok;
+        }
+      }
+      int tok = 0, aq = c.aconst * 4;
+      float ls = LSE_PAD, dl = 0.f;
+      if (qm >= 0) {
+        const int qr = qm * W + xl, qc = qn * W + yl;
+        if (qr < g.nx && qc < g.ny) {
+          tok = qr * g.ny + qc;
+          ls = p.lse[(int64_t)bh * Nloc + tok] * LOG2E;
+          dl = p.delta[(int64_t)bh * Nloc + tok];
+          aq = glo ? 0 : ((xl - dr * W) * c.P + (yl - dc * W) + c.aconst) * 4;
+        }
+      }
+      if (glo && !(qm >= 0 && ls < LSE_PAD)) aq = 0;
+      s_tok[s] = tok; s_aq[s] = aq; s_lse[s] = ls; s_dlt[s] = dl;
+    }
+    // number of steps actually needed (trailing all-padding steps are skipped)
+    int nchunks;
+    if (glo) {
+      nchunks = (bc.nch - split + bc.nsplit - 1) / bc.nsplit;
+    } else {
+      nchunks = 0;
+      for (int a = 0; a < g.nact; ++a) {
+        const int m_ = km - g.adr[a], n_ = kn - g.adc[a];
+        nchunks += (m_ >= 0 && m_ < g.mx && n_ >= 0 && n_ < g.my);
+      }
+    }
+    const int nsteps = (nchunks * W2 + 31) >> 5;
+
+    // ---- this lane's key slots: column j of key-tile kt is key (x, y = 4*hq + 3 - kt)
+    const int jj = wp * 16 + lj;
+    const int kx = jj / c.HQ, khq = jj % c.HQ;
+    const int akl = glo ? -(c.glo0 + min(lj, max(p.G - 1, 0)) * c.gsz) * 4
+                        : (min(kx, W - 1) * c.P + 4 * khq + 3) * 4;
+    int ktok[4];
+    bool kreal[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if (glo) {
+        kreal[kt] = kt == 0 && lj < p.G;
+        ktok[kt] = kreal[kt] ? lj : 0;
+      } else {
+        const int ky = 4 * khq + 3 - kt;
+        const int kr = km * W + kx, kc = kn * W + ky;
+        kreal[kt] = kx < W && ky < W && kr < g.nx && kc < g.ny;
+        ktok[kt] = p.G + (kreal[kt] ? kr * g.ny + kc : (km * W) * g.ny + kn * W);
+      }
+    }
+    bf16x8 kfb[MK][4], vfb[MK][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < MK; ++ks) {
+        const int d0 = ks * 32 + lg * 8;
+        bf16x8 z = {};
+        kfb[ks][kt] = d0 < M ? *(const bf16x8*)(kb + (int64_t)ktok[kt] * p.k_st + d0) : z;
+        vfb[ks][kt] = d0 < M ? *(const bf16x8*)(vb + (int64_t)ktok[kt] * p.v_st + d0) : z;
+      }
+    f32x4 dk[MD][4], dv[MD][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int dt = 0; dt < MD; ++dt) {
+        dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    u32x4 qr_[MD], dr_[MD];
+    auto load_step = [&](int st) {
+#pragma unroll
+      for (int it = 0; it < MD; ++it) {
+        const int cid = it * 64 + lane;
+        const int row = cid / VCH, chn = cid % VCH;
+        const int tok = s_tok[st * 32 + row];
+        qr_[it] = *(const u32x4*)(qb + (int64_t)tok * p.q_st + chn * 8);
+        dr_[it] = *(const u32x4*)(dob + (int64_t)tok * p.do_st + chn * 8);
+      }
+    };
+    if (nsteps > 0) load_step(0);
+
+    for (int st = 0; st < nsteps; ++st) {
+#pragma unroll
+      for (int it = 0; it < MD; ++it) {
+        const int cid = it * 64 + lane;
+        const int row = cid / VCH, chn = cid % VCH;
+        const int off = row * (M * 2) + ((chn * 16) ^ (SWZ * (((row >> 2) & 1) << 5)));
+        *(u32x4*)((char*)s_q + off) = qr_[it];
+        *(u32x4*)((char*)s_do + off) = dr_[it];
+      }
+      if (st + 1 < nsteps) load_step(st + 1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      bf16x8 pb[4], dsb[4];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        bf16x8 qa[MK], da[MK];
+#pragma unroll
+        for (int ks = 0; ks < MK; ++ks) {
+          const int d0 = ks * 32 + lg * 8;
+          const int row = hf * 16 + lj;
+          const int off = row * (M * 2) + ((d0 * 2) ^ (SWZ * (((row >> 2) & 1) << 5)));
+          bf16x8 z = {};
+          qa[ks] = d0 < M ? *(const bf16x8*)((const char*)s_q + off) : z;
+          da[ks] = d0 < M ? *(const bf16x8*)((const char*)s_do + off) : z;
+        }
+        const int sb = st * 32 + hf * 16 + lg * 4;
+        const i32x4 aq4 = *(const i32x4*)(s_aq + sb);
+        const f32x4 ls4 = *(const f32x4*)(s_lse + sb);
+        const f32x4 dl4 = *(const f32x4*)(s_dlt + sb);
+        f32x4 bq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned i0 = (unsigned)(aq4[r] - akl);
+          const unsigned addr = i0 + ((i0 >> 2) & 3u) * (unsigned)c.cstride_b;
+          bq[r] = *(const f32x4*)((const char*)tab + addr);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          f32x4 acc = {bq[0][kt], bq[1][kt], bq[2][kt], bq[3][kt]};
+          f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < MK; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kfb[ks][kt], acc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[ks], vfb[ks][kt], dp, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], c1, -ls4[r]));
+            pb[kt][hf * 4 + r] = (__bf16)pr;
+            dsb[kt][hf * 4 + r] = (__bf16)(pr * (dp[r] - dl4[r]));
+          }
+        }
+      }
+      // dV^T += dO^T P ; dK^T += Q^T dS
+#pragma unroll
+      for (int dt = 0; dt < MD; ++dt) {
+        bf16x8 qt_, dt_;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int row = hf * 16 + lg * 4 + (lj >> 2);
+          const int off = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
+          const bf16x4 tq = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)((char*)s_q + off)));
+          const bf16x4 td = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)((char*)s_do + off)));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { qt_[hf * 4 + e] = tq[e]; dt_[hf * 4 + e] = td[e]; }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt_, pb[kt], dv[dt][kt], 0, 0, 0);
+          dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsb[kt], dk[dt][kt], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- epilogue
+    if (!glo) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        if (kreal[kt]) {
+#pragma unroll
+          for (int dt = 0; dt < MD; ++dt) {
+            bf16x4 wk, wv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              wk[r] = (__bf16)(dk[dt][kt][r] * p.scale);
+              wv[r] = (__bf16)dv[dt][kt][r];
+            }
+            *(bf16x4*)(dkb + (int64_t)ktok[kt] * p.dk_st + dt * 16 + lg * 4) = wk;
+            *(bf16x4*)(dvb + (int64_t)ktok[kt] * p.dv_st + dt * 16 + lg * 4) = wv;
+          }
+        }
+    } else if (kreal[0]) {
+      float* out = bc.glo_parts + ((((int64_t)bh * bc.nsplit + split) * p.G + lj) * 2) * M;
+#pragma unroll
+      for (int dt = 0; dt < MD; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          out[dt * 16 + lg * 4 + r] = dk[dt][0][r] * p.scale;
+          out[M + dt * 16 + lg * 4 + r] = dv[dt][0][r];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// dk/dv rows of the G global tokens = sum over the splits' fp32 partials
+__global__ void k_mfma_reduce_glo(VilParams p, BwdCfg bc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int M = p.M;
+  if (i >= p.B * p.H * p.G * M) return;
+  const int d = i % M; const int gk = (i / M) % p.G; const int bh = i / (M * p.G);
+  const int b = bh / p.H, h = bh % p.H;
+  float sk = 0.f, sv = 0.f;
+  for (int s = 0; s < bc.nsplit; ++s) {
+    const float* rec = bc.glo_parts + ((((int64_t)bh * bc.nsplit + s) * p.G + gk) * 2) * M;
+    sk += rec[d]; sv += rec[M + d];
+  }
+  *((vil_bf16*)p.dk + b * p.dk_sb + (int64_t)gk * p.dk_st + h * p.dk_sh + d) = vil_f2bf(sk);
+  *((vil_bf16*)p.dv + b * p.dv_sb + (int64_t)gk * p.dv_st + h * p.dv_sh + d) = vil_f2bf(sv);
+}
+
+// rowsum(dO * O): one thread per (image, head, token)
+template <int MD>
+__global__ void k_mfma_delta(VilParams p) {
+  constexpr int M = 16 * MD;
+  const int Nloc = p.g.nx * p.g.ny;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)p.B * p.H * Nloc) return;
+  const int tok = i % Nloc; const int bh = i / Nloc; const int b = bh / p.H, h = bh % p.H;
+  const __bf16* op = (const __bf16*)p.out + b * p.o_sb + (int64_t)tok * p.o_st + h * p.o_sh;
+  const __bf16* dp = (const __bf16*)p.dout + b * p.do_sb + (int64_t)tok * p.do_st + h * p.do_sh;
+  float s = 0.f;
+#pragma unroll
+  for (int d0 = 0; d0 < M; d0 += 8) {
+    const bf16x8 a = *(const bf16x8*)(op + d0), c = *(const bf16x8*)(dp + d0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = __builtin_fmaf((float)a[e], (float)c[e], s);
+  }
+  p.delta[i] = s;
+}
+
+// ===================================================================== host side
+static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
+  memset(&bc, 0, sizeof(bc));
+  VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
+  bc.nch = g.mx * g.my;
+  bc.nsplit = d->G > 0 ? (bc.nch + 8) / 9 : 0;
+  bc.units_kv_bh = bc.nch * c.NWP + bc.nsplit;
+  const int groups = (bc.units_kv_bh + 3) / 4;
+  int gpw = (int)(((int64_t)d->B * d->H * groups) / 2048);
+  if (gpw < 1) gpw = 1;
+  if (gpw > groups) gpw = groups;
+  bc.kv_gpw = gpw;
+  bc.kv_wg_per_bh = (groups + gpw - 1) / gpw;
+  bc.nqs = (9 * g.W2 + 31) & ~31;
+  bc.kv_wave_lds = ((bc.nqs * 16 + 2 * 32 * d->M * 2 + 15) / 16) * 16;
+  bc.dq_wave_lds = ((c.NSP * 8 + 32 * d->M * 2 + 15) / 16) * 16;
+  bc.dq_nwg = d->B * d->H * c.wg_per_bh;
+}
+
+static size_t dq_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.copysize * 20 + 4 * (size_t)bc.dq_wave_lds; }
+static size_t kv_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.copysize * 16 + 4 * (size_t)bc.kv_wave_lds; }
+
+int vil_mfma_bwd_supported(const VilAttnDesc* d) {
+  if ((d->do_st | d->do_sb | d->do_sh) & 7) return VIL_E_ALIGN;
+  if ((d->dq_st | d->dq_sb | d->dq_sh | d->dk_st | d->dk_sb | d->dk_sh | d->dv_st | d->dv_sb | d->dv_sh) & 3) return VIL_E_ALIGN;
+  MfmaCfg c; vil_mfma_make_cfg(d, c);
+  BwdCfg bc; bwd_cfg(d, c, bc);
+  if (dq_lds(c, bc) > 160 * 1024 || kv_lds(c, bc) > 160 * 1024) return VIL_E_BACKEND;
+  return VIL_OK;
+}
+
+// floats: [delta | table copies | hist partials | global-key partials]
+static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& bc, size_t off[5]) {
+  const size_t rows = (size_t)d->B * d->H * d->nx * d->ny;
+  off[0] = 0;
+  off[1] = (rows + 3) & ~(size_t)3;
+  off[2] = off[1] + (size_t)d->H * 4 * c.copysize;
+  off[3] = off[2] + (size_t)bc.dq_nwg * c.copysize;
+  off[4] = off[3] + (size_t)d->B * d->H * bc.nsplit * d->G * 2 * d->M;
+}
+
+size_t vil_mfma_bwd_workspace(const VilAttnDesc* d) {
+  MfmaCfg c; vil_mfma_make_cfg(d, c);
+  BwdCfg bc; bwd_cfg(d, c, bc);
+  size_t off[5]; bwd_ws_layout(d, c, bc, off);
+  return off[4] * sizeof(float) + 64;
+}
+
+int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
+  MfmaCfg c; vil_mfma_make_cfg(d, c);
+  BwdCfg bc; bwd_cfg(d, c, bc);
+  size_t off[5]; bwd_ws_layout(d, c, bc, off);
+  float* ws = (float*)p.delta;
+  if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.dout | (uintptr_t)p.out | (uintptr_t)ws) & 15)
+    return VIL_E_ALIGN;
+  if (((uintptr_t)p.dq | (uintptr_t)p.dk | (uintptr_t)p.dv) & 7) return VIL_E_ALIGN;
+  p.delta = ws + off[0];
+  float* tabws = ws + off[1];
+  c.tabws = tabws;
+  bc.hist_parts = ws + off[2];
+  bc.glo_parts = ws + off[3];
+  bc.do_hist = (p.dtable != nullptr) || (p.dg2l != nullptr);
+  const VilWork w(d);
+  const int64_t rows = (int64_t)p.B * p.H * p.g.nx * p.g.ny;
+  int e;
+#define BWD_SWITCH(...)                          \
+  switch (d->M) {                                \
+    case 16: { constexpr int MD_ = 1; __VA_ARGS__; } break; \
+    case 32: { constexpr int MD_ = 2; __VA_ARGS__; } break; \
+    case 48: { constexpr int MD_ = 3; __VA_ARGS__; } break; \
+    case 64: { constexpr int MD_ = 4; __VA_ARGS__; } break; \
+    default: return VIL_E_HEAD_DIM;              \
+  }
+  vil_prof_begin(VIL_K_TABLE, s, 0, 0);
+  k_mfma_table<<<dim3((4 * c.copysize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
+  vil_prof_end(s);
+  if ((e = (int)hipGetLastError())) return e;
+  vil_prof_begin(VIL_K_DELTA, s, w.delta_bytes(), 0);
+  BWD_SWITCH((k_mfma_delta<MD_><<<dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s>>>(p)));
+  vil_prof_end(s);
+  if ((e = (int)hipGetLastError())) return e;
+  if (p.dg2l) {
+    e = (int)hipMemsetAsync(p.dg2l, 0, sizeof(float) * p.H * p.G, s);
+    if (e) return e;
+  }
+  {
+    const size_t lds = dq_lds(c, bc);
+    vil_prof_begin(VIL_K_MFMA_DQ, s, w.dq_bytes(), w.dq_flops());
+    BWD_SWITCH({
+      if (lds > 64 * 1024) {
+        hipError_t he = hipFuncSetAttribute((const void*)k_mfma_bwd_dq<MD_>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (he != hipSuccess) return (int)he;
+      }
+      k_mfma_bwd_dq<MD_><<<dim3((unsigned)bc.dq_nwg), dim3(256), lds, s>>>(p, c, bc);
+    });
+    vil_prof_end(s);
+    if ((e = (int)hipGetLastError())) return e;
+  }
+  {
+    const size_t lds = kv_lds(c, bc);
+    const unsigned grid = (unsigned)(p.B * p.H * bc.kv_wg_per_bh);
+    vil_prof_begin(VIL_K_MFMA_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
+    BWD_SWITCH({
+      if (lds > 64 * 1024) {
+        hipError_t he = hipFuncSetAttribute((const void*)k_mfma_bwd_dkdv<MD_>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (he != hipSuccess) return (int)he;
+      }
+      k_mfma_bwd_dkdv<MD_><<<dim3(grid), dim3(256), lds, s>>>(p, c, bc);
+    });
+    vil_prof_end(s);
+    if ((e = (int)hipGetLastError())) return e;
+  }
+  if (p.G > 0) {
+    vil_prof_begin(VIL_K_REDUCE_GLO, s, 0, 0);
+    k_mfma_reduce_glo<<<dim3((unsigned)((p.B * p.H * p.G * p.M + 255) / 256)), dim3(256), 0, s>>>(p, bc);
+    vil_prof_end(s);
+    if ((e = (int)hipGetLastError())) return e;
+  }
+  if (bc.do_hist) {
+    vil_prof_begin(VIL_K_REDUCE_BIAS, s, 0, 0);
+    k_mfma_reduce_hist<<<dim3((unsigned)((c.copysize + 63) / 64), p.H), dim3(256), 0, s>>>(p, c, bc);
+    vil_prof_end(s);
+  }
+  return (int)hipGetLastError();
+}
