@@ -43,8 +43,10 @@ __global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out) {
   const float inv = 1.0f / p.scale;
   float v = 0.f;
   if (e < tbl * c.P) {
-    const int row = e / c.P, col = e % c.P;
-    if (col < tbl) {
+    // columns are stored with a left pad of VIL_CPAD floats: the dK/dV pass gathers 4-float runs
+    // that may start up to 3 entries left of a row's first real column (dummy key y >= W)
+    const int row = e / c.P, col = e % c.P - VIL_CPAD;
+    if (col >= 0 && col < tbl) {
       if (p.has_bias) v = p.table[(int64_t)(row * tbl + col) * p.H + h] * inv;
       const int dx = row - (2 * W - 1), dy = col - (2 * W - 1);
       if (p.g.exact == 1 && (dx > W || dx < -W || dy > W || dy < -W)) v = VIL_MASK_VAL;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
   float* tab = (float*)smem;
   {
     const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * 4 * c.copysize);
-    for (int i = tid; i < c.copysize; i += 256) ((f32x4*)tab)[i] = src[i];
+    for (int i = tid; i < c.copysize; i += blockDim.x) ((f32x4*)tab)[i] = src[i];
   }
   __syncthreads();
 
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)(lj == 0 ? 1.0f : 0.0f);
 
   for (int gi = 0; gi < c.gpw; ++gi) {
-    const int unit = (wgi * c.gpw + gi) * 4 + wave;
+    const int unit = (wgi * c.gpw + gi) * c.wpw + wave;
     if (unit >= c.units_bh) break;
     const int wp = unit % c.NWP, ch = unit / c.NWP;
     const int cn = ch % g.my, cm = ch / g.my;
@@ -330,7 +332,7 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   c.NWP = (W * c.HQ + 15) / 16;
   // row pitch: >= (4W-1)+3 so that a 4-float run never reaches the next row, and == 8 mod 32 so
   // that the 16 query columns of a wave spread over distinct 16-byte LDS slots
-  int P = 4 * W + 2;
+  int P = 4 * W + 2 + 2 * VIL_CPAD;
   while ((P & 31) != 8) ++P;
   c.P = P;
   const int aqmax = (W - 1) * P + 4 * (c.HQ - 1);
@@ -339,24 +341,26 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   c.glo0 = c.guard0 + c.gsz;
   c.copysize = ((c.glo0 + d->G * c.gsz + 4 + 3) / 4) * 4;
   c.cstride_b = (c.copysize - 1) * 4;
-  c.aconst = (2 * W - 1) * (P + 1);
+  c.aconst = (2 * W - 1) * (P + 1) + VIL_CPAD;
   c.magicW = (unsigned)(0x100000000ull / (unsigned)W) + 1;
   c.magicW2 = (unsigned)(0x100000000ull / (unsigned)(W * W)) + 1;
   c.NS = d->G + g.nact * g.W2;
   c.NSP = (c.NS + 31) & ~31;
   c.units_bh = g.mx * g.my * c.NWP;
-  const int groups = (c.units_bh + 3) / 4;
+  c.wave_lds = ((c.NSP * 8 + 32 * d->M * 2 + 15) / 16) * 16;
+  c.wpw = 4;
+  while (c.wpw > 1 && (size_t)c.copysize * 20 + (size_t)c.wpw * c.wave_lds > 160 * 1024) c.wpw >>= 1;
+  const int groups = (c.units_bh + c.wpw - 1) / c.wpw;
   int gpw = (int)(((int64_t)d->B * d->H * groups) / 2048);
   if (gpw < 1) gpw = 1;
   if (gpw > groups) gpw = groups;
   c.gpw = gpw;
   c.wg_per_bh = (groups + gpw - 1) / gpw;
-  c.wave_lds = ((c.NSP * 8 + 32 * d->M * 2 + 15) / 16) * 16;
   c.no_tr = d->reserved & 1;
   return true;
 }
 
-static size_t mfma_lds_bytes(const MfmaCfg& c) { return (size_t)c.copysize * 16 + 4 * (size_t)c.wave_lds; }
+static size_t mfma_lds_bytes(const MfmaCfg& c) { return (size_t)c.copysize * 16 + (size_t)c.wpw * c.wave_lds; }
 
 int vil_mfma_bwd_supported(const VilAttnDesc* d);
 size_t vil_mfma_bwd_workspace(const VilAttnDesc* d);
@@ -403,7 +407,7 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
       if (he != hipSuccess) return (int)he;                                                          \
     }                                                                                                \
-    k_mfma_fwd<MD_><<<dim3(grid), dim3(256), lds, s>>>(p, c);                                        \
+    k_mfma_fwd<MD_><<<dim3(grid), dim3(64 * c.wpw), lds, s>>>(p, c);                                        \
   }
   switch (d->M) {
     case 16: LAUNCH_FWD(1); break;

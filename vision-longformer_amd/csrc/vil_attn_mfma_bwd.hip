@@ -26,7 +26,7 @@ struct BwdCfg {
   int nch;            // query/key chunks per (image, head) = mx*my
   int nsplit;         // global-key owner units per (image, head)
   int units_kv_bh;    // nch*NWP + (G ? nsplit : 0)
-  int kv_wg_per_bh, kv_gpw;
+  int kv_wg_per_bh, kv_gpw, kv_wpw;
   int nqs;            // streamed query slots per owner unit (padded to 32)
   int kv_wave_lds, dq_wave_lds;
   int do_hist;
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
   float* hist = tab + 4 * c.copysize;
   {
     const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * 4 * c.copysize);
-    for (int i = tid; i < c.copysize; i += 256) ((f32x4*)tab)[i] = src[i];
-    for (int i = tid; i < c.copysize; i += 256) hist[i] = 0.f;
+    for (int i = tid; i < c.copysize; i += blockDim.x) ((f32x4*)tab)[i] = src[i];
+    for (int i = tid; i < c.copysize; i += blockDim.x) hist[i] = 0.f;
   }
   __syncthreads();
 
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
   const int W = g.W, W2 = g.W2;
 
   for (int gi = 0; gi < c.gpw; ++gi) {
-    const int unit = (wgi * c.gpw + gi) * 4 + wave;
+    const int unit = (wgi * c.gpw + gi) * c.wpw + wave;
     if (unit < c.units_bh) {
       const int wp = unit % c.NWP, ch = unit / c.NWP;
       const int cn = ch % g.my, cm = ch / g.my;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
   if (bc.do_hist) {
     __syncthreads();
     float* out = bc.hist_parts + (int64_t)logical * c.copysize;
-    for (int i = tid; i < c.copysize; i += 256) out[i] = hist[i];
+    for (int i = tid; i < c.copysize; i += blockDim.x) out[i] = hist[i];
   }
 }
 
@@ -287,8 +287,8 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
     s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     const int tbl = p.g.tbl;
     if (bin < tbl * c.P) {
-      const int row = bin / c.P, col = bin % c.P;
-      if (col < tbl && p.dtable) p.dtable[(int64_t)(row * tbl + col) * p.H + h] = s;
+      const int row = bin / c.P, col = bin % c.P - VIL_CPAD;
+      if (col >= 0 && col < tbl && p.dtable) p.dtable[(int64_t)(row * tbl + col) * p.H + h] = s;
     } else if (bin >= c.glo0 && p.dg2l) {
       const int gg = (bin - c.glo0) / c.gsz;
       if (gg < p.G) atomicAdd(&p.dg2l[h * p.G + gg], s);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
   float* tab = (float*)smem;
   {
     const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * 4 * c.copysize);
-    for (int i = tid; i < c.copysize; i += 256) ((f32x4*)tab)[i] = src[i];
+    for (int i = tid; i < c.copysize; i += blockDim.x) ((f32x4*)tab)[i] = src[i];
   }
   __syncthreads();
 
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
   const int nown = bc.nch * c.NWP;
 
   for (int gi = 0; gi < bc.kv_gpw; ++gi) {
-    const int unit = (wgi * bc.kv_gpw + gi) * 4 + wave;
+    const int unit = (wgi * bc.kv_gpw + gi) * bc.kv_wpw + wave;
     if (unit >= bc.units_kv_bh) break;
     const bool glo = unit >= nown;                 // global-key owner unit
     const int split = unit - nown;
@@ -605,20 +605,22 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   bc.nch = g.mx * g.my;
   bc.nsplit = d->G > 0 ? (bc.nch + 8) / 9 : 0;
   bc.units_kv_bh = bc.nch * c.NWP + bc.nsplit;
-  const int groups = (bc.units_kv_bh + 3) / 4;
+  bc.nqs = (9 * g.W2 + 31) & ~31;
+  bc.kv_wave_lds = ((bc.nqs * 16 + 2 * 32 * d->M * 2 + 15) / 16) * 16;
+  bc.kv_wpw = 4;
+  while (bc.kv_wpw > 1 && (size_t)c.copysize * 16 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
+  const int groups = (bc.units_kv_bh + bc.kv_wpw - 1) / bc.kv_wpw;
   int gpw = (int)(((int64_t)d->B * d->H * groups) / 2048);
   if (gpw < 1) gpw = 1;
   if (gpw > groups) gpw = groups;
   bc.kv_gpw = gpw;
   bc.kv_wg_per_bh = (groups + gpw - 1) / gpw;
-  bc.nqs = (9 * g.W2 + 31) & ~31;
-  bc.kv_wave_lds = ((bc.nqs * 16 + 2 * 32 * d->M * 2 + 15) / 16) * 16;
   bc.dq_wave_lds = ((c.NSP * 8 + 32 * d->M * 2 + 15) / 16) * 16;
   bc.dq_nwg = d->B * d->H * c.wg_per_bh;
 }
 
-static size_t dq_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.copysize * 20 + 4 * (size_t)bc.dq_wave_lds; }
-static size_t kv_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.copysize * 16 + 4 * (size_t)bc.kv_wave_lds; }
+static size_t dq_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.copysize * 20 + (size_t)c.wpw * bc.dq_wave_lds; }
+static size_t kv_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.copysize * 16 + (size_t)bc.kv_wpw * bc.kv_wave_lds; }
 
 int vil_mfma_bwd_supported(const VilAttnDesc* d) {
   if ((d->do_st | d->do_sb | d->do_sh) & 7) return VIL_E_ALIGN;
@@ -692,7 +694,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (he != hipSuccess) return (int)he;
       }
-      k_mfma_bwd_dq<MD_><<<dim3((unsigned)bc.dq_nwg), dim3(256), lds, s>>>(p, c, bc);
+      k_mfma_bwd_dq<MD_><<<dim3((unsigned)bc.dq_nwg), dim3(64 * c.wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
@@ -707,7 +709,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (he != hipSuccess) return (int)he;
       }
-      k_mfma_bwd_dkdv<MD_><<<dim3(grid), dim3(256), lds, s>>>(p, c, bc);
+      k_mfma_bwd_dkdv<MD_><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;

@@ -11,6 +11,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+#define VIL_CPAD 3   // left pad (floats) of every bias-table row in LDS
 #define VIL_MASK_VAL (-1.0e30f)
 #define VIL_M_INIT (-1.0e20f)
 #define LOG2E 1.4426950408889634f
@@ -22,7 +23,7 @@ struct MfmaCfg {
   int guard0;        // start (floats) of the all-masked region
   int glo0;          // start of the per-global-token constant regions
   int gsz;           // size of one such region (Aq range + 4)
-  int aconst;        // (2W-1)*(P+1)
+  int aconst;        // (2W-1)*(P+1) + VIL_CPAD
   unsigned magicW, magicW2;
   int HQ;            // query quads per chunk row = ceil(W/4)
   int NWP;           // waves per chunk = ceil(W*HQ/16)
@@ -30,6 +31,7 @@ struct MfmaCfg {
   int NSP;           // padded to a multiple of 32
   int units_bh;      // mx*my*NWP
   int wg_per_bh, gpw;
+  int wpw;           // waves per workgroup (4, or fewer when the per-wave LDS is large)
   int wave_lds;      // bytes of private LDS per wave
   int no_tr;         // debug: read V^T with scalar LDS loads instead of ds_read_b64_tr_b16
   const float* tabws;  // (H, 4*copysize) prepared bias tables
