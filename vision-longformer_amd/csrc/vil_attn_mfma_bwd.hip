@@ -33,6 +33,8 @@ struct BwdCfg {
   float* hist_parts;  // (dq workgroups, copysize)
   float* glo_parts;   // (B*H, nsplit, G, 2, M)
   int dq_nwg;
+  int hist_nmax;      // upper bound of contributions one histogram bin can receive in one workgroup
+  unsigned* norm2;    // [2]: max ||dO_q||^2, max ||v_k||^2 as float bits (written by k_mfma_delta)
 };
 
 // ===================================================================== dQ pass
@@ -55,13 +57,28 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
   const int b = bh / p.H, h = bh % p.H;
 
   float* tab = (float*)smem;
-  float* hist = tab + 4 * c.copysize;
+  int* hist = (int*)(tab + 4 * c.copysize);
   {
     const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * 4 * c.copysize);
     for (int i = tid; i < c.copysize; i += blockDim.x) ((f32x4*)tab)[i] = src[i];
-    for (int i = tid; i < c.copysize; i += blockDim.x) hist[i] = 0.f;
+    for (int i = tid; i < c.copysize; i += blockDim.x) hist[i] = 0;
   }
   __syncthreads();
+  // Fixed-point scale of the bias-gradient histogram.  ds_add_f32 runs ~40x slower than
+  // ds_add_u32 on gfx950 (measured: 193 vs 5-8 CU-cycles per wave instruction), so dS is
+  // accumulated as int32 in units of 2^-lfx.  |dS| <= 2 max|dO.v| <= 2 |dO|_max |v|_max
+  // (Cauchy-Schwarz), a bin gets <= hist_nmax contributions per workgroup, hence 2^lfx =
+  // 2^30 / (hist_nmax * 2 * bound) can never overflow.  The power-of-two scale is folded into
+  // lse (free) and taken out again in the dQ epilogue and the histogram reduce.
+  int lfx = 0;
+  if (bc.do_hist) {
+    const float bound = 2.0f * __builtin_sqrtf(__uint_as_float(bc.norm2[0]) * __uint_as_float(bc.norm2[1]));
+    if (bound > 0.f && bound < 1e30f) {
+      lfx = 29 - (int)ceilf(__log2f(bound * (float)bc.hist_nmax));
+      lfx = max(-60, min(60, lfx));
+    }
+  }
+  const float unscale = p.scale * __builtin_amdgcn_exp2f((float)-lfx);
 
   char* wbase = smem + (size_t)c.copysize * 20 + (size_t)wave * bc.dq_wave_lds;
   int* s_koff = (int*)wbase;
@@ -115,7 +132,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
         qreal[qt] = qx < W && qy < W && qr < g.nx && qc < g.ny;
         qtok[qt] = qreal[qt] ? qr * g.ny + qc : own_tok - p.G;
         // a non-existent query slot gets lse = +big: its probabilities (hence dS) are exactly 0
-        lse2[qt] = qreal[qt] ? p.lse[(int64_t)bh * Nloc + qtok[qt]] * LOG2E : LSE_PAD;
+        lse2[qt] = qreal[qt] ? p.lse[(int64_t)bh * Nloc + qtok[qt]] * LOG2E - (float)lfx : LSE_PAD;
         dlt[qt] = qreal[qt] ? p.delta[(int64_t)bh * Nloc + qtok[qt]] : 0.f;
       }
       bf16x8 qf[MK][4], dof[MK][4];
@@ -219,7 +236,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
               const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], c1, -lse2[qt]));
               const float ds = pr * (dp[r] - dlt[qt]);
               dsb[qt][hf * 4 + r] = (__bf16)ds;
-              if (bc.do_hist) atomicAdd((float*)((char*)hist + i0[r]) + qt, ds);
+              if (bc.do_hist) atomicAdd((int*)((char*)hist + i0[r]) + qt, __float2int_rn(ds));
             }
           }
         }
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
           for (int dt = 0; dt < MD; ++dt) {
             bf16x4 w;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w[r] = (__bf16)(dq[dt][qt][r] * p.scale);
+            for (int r = 0; r < 4; ++r) w[r] = (__bf16)(dq[dt][qt][r] * unscale);
             *(bf16x4*)(dqb + (int64_t)qtok[qt] * p.dq_st + dt * 16 + lg * 4) = w;
           }
         }
@@ -261,30 +278,34 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
   }
   if (bc.do_hist) {
     __syncthreads();
-    float* out = bc.hist_parts + (int64_t)logical * c.copysize;
+    int* out = (int*)bc.hist_parts + (int64_t)logical * c.copysize;
     for (int i = tid; i < c.copysize; i += blockDim.x) out[i] = hist[i];
+    if (logical == 0 && tid == 0) ((int*)bc.norm2)[2] = lfx;      // the reduce needs the scale
   }
 }
 
 // d(table)[idx*H+h] and d(g2l)[h*G+g] from the per-workgroup histograms.
 // grid (ceil(copysize/64), H), block 256 = 64 bins x 4 partial groups.
 __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
-  __shared__ float red[4][64];
+  __shared__ long long red[4][64];
   const int h = blockIdx.y;
   const int bin = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-  float s = 0.f;
+  long long si = 0;
   if (bin < c.copysize) {
     // workgroups of head h: logical = (b*H + h)*wg_per_bh + w
     const int per = c.wg_per_bh;
+    const int* parts = (const int*)bc.hist_parts;
     for (int i = grp; i < p.B * per; i += 4) {
       const int b = i / per, w = i % per;
-      s += bc.hist_parts[((int64_t)(b * p.H + h) * per + w) * c.copysize + bin];
+      si += parts[((int64_t)(b * p.H + h) * per + w) * c.copysize + bin];
     }
   }
-  red[grp][threadIdx.x & 63] = s;
+  red[grp][threadIdx.x & 63] = si;
   __syncthreads();
   if (grp == 0 && bin < c.copysize) {
-    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    si = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    const int lfx = ((const int*)bc.norm2)[2];
+    const float s = (float)((double)si * exp2((double)-lfx));
     const int tbl = p.g.tbl;
     if (bin < tbl * c.P) {
       const int row = bin / c.P, col = bin % c.P - VIL_CPAD;
@@ -579,23 +600,50 @@ __global__ void k_mfma_reduce_glo(VilParams p, BwdCfg bc) {
 }
 
 // rowsum(dO * O): one thread per (image, head, token)
+// also: max_q |dO_q|^2 and max_k |v_k|^2 (float bits, atomicMax) for the histogram's fixed-point scale
 template <int MD>
-__global__ void k_mfma_delta(VilParams p) {
+__global__ void k_mfma_delta(VilParams p, unsigned* norm2) {
   constexpr int M = 16 * MD;
   const int Nloc = p.g.nx * p.g.ny;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)p.B * p.H * Nloc) return;
-  const int tok = i % Nloc; const int bh = i / Nloc; const int b = bh / p.H, h = bh % p.H;
-  const __bf16* op = (const __bf16*)p.out + b * p.o_sb + (int64_t)tok * p.o_st + h * p.o_sh;
-  const __bf16* dp = (const __bf16*)p.dout + b * p.do_sb + (int64_t)tok * p.do_st + h * p.do_sh;
-  float s = 0.f;
+  float n_do = 0.f, n_v = 0.f;
+  if (i < (int64_t)p.B * p.H * Nloc) {
+    const int tok = i % Nloc; const int bh = i / Nloc; const int b = bh / p.H, h = bh % p.H;
+    const __bf16* op = (const __bf16*)p.out + b * p.o_sb + (int64_t)tok * p.o_st + h * p.o_sh;
+    const __bf16* dp = (const __bf16*)p.dout + b * p.do_sb + (int64_t)tok * p.do_st + h * p.do_sh;
+    const __bf16* vp = (const __bf16*)p.v + b * p.v_sb + (int64_t)(p.G + tok) * p.v_st + h * p.v_sh;
+    float s = 0.f;
 #pragma unroll
-  for (int d0 = 0; d0 < M; d0 += 8) {
-    const bf16x8 a = *(const bf16x8*)(op + d0), c = *(const bf16x8*)(dp + d0);
+    for (int d0 = 0; d0 < M; d0 += 8) {
+      const bf16x8 a = *(const bf16x8*)(op + d0), c = *(const bf16x8*)(dp + d0), v = *(const bf16x8*)(vp + d0);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s = __builtin_fmaf((float)a[e], (float)c[e], s);
+      for (int e = 0; e < 8; ++e) {
+        s = __builtin_fmaf((float)a[e], (float)c[e], s);
+        n_do = __builtin_fmaf((float)c[e], (float)c[e], n_do);
+        n_v = __builtin_fmaf((float)v[e], (float)v[e], n_v);
+      }
+    }
+    p.delta[i] = s;
+    if (tok < p.G) {        // the G global rows of v
+      const __bf16* vg = (const __bf16*)p.v + b * p.v_sb + (int64_t)tok * p.v_st + h * p.v_sh;
+      float t = 0.f;
+      for (int d = 0; d < M; ++d) t = __builtin_fmaf((float)vg[d], (float)vg[d], t);
+      n_v = fmaxf(n_v, t);
+    }
   }
-  p.delta[i] = s;
+  if (norm2) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      n_do = fmaxf(n_do, __shfl_xor(n_do, o, 64));
+      n_v = fmaxf(n_v, __shfl_xor(n_v, o, 64));
+    }
+    // one atomic per wave at most, and only when it would raise the current maximum
+    if ((threadIdx.x & 63) == 0) {
+      const unsigned a = __float_as_uint(n_do), b2 = __float_as_uint(n_v);
+      if (a > __hip_atomic_load(&norm2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&norm2[0], a);
+      if (b2 > __hip_atomic_load(&norm2[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&norm2[1], b2);
+    }
+  }
 }
 
 // ===================================================================== host side
@@ -635,7 +683,7 @@ int vil_mfma_bwd_supported(const VilAttnDesc* d) {
 static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& bc, size_t off[5]) {
   const size_t rows = (size_t)d->B * d->H * d->nx * d->ny;
   off[0] = 0;
-  off[1] = (rows + 3) & ~(size_t)3;
+  off[1] = ((rows + 3) & ~(size_t)3) + 4;      // + 4 words: norm maxima and the histogram scale
   off[2] = off[1] + (size_t)d->H * 4 * c.copysize;
   off[3] = off[2] + (size_t)bc.dq_nwg * c.copysize;
   off[4] = off[3] + (size_t)d->B * d->H * bc.nsplit * d->G * 2 * d->M;
@@ -662,6 +710,8 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   bc.hist_parts = ws + off[2];
   bc.glo_parts = ws + off[3];
   bc.do_hist = (p.dtable != nullptr) || (p.dg2l != nullptr);
+  bc.norm2 = (unsigned*)(ws + off[1] - 4);
+  bc.hist_nmax = p.g.W2 * c.gpw * c.wpw;
   const VilWork w(d);
   const int64_t rows = (int64_t)p.B * p.H * p.g.nx * p.g.ny;
   int e;
@@ -677,8 +727,11 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   k_mfma_table<<<dim3((4 * c.copysize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
+  e = (int)hipMemsetAsync(bc.norm2, 0, 16, s);
+  if (e) return e;
   vil_prof_begin(VIL_K_DELTA, s, w.delta_bytes(), 0);
-  BWD_SWITCH((k_mfma_delta<MD_><<<dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s>>>(p)));
+  BWD_SWITCH((k_mfma_delta<MD_><<<dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s>>>(
+      p, bc.do_hist ? bc.norm2 : nullptr)));
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
   if (p.dg2l) {
