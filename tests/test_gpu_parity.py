@@ -166,14 +166,6 @@ def test_mfma_bf16_vs_oracle(c, dev):
     compare("mfma/bf16 " + _cid(c), got, ref, BF16_TOL)
 
 
-@pytest.mark.parametrize("c", [MFMA_CASES[0], MFMA_CASES[10], MFMA_CASES[11]], ids=_cid)
-def test_mfma_tr_read_equals_scalar_lds_read(c, dev):
-    inp = make_inputs(c, torch.bfloat16)
-    a = run_hip(c, *inp, torch.bfloat16, "auto", dev, debug=0)
-    b = run_hip(c, *inp, torch.bfloat16, "auto", dev, debug=1)
-    assert torch.equal(a["out"], b["out"])
-
-
 def test_mfma_forced_rescale_branch(dev):
     """The deferred-max rescale is rare on random data: force it with a spiked key
     (cdna guide 5.4 rule 26) late in the key order and check against the oracle."""

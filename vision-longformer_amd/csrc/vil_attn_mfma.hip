@@ -10,11 +10,11 @@
 //
 //   S^T tile (16 keys x 16 queries)  = mfma_16x16x32_bf16(A = K rows, B = Q rows, C = bias)
 //        K and Q fragments are loaded straight from HBM/L2 (8 contiguous head
-//        dims per lane = the natural row layout, 16-byte loads); the bias (and
+//        dims per lane = the natural row layout, 16-byte buffer loads); the bias (and
 //        the -inf of masked / out-of-image keys, and the exact-window mask) enters
 //        as the accumulator's initial value, gathered from an LDS copy of this
-//        head's bias table: one ds_read_b128 returns the bias of one key for the
-//        lane's four y-consecutive queries, so bias + mask cost 3 VALU per 4 scores.
+//        head's bias table straight into the accumulator registers: one v_sub per
+//        key, the lane's four y-consecutive queries are immediate offsets.
 //   softmax: a lane holds 8 keys x 1 query per step; the row maximum is
 //        deferred (only when a score exceeds the running maximum by > 8 nats
 //        does the wave re-synchronise maxima across its four lane groups and
@@ -29,22 +29,14 @@
 #include "vil_mfma_common.h"
 
 // ------------------------------------------------------------------ table prologue
-// Logical table of one head, stored 4 times, copy c shifted by c floats so that any
-// 4-float run starts 16-byte aligned in copy (start & 3):
-//   [ (4W-1) rows x P : bias/scale (exact==1: -inf outside the (2W+1)^2 window) |
-//     gsz x -inf (masked / padded key slots) | G x gsz x g2l[h][g]/scale ]
 __global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out) {
   const int h = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 4 * c.copysize) return;
-  const int cp = i / c.copysize, pos = i % c.copysize;
-  const int e = pos + cp;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= c.tabsize) return;
   const int tbl = p.g.tbl, W = p.g.W;
   const float inv = 1.0f / p.scale;
   float v = 0.f;
   if (e < tbl * c.P) {
-    // columns are stored with a left pad of VIL_CPAD floats: the dK/dV pass gathers 4-float runs
-    // that may start up to 3 entries left of a row's first real column (dummy key y >= W)
     const int row = e / c.P, col = e % c.P - VIL_CPAD;
     if (col >= 0 && col < tbl) {
       if (p.has_bias) v = p.table[(int64_t)(row * tbl + col) * p.H + h] * inv;
@@ -57,7 +49,7 @@ __global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out) {
     const int g = (e - c.glo0) / c.gsz;
     if (g < p.G && p.has_g2l) v = p.g2l[h * p.G + g] * inv;
   }
-  out[(int64_t)h * 4 * c.copysize + i] = v;
+  out[(int64_t)h * c.tabsize + e] = v;
 }
 
 // ------------------------------------------------------------------ forward
@@ -73,68 +65,61 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, lg = lane >> 4;
 
-  // XCD-aware bijective remap: consecutive logical workgroups (same image/head,
-  // neighbouring chunks -> shared K/V) land on the same XCD's L2
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = logical / c.wg_per_bh, wgi = logical % c.wg_per_bh;
   const int b = bh / p.H, h = bh % p.H;
 
   float* tab = (float*)smem;
   {
-    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * 4 * c.copysize);
-    for (int i = tid; i < c.copysize; i += blockDim.x) ((f32x4*)tab)[i] = src[i];
+    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
+    for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
   }
   __syncthreads();
 
-  char* wbase = smem + (size_t)c.copysize * 16 + (size_t)wave * c.wave_lds;
-  int* s_koff = (int*)wbase;                       // [NSP] token offset (elements) of each key slot
+  char* wbase = smem + (size_t)c.tabsize * 4 + (size_t)wave * c.wave_lds;
+  int* s_koff = (int*)wbase;                       // [NSP] byte offset of each key slot's K/V row
   int* s_akey = s_koff + c.NSP;                    // [NSP] bias-table address term (bytes)
-  __bf16* s_v = (__bf16*)(s_akey + c.NSP);         // [32][M] V tile of the current step
+  char* s_v = (char*)(s_akey + c.NSP);             // [32][M] bf16 V tile of the current step
 
+  const __amdgpu_buffer_rsrc_t krs = make_rsrc((const __bf16*)p.k + b * p.k_sb + h * p.k_sh);
+  const __amdgpu_buffer_rsrc_t vrs = make_rsrc((const __bf16*)p.v + b * p.v_sb + h * p.v_sh);
   const __bf16* qb = (const __bf16*)p.q + b * p.q_sb + h * p.q_sh;
-  const __bf16* kb = (const __bf16*)p.k + b * p.k_sb + h * p.k_sh;
-  const __bf16* vb = (const __bf16*)p.v + b * p.v_sb + h * p.v_sh;
   __bf16* ob = (__bf16*)p.o + b * p.o_sb + h * p.o_sh;
   const int Nloc = g.nx * g.ny;
+  const int kstride_b = (int)p.k_st * 2;
   const float c1 = p.scale * LOG2E;               // scores are kept unscaled: s*c1 is log2-domain
   const float thr = 8.0f / p.scale;               // deferred-max threshold (8 nats)
-  const int W = g.W, W2 = g.W2;
+  const int W = g.W;
 
   // constant A operand whose row 0 is all ones: D[0][j] = sum_k P^T[k][j]
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)(lj == 0 ? 1.0f : 0.0f);
 
+  // lane-constant pieces of the V staging / tr-read addresses
+  int vst_off[MD], vld_off[MD], vtr_off[2][MD];
+#pragma unroll
+  for (int it = 0; it < MD; ++it) {
+    const int cid = it * 64 + lane;
+    const int row = cid / VCH, chn = cid % VCH;
+    vst_off[it] = row * (M * 2) + ((chn * 16) ^ (SWZ * (((row >> 2) & 1) << 5)));
+    vld_off[it] = chn * 16;
+  }
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int row = hf * 16 + lg * 4 + (lj >> 2);
+#pragma unroll
+    for (int dt = 0; dt < MD; ++dt)
+      vtr_off[hf][dt] = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
+  }
+  const int lgo = lg * 16;
+
   for (int gi = 0; gi < c.gpw; ++gi) {
     const int unit = (wgi * c.gpw + gi) * c.wpw + wave;
     if (unit >= c.units_bh) break;
     const int wp = unit % c.NWP, ch = unit / c.NWP;
     const int cn = ch % g.my, cm = ch / g.my;
-
-    // ---- key slot table (wave-private LDS)
-    const int own_tok = p.G + (cm * W) * g.ny + cn * W;     // always a real token
-    for (int s = lane; s < c.NSP; s += 64) {
-      int tok = own_tok, ak = -c.guard0;
-      if (s < p.G) {
-        tok = s; ak = -(c.glo0 + s * c.gsz);
-      } else if (s < c.NS) {
-        const unsigned sl = s - p.G;
-        const int a = fdiv(sl, c.magicW2), t = sl - a * W2;
-        const int xt = fdiv(t, c.magicW), yt = t - xt * W;
-        // neighbour offset of active slot a, without a divergent lookup into the kernarg arrays
-        const int a3 = (a * 11) >> 5;                       // a / 3 for a in [0, 9)
-        const int dr = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : g.adr[1]);
-        const int dc = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : g.adc[1]);
-        int kr, kc;
-        if (vil_key_state(g, cm, cn, dr, dc, xt, yt, kr, kc) == VIL_KEY_REAL) {
-          tok = p.G + kr * g.ny + kc;
-          ak = (dr * W + xt) * c.P + (dc * W + yt) - c.aconst;
-        }
-      }
-      s_koff[s] = tok; s_akey[s] = ak * 4;
-    }
+    build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey);
 
     // ---- query slots of this lane: column j of q-tile qt is query (x, y = 4*hq + qt)
     const int jj = wp * 16 + lj;
@@ -147,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
       const int qy = 4 * qhq + qt;
       const int qr = cm * W + qx, qc = cn * W + qy;
       qreal[qt] = qx < W && qy < W && qr < g.nx && qc < g.ny;
-      qtok[qt] = qreal[qt] ? qr * g.ny + qc : own_tok - p.G;
+      qtok[qt] = qreal[qt] ? qr * g.ny + qc : (cm * W) * g.ny + cn * W;
     }
     bf16x8 qf[MK][4];
 #pragma unroll
@@ -168,31 +153,24 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
 #pragma unroll
       for (int dt = 0; dt < MD; ++dt) o[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     const int nsteps = c.NSP >> 5;
-    // prefetch registers for step 0
     bf16x8 kf[2][MK];
     u32x4 vr[MD];
     auto load_step = [&](int st) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const int tok = s_koff[st * 32 + hf * 16 + lj];
+        const int off = s_koff[st * 32 + hf * 16 + lj] + lgo;
 #pragma unroll
         for (int ks = 0; ks < MK; ++ks) {
-          const int d0 = ks * 32 + lg * 8;
           bf16x8 z = {};
-          kf[hf][ks] = d0 < M ? *(const bf16x8*)(kb + (int64_t)tok * p.k_st + d0) : z;
+          kf[hf][ks] = (ks * 32 + lg * 8) < M ? buf_load8(krs, off + ks * 64) : z;
         }
       }
 #pragma unroll
       for (int it = 0; it < MD; ++it) {
-        const int cid = it * 64 + lane;
-        const int row = cid / VCH, chn = cid % VCH;
-        const int tok = s_koff[st * 32 + row];
-        vr[it] = *(const u32x4*)(vb + (int64_t)tok * p.v_st + chn * 8);
+        const int row = (it * 64 + lane) / VCH;
+        vr[it] = __builtin_amdgcn_raw_buffer_load_b128(vrs, s_koff[st * 32 + row] + vld_off[it], 0, 0);
       }
     };
     load_step(0);
@@ -205,33 +183,22 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
 #pragma unroll
         for (int ks = 0; ks < MK; ++ks) kc_[hf][ks] = kf[hf][ks];
 #pragma unroll
-      for (int it = 0; it < MD; ++it) {
-        const int cid = it * 64 + lane;
-        const int row = cid / VCH, chn = cid % VCH;
-        *(u32x4*)((char*)s_v + row * (M * 2) + ((chn * 16) ^ (SWZ * (((row >> 2) & 1) << 5)))) = vr[it];
-      }
-      int ak[2][4];
+      for (int it = 0; it < MD; ++it) *(u32x4*)(s_v + vst_off[it]) = vr[it];
+      i32x4 ak[2];
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const i32x4 a4 = *(const i32x4*)(s_akey + st * 32 + hf * 16 + lg * 4);
-        ak[hf][0] = a4[0]; ak[hf][1] = a4[1]; ak[hf][2] = a4[2]; ak[hf][3] = a4[3];
-      }
+      for (int hf = 0; hf < 2; ++hf) ak[hf] = *(const i32x4*)(s_akey + st * 32 + hf * 16 + lg * 4);
       if (st + 1 < nsteps) load_step(st + 1);
 
       // ---- S^T = K Q^T + bias   (accumulator initialised with the gathered bias)
       f32x4 sc[2][4];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        f32x4 bq[4];            // bq[r] = bias of key r for the lane's 4 q-tiles
+        const float* tb[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const unsigned i0 = (unsigned)(aq0b - ak[hf][r]);
-          const unsigned addr = i0 + ((i0 >> 2) & 3u) * (unsigned)c.cstride_b;
-          bq[r] = *(const f32x4*)((const char*)tab + addr);
-        }
+        for (int r = 0; r < 4; ++r) tb[r] = (const float*)((const char*)tab + (aq0b - ak[hf][r]));
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
-          f32x4 acc = {bq[0][qt], bq[1][qt], bq[2][qt], bq[3][qt]};
+          f32x4 acc = {tb[0][qt], tb[1][qt], tb[2][qt], tb[3][qt]};
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks)
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_[hf][ks], qf[ks][qt], acc, 0, 0, 0);
@@ -264,31 +231,17 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
       }
 
       // ---- O^T += V^T P^T ; row sums via the ones-row
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wave_lds_fence();
 #pragma unroll
       for (int dt = 0; dt < MD; ++dt) {
         bf16x8 vt;
-        if (!c.no_tr) {
 #pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            const int row = hf * 16 + lg * 4 + (lj >> 2);
-            const int off = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
-            const s16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)((char*)s_v + off));
-            const bf16x4 tb = __builtin_bit_cast(bf16x4, t4);
+        for (int hf = 0; hf < 2; ++hf) {
+          const s16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(s_v + vtr_off[hf][dt]));
+          const bf16x4 tb4 = __builtin_bit_cast(bf16x4, t4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vt[hf * 4 + e] = tb[e];
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int row = (e >> 2) * 16 + lg * 4 + (e & 3);
-            const int bcol = (dt * 16 + lj) * 2;
-            const int off = row * (M * 2) + (bcol ^ (SWZ * (((row >> 2) & 1) << 5)));
-            vt[e] = *(const __bf16*)((const char*)s_v + off);
-          }
+          for (int e = 0; e < 4; ++e) vt[hf * 4 + e] = tb4[e];
         }
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt)
@@ -297,8 +250,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt)
         lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qt], lacc[qt], 0, 0, 0);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_fence();
     }
 
     // ---- epilogue: normalise, store O (4 dims x 8 bytes per d-tile) and LSE
@@ -318,8 +270,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
           p.lse[(int64_t)bh * Nloc + qtok[qt]] = mrow[qt] * p.scale + __logf(l);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
   }
 }
 
@@ -330,17 +281,14 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   const int W = d->W;
   c.HQ = (W + 3) / 4;
   c.NWP = (W * c.HQ + 15) / 16;
-  // row pitch: >= (4W-1)+3 so that a 4-float run never reaches the next row, and == 8 mod 32 so
-  // that the 16 query columns of a wave spread over distinct 16-byte LDS slots
   int P = 4 * W + 2 + 2 * VIL_CPAD;
-  while ((P & 31) != 8) ++P;
+  while ((P & 31) != 11) ++P;
   c.P = P;
-  const int aqmax = (W - 1) * P + 4 * (c.HQ - 1);
-  c.gsz = ((aqmax + 4 + 3) / 4) * 4;
+  const int aqmax = (W - 1) * P + 4 * (c.HQ - 1) + 3;
+  c.gsz = ((aqmax + 8) / 4) * 4;
   c.guard0 = ((g.tbl * P + 3) / 4) * 4;
   c.glo0 = c.guard0 + c.gsz;
-  c.copysize = ((c.glo0 + d->G * c.gsz + 4 + 3) / 4) * 4;
-  c.cstride_b = (c.copysize - 1) * 4;
+  c.tabsize = ((c.glo0 + d->G * c.gsz + 4 + 3) / 4) * 4;
   c.aconst = (2 * W - 1) * (P + 1) + VIL_CPAD;
   c.magicW = (unsigned)(0x100000000ull / (unsigned)W) + 1;
   c.magicW2 = (unsigned)(0x100000000ull / (unsigned)(W * W)) + 1;
@@ -349,18 +297,17 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   c.units_bh = g.mx * g.my * c.NWP;
   c.wave_lds = ((c.NSP * 8 + 32 * d->M * 2 + 15) / 16) * 16;
   c.wpw = 4;
-  while (c.wpw > 1 && (size_t)c.copysize * 20 + (size_t)c.wpw * c.wave_lds > 160 * 1024) c.wpw >>= 1;
+  while (c.wpw > 1 && (size_t)c.tabsize * 8 + (size_t)c.wpw * c.wave_lds > 160 * 1024) c.wpw >>= 1;
   const int groups = (c.units_bh + c.wpw - 1) / c.wpw;
   int gpw = (int)(((int64_t)d->B * d->H * groups) / 2048);
   if (gpw < 1) gpw = 1;
   if (gpw > groups) gpw = groups;
   c.gpw = gpw;
   c.wg_per_bh = (groups + gpw - 1) / gpw;
-  c.no_tr = d->reserved & 1;
   return true;
 }
 
-static size_t mfma_lds_bytes(const MfmaCfg& c) { return (size_t)c.copysize * 16 + (size_t)c.wpw * c.wave_lds; }
+static size_t mfma_lds_bytes(const MfmaCfg& c) { return (size_t)c.tabsize * 4 + (size_t)c.wpw * c.wave_lds; }
 
 int vil_mfma_bwd_supported(const VilAttnDesc* d);
 size_t vil_mfma_bwd_workspace(const VilAttnDesc* d);
@@ -374,6 +321,10 @@ int vil_mfma_supported(const VilAttnDesc* d, int pass) {
   // 16-byte row loads: token/batch/head strides and M must keep rows 16-byte aligned
   if ((d->q_st | d->k_st | d->v_st | d->q_sb | d->k_sb | d->v_sb | d->q_sh | d->k_sh | d->v_sh) & 7) return VIL_E_ALIGN;
   if ((d->o_st | d->o_sb | d->o_sh) & 3) return VIL_E_ALIGN;
+  // K and V rows are addressed through one slot table of 32-bit byte offsets (views of one kv tensor)
+  const int64_t ntok = (int64_t)d->G + (int64_t)d->nx * d->ny;
+  if (d->k_st != d->v_st || d->k_st >= (1 << 22) || ntok >= (1 << 23) || d->k_st * 2 * ntok >= (1ll << 31))
+    return VIL_E_BACKEND;
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   if (mfma_lds_bytes(c) > 160 * 1024) return VIL_E_BACKEND;
   return pass == 0 ? VIL_OK : vil_mfma_bwd_supported(d);
@@ -382,7 +333,7 @@ int vil_mfma_supported(const VilAttnDesc* d, int pass) {
 size_t vil_mfma_workspace(const VilAttnDesc* d, int pass) {
   if (pass != 0) return vil_mfma_bwd_workspace(d);
   MfmaCfg c; vil_mfma_make_cfg(d, c);
-  return (size_t)d->H * 4 * c.copysize * sizeof(float);
+  return (size_t)d->H * c.tabsize * sizeof(float);
 }
 
 int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
@@ -393,7 +344,7 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   if ((uintptr_t)p.o & 7) return VIL_E_ALIGN;
   const VilWork w(d);
   vil_prof_begin(VIL_K_TABLE, s, 0, 0);
-  k_mfma_table<<<dim3((4 * c.copysize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
+  k_mfma_table<<<dim3((c.tabsize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
   vil_prof_end(s);
   int e = (int)hipGetLastError();
   if (e) return e;
@@ -407,7 +358,7 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
       if (he != hipSuccess) return (int)he;                                                          \
     }                                                                                                \
-    k_mfma_fwd<MD_><<<dim3(grid), dim3(64 * c.wpw), lds, s>>>(p, c);                                        \
+    k_mfma_fwd<MD_><<<dim3(grid), dim3(64 * c.wpw), lds, s>>>(p, c);                                 \
   }
   switch (d->M) {
     case 16: LAUNCH_FWD(1); break;

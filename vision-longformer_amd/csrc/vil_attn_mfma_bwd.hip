@@ -30,7 +30,7 @@ struct BwdCfg {
   int nqs;            // streamed query slots per owner unit (padded to 32)
   int kv_wave_lds, dq_wave_lds;
   int do_hist;
-  float* hist_parts;  // (dq workgroups, copysize)
+  float* hist_parts;  // (dq workgroups, tabsize) int32
   float* glo_parts;   // (B*H, nsplit, G, 2, M)
   int dq_nwg;
   int hist_nmax;      // upper bound of contributions one histogram bin can receive in one workgroup
@@ -50,18 +50,16 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, lg = lane >> 4;
 
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = logical / c.wg_per_bh, wgi = logical % c.wg_per_bh;
   const int b = bh / p.H, h = bh % p.H;
 
   float* tab = (float*)smem;
-  int* hist = (int*)(tab + 4 * c.copysize);
+  int* hist = (int*)(tab + c.tabsize);
   {
-    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * 4 * c.copysize);
-    for (int i = tid; i < c.copysize; i += blockDim.x) ((f32x4*)tab)[i] = src[i];
-    for (int i = tid; i < c.copysize; i += blockDim.x) hist[i] = 0;
+    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
+    for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
+    for (int i = tid; i < c.tabsize; i += blockDim.x) hist[i] = 0;
   }
   __syncthreads();
   // Fixed-point scale of the bias-gradient histogram.  ds_add_f32 runs ~40x slower than
@@ -80,45 +78,48 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
   }
   const float unscale = p.scale * __builtin_amdgcn_exp2f((float)-lfx);
 
-  char* wbase = smem + (size_t)c.copysize * 20 + (size_t)wave * bc.dq_wave_lds;
+  char* wbase = smem + (size_t)c.tabsize * 8 + (size_t)wave * bc.dq_wave_lds;
   int* s_koff = (int*)wbase;
   int* s_akey = s_koff + c.NSP;
-  __bf16* s_k = (__bf16*)(s_akey + c.NSP);          // [32][M] K tile of the current step
+  char* s_k = (char*)(s_akey + c.NSP);              // [32][M] bf16 K tile of the current step
 
   const __bf16* qb = (const __bf16*)p.q + b * p.q_sb + h * p.q_sh;
-  const __bf16* kb = (const __bf16*)p.k + b * p.k_sb + h * p.k_sh;
-  const __bf16* vb = (const __bf16*)p.v + b * p.v_sb + h * p.v_sh;
+  const __amdgpu_buffer_rsrc_t krs = make_rsrc((const __bf16*)p.k + b * p.k_sb + h * p.k_sh);
+  const __amdgpu_buffer_rsrc_t vrs = make_rsrc((const __bf16*)p.v + b * p.v_sb + h * p.v_sh);
   const __bf16* dob = (const __bf16*)p.dout + b * p.do_sb + h * p.do_sh;
   __bf16* dqb = (__bf16*)p.dq + b * p.dq_sb + h * p.dq_sh;
   const int Nloc = g.nx * g.ny;
+  const int kstride_b = (int)p.k_st * 2;
   const float c1 = p.scale * LOG2E;
-  const int W = g.W, W2 = g.W2;
+  const int W = g.W;
+
+  int kst_off[MD], kld_off[MD], ktr_off[2][MD], krow_off[2][MK];
+#pragma unroll
+  for (int it = 0; it < MD; ++it) {
+    const int cid = it * 64 + lane;
+    const int row = cid / VCH, chn = cid % VCH;
+    kst_off[it] = row * (M * 2) + ((chn * 16) ^ (SWZ * (((row >> 2) & 1) << 5)));
+    kld_off[it] = chn * 16;
+  }
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int row = hf * 16 + lg * 4 + (lj >> 2);
+#pragma unroll
+    for (int dt = 0; dt < MD; ++dt)
+      ktr_off[hf][dt] = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
+    const int row2 = hf * 16 + lj;
+#pragma unroll
+    for (int ks = 0; ks < MK; ++ks)
+      krow_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ (SWZ * (((row2 >> 2) & 1) << 5)));
+  }
+  const int lgo = lg * 16;
 
   for (int gi = 0; gi < c.gpw; ++gi) {
     const int unit = (wgi * c.gpw + gi) * c.wpw + wave;
     if (unit < c.units_bh) {
       const int wp = unit % c.NWP, ch = unit / c.NWP;
       const int cn = ch % g.my, cm = ch / g.my;
-      const int own_tok = p.G + (cm * W) * g.ny + cn * W;
-      for (int s = lane; s < c.NSP; s += 64) {
-        int tok = own_tok, ak = -c.guard0;
-        if (s < p.G) {
-          tok = s; ak = -(c.glo0 + s * c.gsz);
-        } else if (s < c.NS) {
-          const unsigned sl = s - p.G;
-          const int a = fdiv(sl, c.magicW2), t = sl - a * W2;
-          const int xt = fdiv(t, c.magicW), yt = t - xt * W;
-          const int a3 = (a * 11) >> 5;
-          const int dr = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : g.adr[1]);
-          const int dc = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : g.adc[1]);
-          int kr, kc;
-          if (vil_key_state(g, cm, cn, dr, dc, xt, yt, kr, kc) == VIL_KEY_REAL) {
-            tok = p.G + kr * g.ny + kc;
-            ak = (dr * W + xt) * c.P + (dc * W + yt) - c.aconst;
-          }
-        }
-        s_koff[s] = tok; s_akey[s] = ak * 4;
-      }
+      build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey);
       const int jj = wp * 16 + lj;
       const int qx = jj / c.HQ, qhq = jj % c.HQ;
       const int aq0b = (min(qx, W - 1) * c.P + 4 * qhq) * 4;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
         const int qy = 4 * qhq + qt;
         const int qr = cm * W + qx, qc = cn * W + qy;
         qreal[qt] = qx < W && qy < W && qr < g.nx && qc < g.ny;
-        qtok[qt] = qreal[qt] ? qr * g.ny + qc : own_tok - p.G;
+        qtok[qt] = qreal[qt] ? qr * g.ny + qc : (cm * W) * g.ny + cn * W;
         // a non-existent query slot gets lse = +big: its probabilities (hence dS) are exactly 0
         lse2[qt] = qreal[qt] ? p.lse[(int64_t)bh * Nloc + qtok[qt]] * LOG2E - (float)lfx : LSE_PAD;
         dlt[qt] = qreal[qt] ? p.delta[(int64_t)bh * Nloc + qtok[qt]] : 0.f;
@@ -150,9 +151,6 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
       for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
         for (int dt = 0; dt < MD; ++dt) dq[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
       const int nsteps = c.NSP >> 5;
       bf16x8 vf[2][MK];
@@ -160,20 +158,17 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
       auto load_step = [&](int st) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          const int tok = s_koff[st * 32 + hf * 16 + lj];
+          const int off = s_koff[st * 32 + hf * 16 + lj] + lgo;
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) {
-            const int d0 = ks * 32 + lg * 8;
             bf16x8 z = {};
-            vf[hf][ks] = d0 < M ? *(const bf16x8*)(vb + (int64_t)tok * p.v_st + d0) : z;
+            vf[hf][ks] = (ks * 32 + lg * 8) < M ? buf_load8(vrs, off + ks * 64) : z;
           }
         }
 #pragma unroll
         for (int it = 0; it < MD; ++it) {
-          const int cid = it * 64 + lane;
-          const int row = cid / VCH, chn = cid % VCH;
-          const int tok = s_koff[st * 32 + row];
-          kr_[it] = *(const u32x4*)(kb + (int64_t)tok * p.k_st + chn * 8);
+          const int row = (it * 64 + lane) / VCH;
+          kr_[it] = __builtin_amdgcn_raw_buffer_load_b128(krs, s_koff[st * 32 + row] + kld_off[it], 0, 0);
         }
       };
       load_step(0);
@@ -185,21 +180,12 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) vc[hf][ks] = vf[hf][ks];
 #pragma unroll
-        for (int it = 0; it < MD; ++it) {
-          const int cid = it * 64 + lane;
-          const int row = cid / VCH, chn = cid % VCH;
-          *(u32x4*)((char*)s_k + row * (M * 2) + ((chn * 16) ^ (SWZ * (((row >> 2) & 1) << 5)))) = kr_[it];
-        }
-        int ak[2][4];
+        for (int it = 0; it < MD; ++it) *(u32x4*)(s_k + kst_off[it]) = kr_[it];
+        i32x4 ak[2];
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const i32x4 a4 = *(const i32x4*)(s_akey + st * 32 + hf * 16 + lg * 4);
-          ak[hf][0] = a4[0]; ak[hf][1] = a4[1]; ak[hf][2] = a4[2]; ak[hf][3] = a4[3];
-        }
+        for (int hf = 0; hf < 2; ++hf) ak[hf] = *(const i32x4*)(s_akey + st * 32 + hf * 16 + lg * 4);
         if (st + 1 < nsteps) load_step(st + 1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_lds_fence();
 
         bf16x8 dsb[4];
 #pragma unroll
@@ -208,23 +194,19 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
           bf16x8 kc_[MK];
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) {
-            const int d0 = ks * 32 + lg * 8;
-            const int row = hf * 16 + lj;
             bf16x8 z = {};
-            kc_[ks] = d0 < M ? *(const bf16x8*)((const char*)s_k + row * (M * 2) +
-                                                ((d0 * 2) ^ (SWZ * (((row >> 2) & 1) << 5)))) : z;
+            kc_[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(s_k + krow_off[hf][ks]) : z;
           }
-          unsigned i0[4];
-          f32x4 bq[4];
+          int i0[4];
+          const float* tb[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            i0[r] = (unsigned)(aq0b - ak[hf][r]);
-            const unsigned addr = i0[r] + ((i0[r] >> 2) & 3u) * (unsigned)c.cstride_b;
-            bq[r] = *(const f32x4*)((const char*)tab + addr);
+            i0[r] = aq0b - ak[hf][r];
+            tb[r] = (const float*)((const char*)tab + i0[r]);
           }
 #pragma unroll
           for (int qt = 0; qt < 4; ++qt) {
-            f32x4 acc = {bq[0][qt], bq[1][qt], bq[2][qt], bq[3][qt]};
+            f32x4 acc = {tb[0][qt], tb[1][qt], tb[2][qt], tb[3][qt]};
             f32x4 dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < MK; ++ks) {
@@ -246,10 +228,8 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
           bf16x8 kt_;
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
-            const int row = hf * 16 + lg * 4 + (lj >> 2);
-            const int off = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
             const s16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)((char*)s_k + off));
+                (s16x4 __attribute__((address_space(3)))*)(s_k + ktr_off[hf][dt]));
             const bf16x4 tb = __builtin_bit_cast(bf16x4, t4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) kt_[hf * 4 + e] = tb[e];
@@ -258,8 +238,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
           for (int qt = 0; qt < 4; ++qt)
             dq[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsb[qt], dq[dt][qt], 0, 0, 0);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_fence();
       }
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt)
@@ -278,31 +257,31 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
   }
   if (bc.do_hist) {
     __syncthreads();
-    int* out = (int*)bc.hist_parts + (int64_t)logical * c.copysize;
-    for (int i = tid; i < c.copysize; i += blockDim.x) out[i] = hist[i];
+    int* out = (int*)bc.hist_parts + (int64_t)logical * c.tabsize;
+    for (int i = tid; i < c.tabsize; i += blockDim.x) out[i] = hist[i];
     if (logical == 0 && tid == 0) ((int*)bc.norm2)[2] = lfx;      // the reduce needs the scale
   }
 }
 
 // d(table)[idx*H+h] and d(g2l)[h*G+g] from the per-workgroup histograms.
-// grid (ceil(copysize/64), H), block 256 = 64 bins x 4 partial groups.
+// grid (ceil(tabsize/64), H), block 256 = 64 bins x 4 partial groups.
 __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
   __shared__ long long red[4][64];
   const int h = blockIdx.y;
   const int bin = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
   long long si = 0;
-  if (bin < c.copysize) {
+  if (bin < c.tabsize) {
     // workgroups of head h: logical = (b*H + h)*wg_per_bh + w
     const int per = c.wg_per_bh;
     const int* parts = (const int*)bc.hist_parts;
     for (int i = grp; i < p.B * per; i += 4) {
       const int b = i / per, w = i % per;
-      si += parts[((int64_t)(b * p.H + h) * per + w) * c.copysize + bin];
+      si += parts[((int64_t)(b * p.H + h) * per + w) * c.tabsize + bin];
     }
   }
   red[grp][threadIdx.x & 63] = si;
   __syncthreads();
-  if (grp == 0 && bin < c.copysize) {
+  if (grp == 0 && bin < c.tabsize) {
     si = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     const int lfx = ((const int*)bc.norm2)[2];
     const float s = (float)((double)si * exp2((double)-lfx));
@@ -330,37 +309,58 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, lg = lane >> 4;
 
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = logical / bc.kv_wg_per_bh, wgi = logical % bc.kv_wg_per_bh;
   const int b = bh / p.H, h = bh % p.H;
 
   float* tab = (float*)smem;
   {
-    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * 4 * c.copysize);
-    for (int i = tid; i < c.copysize; i += blockDim.x) ((f32x4*)tab)[i] = src[i];
+    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
+    for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
   }
   __syncthreads();
 
-  char* wbase = smem + (size_t)c.copysize * 16 + (size_t)wave * bc.kv_wave_lds;
-  int* s_tok = (int*)wbase;                       // [nqs] local token of each streamed query slot
+  char* wbase = smem + (size_t)c.tabsize * 4 + (size_t)wave * bc.kv_wave_lds;
+  int* s_tok = (int*)wbase;                       // [nqs] byte offset of each streamed query slot's Q/dO row
   int* s_aq = s_tok + bc.nqs;                     // [nqs] bias-table address term (bytes)
   float* s_lse = (float*)(s_aq + bc.nqs);         // [nqs] lse * log2(e)   (+big for padding slots)
   float* s_dlt = s_lse + bc.nqs;                  // [nqs] delta
-  __bf16* s_q = (__bf16*)(s_dlt + bc.nqs);        // [32][M] Q tile
-  __bf16* s_do = s_q + 32 * M;                    // [32][M] dO tile
+  char* s_q = (char*)(s_dlt + bc.nqs);            // [32][M] bf16 Q tile
+  char* s_do = s_q + 32 * M * 2;                  // [32][M] bf16 dO tile
 
-  const __bf16* qb = (const __bf16*)p.q + b * p.q_sb + h * p.q_sh;
+  const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const __bf16*)p.q + b * p.q_sb + h * p.q_sh);
+  const __amdgpu_buffer_rsrc_t drs = make_rsrc((const __bf16*)p.dout + b * p.do_sb + h * p.do_sh);
   const __bf16* kb = (const __bf16*)p.k + b * p.k_sb + h * p.k_sh;
   const __bf16* vb = (const __bf16*)p.v + b * p.v_sb + h * p.v_sh;
-  const __bf16* dob = (const __bf16*)p.dout + b * p.do_sb + h * p.do_sh;
   __bf16* dkb = (__bf16*)p.dk + b * p.dk_sb + h * p.dk_sh;
   __bf16* dvb = (__bf16*)p.dv + b * p.dv_sb + h * p.dv_sh;
   const int Nloc = g.nx * g.ny;
+  const int qstride_b = (int)p.q_st * 2;
   const float c1 = p.scale * LOG2E;
   const int W = g.W, W2 = g.W2;
   const int nown = bc.nch * c.NWP;
+  const float* lse_bh = p.lse + (int64_t)bh * Nloc;
+  const float* dlt_bh = p.delta + (int64_t)bh * Nloc;
+
+  int st_off[MD], ld_off[MD], tr_off[2][MD], row_off[2][MK];
+#pragma unroll
+  for (int it = 0; it < MD; ++it) {
+    const int cid = it * 64 + lane;
+    const int row = cid / VCH, chn = cid % VCH;
+    st_off[it] = row * (M * 2) + ((chn * 16) ^ (SWZ * (((row >> 2) & 1) << 5)));
+    ld_off[it] = chn * 16;
+  }
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int row = hf * 16 + lg * 4 + (lj >> 2);
+#pragma unroll
+    for (int dt = 0; dt < MD; ++dt)
+      tr_off[hf][dt] = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
+    const int row2 = hf * 16 + lj;
+#pragma unroll
+    for (int ks = 0; ks < MK; ++ks)
+      row_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ (SWZ * (((row2 >> 2) & 1) << 5)));
+  }
 
   for (int gi = 0; gi < bc.kv_gpw; ++gi) {
     const int unit = (wgi * bc.kv_gpw + gi) * bc.kv_wpw + wave;
@@ -370,14 +370,27 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
     const int wp = glo ? 0 : unit % c.NWP, ch = glo ? 0 : unit / c.NWP;
     const int kn = ch % g.my, km = ch / g.my;
 
-    // ---- streamed query slot table
+    // ---- streamed query slot table: defaults (padding), then one neighbourhood row per lane
     for (int s = lane; s < bc.nqs; s += 64) {
-      const int ci = fdiv(s, c.magicW2), l = s - ci * W2;
-      const int xl = fdiv(l, c.magicW), yl = l - xl * W;
+      s_tok[s] = 0; s_aq[s] = glo ? 0 : c.aconst * 4; s_lse[s] = LSE_PAD; s_dlt[s] = 0.f;
+    }
+    wave_lds_fence();
+    int nchunks;
+    if (glo) {
+      nchunks = (bc.nch - split + bc.nsplit - 1) / bc.nsplit;
+    } else {
+      nchunks = 0;
+      for (int a = 0; a < g.nact; ++a) {
+        const int m_ = km - g.adr[a], n_ = kn - g.adc[a];
+        nchunks += (m_ >= 0 && m_ < g.mx && n_ >= 0 && n_ < g.my);
+      }
+    }
+    for (int rid = lane; rid < nchunks * W; rid += 64) {
+      const int ci = fdiv(rid, c.magicW), xl = rid - ci * W;
       int qm = -1, qn = -1, dr = 0, dc = 0;
       if (glo) {
         const int qch = split + ci * bc.nsplit;
-        if (qch < bc.nch) { qm = qch / g.my; qn = qch % g.my; }
+        qm = qch / g.my; qn = qch - qm * g.my;
       } else {
         int cnt = 0;
         for (int a = 0; a < g.nact; ++a) {
@@ -390,29 +403,19 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
           cnt += ok;
         }
       }
-      int tok = 0, aq = c.aconst * 4;
-      float ls = LSE_PAD, dl = 0.f;
-      if (qm >= 0) {
-        const int qr = qm * W + xl, qc = qn * W + yl;
-        if (qr < g.nx && qc < g.ny) {
-          tok = qr * g.ny + qc;
-          ls = p.lse[(int64_t)bh * Nloc + tok] * LOG2E;
-          dl = p.delta[(int64_t)bh * Nloc + tok];
-          aq = glo ? 0 : ((xl - dr * W) * c.P + (yl - dc * W) + c.aconst) * 4;
+      const int qr = qm * W + xl;
+      if (qm >= 0 && qr < g.nx) {
+        const int qc0 = qn * W;
+        const int nvalid = min(W, g.ny - qc0);
+        int tok = qr * g.ny + qc0;
+        int off = __mul24(tok, qstride_b);
+        int aq = glo ? 0 : ((xl - dr * W) * c.P - dc * W + c.aconst) * 4;
+        int s = ci * W2 + xl * W;
+        for (int yl = 0; yl < nvalid; ++yl) {
+          s_tok[s] = off; s_aq[s] = aq;
+          s_lse[s] = lse_bh[tok] * LOG2E; s_dlt[s] = dlt_bh[tok];
+          ++s; ++tok; off += qstride_b; aq += glo ? 0 : 4;
         }
-      }
-      if (glo && !(qm >= 0 && ls < LSE_PAD)) aq = 0;
-      s_tok[s] = tok; s_aq[s] = aq; s_lse[s] = ls; s_dlt[s] = dl;
-    }
-    // number of steps actually needed (trailing all-padding steps are skipped)
-    int nchunks;
-    if (glo) {
-      nchunks = (bc.nch - split + bc.nsplit - 1) / bc.nsplit;
-    } else {
-      nchunks = 0;
-      for (int a = 0; a < g.nact; ++a) {
-        const int m_ = km - g.adr[a], n_ = kn - g.adc[a];
-        nchunks += (m_ >= 0 && m_ < g.mx && n_ >= 0 && n_ < g.my);
       }
     }
     const int nsteps = (nchunks * W2 + 31) >> 5;
@@ -454,19 +457,16 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
         dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_lds_fence();
 
     u32x4 qr_[MD], dr_[MD];
     auto load_step = [&](int st) {
 #pragma unroll
       for (int it = 0; it < MD; ++it) {
-        const int cid = it * 64 + lane;
-        const int row = cid / VCH, chn = cid % VCH;
-        const int tok = s_tok[st * 32 + row];
-        qr_[it] = *(const u32x4*)(qb + (int64_t)tok * p.q_st + chn * 8);
-        dr_[it] = *(const u32x4*)(dob + (int64_t)tok * p.do_st + chn * 8);
+        const int row = (it * 64 + lane) / VCH;
+        const int off = s_tok[st * 32 + row] + ld_off[it];
+        qr_[it] = __builtin_amdgcn_raw_buffer_load_b128(qrs, off, 0, 0);
+        dr_[it] = __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0);
       }
     };
     if (nsteps > 0) load_step(0);
@@ -474,16 +474,11 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
     for (int st = 0; st < nsteps; ++st) {
 #pragma unroll
       for (int it = 0; it < MD; ++it) {
-        const int cid = it * 64 + lane;
-        const int row = cid / VCH, chn = cid % VCH;
-        const int off = row * (M * 2) + ((chn * 16) ^ (SWZ * (((row >> 2) & 1) << 5)));
-        *(u32x4*)((char*)s_q + off) = qr_[it];
-        *(u32x4*)((char*)s_do + off) = dr_[it];
+        *(u32x4*)(s_q + st_off[it]) = qr_[it];
+        *(u32x4*)(s_do + st_off[it]) = dr_[it];
       }
       if (st + 1 < nsteps) load_step(st + 1);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wave_lds_fence();
 
       bf16x8 pb[4], dsb[4];
 #pragma unroll
@@ -491,27 +486,20 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
         bf16x8 qa[MK], da[MK];
 #pragma unroll
         for (int ks = 0; ks < MK; ++ks) {
-          const int d0 = ks * 32 + lg * 8;
-          const int row = hf * 16 + lj;
-          const int off = row * (M * 2) + ((d0 * 2) ^ (SWZ * (((row >> 2) & 1) << 5)));
           bf16x8 z = {};
-          qa[ks] = d0 < M ? *(const bf16x8*)((const char*)s_q + off) : z;
-          da[ks] = d0 < M ? *(const bf16x8*)((const char*)s_do + off) : z;
+          qa[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(s_q + row_off[hf][ks]) : z;
+          da[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(s_do + row_off[hf][ks]) : z;
         }
         const int sb = st * 32 + hf * 16 + lg * 4;
         const i32x4 aq4 = *(const i32x4*)(s_aq + sb);
         const f32x4 ls4 = *(const f32x4*)(s_lse + sb);
         const f32x4 dl4 = *(const f32x4*)(s_dlt + sb);
-        f32x4 bq[4];
+        const float* tb[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const unsigned i0 = (unsigned)(aq4[r] - akl);
-          const unsigned addr = i0 + ((i0 >> 2) & 3u) * (unsigned)c.cstride_b;
-          bq[r] = *(const f32x4*)((const char*)tab + addr);
-        }
+        for (int r = 0; r < 4; ++r) tb[r] = (const float*)((const char*)tab + (aq4[r] - akl));
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-          f32x4 acc = {bq[0][kt], bq[1][kt], bq[2][kt], bq[3][kt]};
+          f32x4 acc = {tb[0][kt], tb[1][kt], tb[2][kt], tb[3][kt]};
           f32x4 dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) {
@@ -532,12 +520,10 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
         bf16x8 qt_, dt_;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          const int row = hf * 16 + lg * 4 + (lj >> 2);
-          const int off = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
           const bf16x4 tq = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)((char*)s_q + off)));
+              (s16x4 __attribute__((address_space(3)))*)(s_q + tr_off[hf][dt])));
           const bf16x4 td = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)((char*)s_do + off)));
+              (s16x4 __attribute__((address_space(3)))*)(s_do + tr_off[hf][dt])));
 #pragma unroll
           for (int e = 0; e < 4; ++e) { qt_[hf * 4 + e] = tq[e]; dt_[hf * 4 + e] = td[e]; }
         }
@@ -547,8 +533,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
           dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsb[kt], dk[dt][kt], 0, 0, 0);
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_fence();
     }
 
     // ---- epilogue
@@ -578,8 +563,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
           out[M + dt * 16 + lg * 4 + r] = dv[dt][0][r];
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_fence();
   }
 }
 
@@ -656,7 +640,7 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   bc.nqs = (9 * g.W2 + 31) & ~31;
   bc.kv_wave_lds = ((bc.nqs * 16 + 2 * 32 * d->M * 2 + 15) / 16) * 16;
   bc.kv_wpw = 4;
-  while (bc.kv_wpw > 1 && (size_t)c.copysize * 16 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
+  while (bc.kv_wpw > 1 && (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
   const int groups = (bc.units_kv_bh + bc.kv_wpw - 1) / bc.kv_wpw;
   int gpw = (int)(((int64_t)d->B * d->H * groups) / 2048);
   if (gpw < 1) gpw = 1;
@@ -667,11 +651,13 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   bc.dq_nwg = d->B * d->H * c.wg_per_bh;
 }
 
-static size_t dq_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.copysize * 20 + (size_t)c.wpw * bc.dq_wave_lds; }
-static size_t kv_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.copysize * 16 + (size_t)bc.kv_wpw * bc.kv_wave_lds; }
+static size_t dq_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.tabsize * 8 + (size_t)c.wpw * bc.dq_wave_lds; }
+static size_t kv_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds; }
 
 int vil_mfma_bwd_supported(const VilAttnDesc* d) {
   if ((d->do_st | d->do_sb | d->do_sh) & 7) return VIL_E_ALIGN;
+  // Q and dO rows are addressed through one table of 32-bit byte offsets in the dK/dV pass
+  if (d->do_st != d->q_st || d->q_st >= (1 << 22) || d->q_st * 2 * (int64_t)d->nx * d->ny >= (1ll << 31)) return VIL_E_BACKEND;
   if ((d->dq_st | d->dq_sb | d->dq_sh | d->dk_st | d->dk_sb | d->dk_sh | d->dv_st | d->dv_sb | d->dv_sh) & 3) return VIL_E_ALIGN;
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   BwdCfg bc; bwd_cfg(d, c, bc);
@@ -684,8 +670,8 @@ static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& 
   const size_t rows = (size_t)d->B * d->H * d->nx * d->ny;
   off[0] = 0;
   off[1] = ((rows + 3) & ~(size_t)3) + 4;      // + 4 words: norm maxima and the histogram scale
-  off[2] = off[1] + (size_t)d->H * 4 * c.copysize;
-  off[3] = off[2] + (size_t)bc.dq_nwg * c.copysize;
+  off[2] = off[1] + (size_t)d->H * c.tabsize;
+  off[3] = off[2] + (size_t)bc.dq_nwg * c.tabsize;
   off[4] = off[3] + (size_t)d->B * d->H * bc.nsplit * d->G * 2 * d->M;
 }
 
@@ -724,7 +710,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     default: return VIL_E_HEAD_DIM;              \
   }
   vil_prof_begin(VIL_K_TABLE, s, 0, 0);
-  k_mfma_table<<<dim3((4 * c.copysize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
+  k_mfma_table<<<dim3((c.tabsize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
   e = (int)hipMemsetAsync(bc.norm2, 0, 16, s);
@@ -775,7 +761,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   }
   if (bc.do_hist) {
     vil_prof_begin(VIL_K_REDUCE_BIAS, s, 0, 0);
-    k_mfma_reduce_hist<<<dim3((unsigned)((c.copysize + 63) / 64), p.H), dim3(256), 0, s>>>(p, c, bc);
+    k_mfma_reduce_hist<<<dim3((unsigned)((c.tabsize + 63) / 64), p.H), dim3(256), 0, s>>>(p, c, bc);
     vil_prof_end(s);
   }
   return (int)hipGetLastError();

@@ -1,5 +1,5 @@
-// vil_mfma_common.h -- types, launch configuration and LDS bias-table layout shared by the
-// MFMA forward and backward kernels.
+// vil_mfma_common.h -- types, launch configuration, LDS bias-table layout and the per-unit
+// key-slot table builder shared by the MFMA forward and backward kernels.
 #pragma once
 #include "vil_internal.h"
 #include <string.h>
@@ -16,14 +16,21 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define VIL_M_INIT (-1.0e20f)
 #define LOG2E 1.4426950408889634f
 
+// LDS bias table of one head (floats):
+//   [ (4W-1) rows x P : bias/scale at column CPAD + (dy + 2W-1); exact==1: -1e30 outside the window |
+//     gsz x -1e30 : where masked / padded key slots point |
+//     G x gsz x g2l[h][g]/scale : where the global key slots point ]
+// The table entry of (query (xq,yq), key (X,Y) in the query chunk's frame) is at
+//   Aq - Ak + aconst,  Aq = xq*P + yq,  Ak = X*P + Y,  aconst = (2W-1)*(P+1) + CPAD,
+// so a lane gathers it with one v_sub (per key) and an immediate offset (per query of its quad).
+// P == 11 (mod 32) spreads the 16 query columns of a wave (x*P + 4*hq) over distinct banks.
 struct MfmaCfg {
-  int P;             // row pitch (floats) of the LDS bias table
-  int copysize;      // floats per table copy (multiple of 4)
-  int cstride_b;     // (copysize - 1) * 4: byte offset between consecutive shifted copies
-  int guard0;        // start (floats) of the all-masked region
+  int P;             // row pitch (floats)
+  int tabsize;       // floats per head (multiple of 4)
+  int guard0;        // start of the all-masked region
   int glo0;          // start of the per-global-token constant regions
-  int gsz;           // size of one such region (Aq range + 4)
-  int aconst;        // (2W-1)*(P+1) + VIL_CPAD
+  int gsz;           // size of one such region (>= Aq range)
+  int aconst;
   unsigned magicW, magicW2;
   int HQ;            // query quads per chunk row = ceil(W/4)
   int NWP;           // waves per chunk = ceil(W*HQ/16)
@@ -32,15 +39,72 @@ struct MfmaCfg {
   int units_bh;      // mx*my*NWP
   int wg_per_bh, gpw;
   int wpw;           // waves per workgroup (4, or fewer when the per-wave LDS is large)
-  int wave_lds;      // bytes of private LDS per wave
-  int no_tr;         // debug: read V^T with scalar LDS loads instead of ds_read_b64_tr_b16
-  const float* tabws;  // (H, 4*copysize) prepared bias tables
+  int wave_lds;      // bytes of private LDS per wave (forward / dQ pass)
+  const float* tabws;  // (H, tabsize) prepared bias tables
 };
 
 __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned magic) { return __umulhi(n, magic); }
 
+// XCD-aware bijective remap: consecutive logical workgroups (same image/head, neighbouring
+// chunks -> shared K/V) land on the same XCD's L2 (hardware places block b on XCD b % 8)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 buf_load8(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Key-slot table of query chunk (cm,cn) in the wave's private LDS:
+//   s_koff[s] = byte offset (token * row stride) of key slot s inside the (image, head) K/V slice
+//   s_akey[s] = 4 * (Ak - aconst)   (masked slots: -4*guard0; global slot g: -4*(glo0 + g*gsz))
+// slots: [0,G) global tokens, then for each active neighbour a: W*W keys row-major, then padding.
+// Rows of the neighbourhood are distributed over lanes (one validity test per row).
+__device__ __forceinline__ void build_key_slots(const VilParams& p, const MfmaCfg& c, int cm, int cn, int lane,
+                                                int row_stride_b, int* s_koff, int* s_akey) {
+  const VilGeom& g = p.g;
+  const int W = g.W;
+  const int own_tok = p.G + (cm * W) * g.ny + cn * W;     // always a real token
+  const int own_off = __mul24(own_tok, row_stride_b);
+  for (int s = lane; s < c.NSP; s += 64) {
+    int off = own_off, ak = -c.guard0;
+    if (s < p.G) { off = __mul24(s, row_stride_b); ak = -(c.glo0 + s * c.gsz); }
+    s_koff[s] = off; s_akey[s] = ak * 4;
+  }
+  wave_lds_fence();
+  const int nrows = g.nact * W;
+  for (int rid = lane; rid < nrows; rid += 64) {
+    const int a = fdiv(rid, c.magicW), xt = rid - a * W;
+    const int a3 = (a * 11) >> 5;                           // a / 3 for a in [0, 9)
+    const int dr = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : g.adr[1]);
+    const int dc = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : g.adc[1]);
+    const int rm = cm + dr, rn = cn + dc, kr = rm * W + xt;
+    if (rm >= 0 && rm < g.mx && rn >= 0 && rn < g.my && kr < g.nx) {
+      const int kc0 = rn * W;
+      const int nvalid = min(W, g.ny - kc0);
+      int off = __mul24(p.G + kr * g.ny + kc0, row_stride_b);
+      int ak = ((dr * W + xt) * c.P + dc * W - c.aconst) * 4;
+      int s = p.G + a * g.W2 + xt * W;
+      for (int yt = 0; yt < nvalid; ++yt) {
+        s_koff[s] = off; s_akey[s] = ak;
+        ++s; off += row_stride_b; ak += 4;
+      }
+    }
+  }
+  wave_lds_fence();
+}
 
 // host: fills the launch configuration for a descriptor
 bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c);
-// device prologue kernel: builds the 4 shifted copies of every head's bias table
+// device prologue kernel: builds every head's bias table in the workspace
 __global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out);
