@@ -112,6 +112,20 @@ int vil_attn_bwd(const VilAttnDesc* d, const void* q, const void* k, const void*
                  void* dq, void* dk, void* dv, float* dbias_table, float* dg2l,
                  void* workspace, void* stream);
 
+/* ---- block glue: fused LayerNorm around the attention / MLP blocks
+ * (`x + drop_path(attn(norm(x), nx, ny))`, reference src/models/msvit.py:313-316,336-340).
+ * x: (rows, C) fp32 or bf16 with a row stride (elements); y is written in y_dtype (bf16 feeds the
+ * following GEMM directly); gamma/beta/mean/rstd fp32; C % 8 == 0, C <= 1024. */
+size_t vil_layernorm_workspace_bytes(int64_t rows, int C);
+int vil_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
+                      void* y, int y_dtype, float* mean, float* rstd, int64_t rows, int C,
+                      int64_t x_row_stride, int64_t y_row_stride, float eps, void* stream);
+/* dx has x's dtype; dgamma/dbeta (C) fp32 are overwritten; workspace >= vil_layernorm_workspace_bytes */
+int vil_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
+                      const float* mean, const float* rstd, void* dx, int dx_dtype,
+                      float* dgamma, float* dbeta, void* workspace, int64_t rows, int C,
+                      int64_t dy_row_stride, int64_t x_row_stride, int64_t dx_row_stride, void* stream);
+
 /* ---- optional profiling sink (a measurement aid for bench.py; the ONLY state the
  * library keeps: process-global, not thread-safe).  Between _begin and _end every
  * kernel the library launches is bracketed by hipEventRecord on its launch stream.

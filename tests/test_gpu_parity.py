@@ -342,3 +342,39 @@ def test_model_vil_tiny_vs_reference_logits(dev, golden_dir):
     errb = (lb.double().cpu() - ref).abs().max().item()
     _report(f"     model ViL-Tiny bf16 autocast: max|logit err| = {errb:.3e} (logit range {ref.abs().max():.2f})")
     assert errb < 0.1
+
+
+# ---------------------------------------------------------------- block glue: fused LayerNorm
+@pytest.mark.parametrize("C,rows", [(96, 1000), (48, 333), (192, 4097), (384, 777), (768, 130), (16, 70)])
+@pytest.mark.parametrize("mode", ["fp32", "fp32_to_bf16", "bf16"])
+def test_fused_layernorm_vs_torch(dev, C, rows, mode):
+    from vision_longformer_amd.layernorm import VilLayerNorm
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5)
+    dy = torch.randn(rows, C, generator=g)
+    ln = VilLayerNorm(C, eps=1e-6).to(dev)
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.3); ln.bias.normal_(0, 0.3)
+    ref = torch.nn.LayerNorm(C, eps=1e-6).double()
+    ref.weight.data.copy_(ln.weight.detach().double().cpu()); ref.bias.data.copy_(ln.bias.detach().double().cpu())
+    xin_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+    xd = x.to(xin_dtype).to(dev).requires_grad_(True)
+    xr = x.to(xin_dtype).double().requires_grad_(True)
+    if mode == "fp32_to_bf16":
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = ln(xd)
+        assert y.dtype == torch.bfloat16
+    else:
+        y = ln(xd)
+        assert y.dtype == xin_dtype
+    dyd = dy.to(y.dtype).to(dev)
+    y.backward(dyd)
+    yr = ref(xr)
+    yr.backward(dyd.double().cpu())
+    torch.cuda.synchronize()
+    lo = mode != "fp32"
+    torch.testing.assert_close(y.double().cpu(), yr.detach(), atol=3e-2 if lo else 2e-5, rtol=2e-2 if lo else 1e-5)
+    torch.testing.assert_close(xd.grad.double().cpu(), xr.grad, atol=3e-2 if mode == "bf16" else 2e-4, rtol=2e-2 if mode == "bf16" else 1e-4)
+    gs = max(1.0, float(ref.weight.grad.abs().max()))
+    torch.testing.assert_close(ln.weight.grad.double().cpu(), ref.weight.grad, atol=2e-3 * gs, rtol=2e-3)
+    torch.testing.assert_close(ln.bias.grad.double().cpu(), ref.bias.grad, atol=2e-3 * gs, rtol=2e-3)

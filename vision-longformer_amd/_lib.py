@@ -20,7 +20,8 @@ ABI_VERSION = 1
 
 EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_attn_workspace_bytes",
            "vil_attn_fwd", "vil_attn_bwd", "vil_geom_mask", "vil_geom_bias_index",
-           "vil_attn_profile_begin", "vil_attn_profile_end", "vil_attn_kernel_name")
+           "vil_attn_profile_begin", "vil_attn_profile_end", "vil_attn_kernel_name",
+           "vil_layernorm_workspace_bytes", "vil_layernorm_fwd", "vil_layernorm_bwd")
 
 
 class VilAttnDesc(ctypes.Structure):
@@ -71,6 +72,15 @@ def lib():
         L.vil_attn_profile_end.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
         L.vil_attn_kernel_name.restype = ctypes.c_char_p
         L.vil_attn_kernel_name.argtypes = [ctypes.c_int]
+        i64 = ctypes.c_int64
+        L.vil_layernorm_workspace_bytes.restype = ctypes.c_size_t
+        L.vil_layernorm_workspace_bytes.argtypes = [i64, ctypes.c_int]
+        L.vil_layernorm_fwd.restype = ctypes.c_int
+        L.vil_layernorm_fwd.argtypes = [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp, vp, i64, ctypes.c_int,
+                                        i64, i64, ctypes.c_float, vp]
+        L.vil_layernorm_bwd.restype = ctypes.c_int
+        L.vil_layernorm_bwd.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp,
+                                        i64, ctypes.c_int, i64, i64, i64, vp]
         if L.vil_attn_abi_version() != ABI_VERSION:
             raise RuntimeError("libvilattn.so ABI version mismatch; rebuild it")
         _lib = L

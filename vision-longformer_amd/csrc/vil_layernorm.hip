@@ -1,0 +1,285 @@
+// vil_layernorm.hip -- fused LayerNorm forward / backward for the blocks either side of the
+// hot path ("block glue": `x + drop_path(attn(norm(x), nx, ny))`,
+// reference src/models/msvit.py:313-316,336-340).  HBM-bound row kernels:
+//   forward  y = (x - mean) * rstd * gamma + beta, x fp32 or bf16, y written directly in the dtype
+//            the consumer wants (bf16 for the q/kv/fc1 GEMMs under autocast) -> no separate cast
+//            kernels, half the write traffic; mean / rstd kept in fp32 for the backward.
+//   backward dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
+//            dgamma/dbeta: per-lane register partials over a grid-stride row loop, reduced across
+//            the wave by shuffles and across workgroups by a second, tiny kernel (deterministic).
+// Mapping: LPR lanes per row (16/32/64), 8 contiguous channels per lane and iteration (16-byte bf16 /
+// 2 x 16-byte fp32 accesses), 64/LPR rows per wavefront, butterfly reductions inside the LPR lanes.
+#include "vil_internal.h"
+#include <string.h>
+
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+
+template <typename T> struct LNIO;
+template <> struct LNIO<float> {
+  static __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    const f32x4_ a = *(const f32x4_*)p, b = *(const f32x4_*)(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  }
+  static __device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+    *(f32x4_*)p = (f32x4_){v[0], v[1], v[2], v[3]};
+    *(f32x4_*)(p + 4) = (f32x4_){v[4], v[5], v[6], v[7]};
+  }
+};
+template <> struct LNIO<vil_bf16> {
+  static __device__ __forceinline__ void ld8(const vil_bf16* p, float (&v)[8]) {
+    const u32x4_ a = *(const u32x4_*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(a[i] << 16);
+      v[2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void st8(vil_bf16* p, const float (&v)[8]) {
+    typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+    bf16x8_ o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];       // v_cvt_pk_bf16_f32, round-to-nearest-even
+    *(bf16x8_*)p = o;
+  }
+};
+
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct LNParams {
+  const void* x; const void* dy; void* y; void* dx;
+  const float* gamma; const float* beta;
+  float* mean; float* rstd;
+  float* parts;            // backward: (nblocks, 2, C)
+  float* dgamma; float* dbeta;
+  int64_t rows, x_rs, y_rs, dy_rs, dx_rs;
+  int C, nblocks;
+  float eps;
+};
+
+template <typename TI, typename TO, int LPR, int NIT>
+__global__ __launch_bounds__(256) void k_ln_fwd(LNParams p) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane % LPR, slot = lane / LPR;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + slot;
+  const bool rok = row < p.rows;
+  float v[NIT][8];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e0 = (it * LPR + sub) * 8;
+    if (rok && e0 < p.C) LNIO<TI>::ld8((const TI*)p.x + row * p.x_rs + e0, v[it]);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[it][i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[it][i];
+  }
+  const float mean = row_sum<LPR>(s) / p.C;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e0 = (it * LPR + sub) * 8;
+    if (e0 < p.C) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[it][i] - mean; q = fmaf(d, d, q); }
+    }
+  }
+  const float rstd = rsqrtf(row_sum<LPR>(q) / p.C + p.eps);
+  if (!rok) return;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e0 = (it * LPR + sub) * 8;
+    if (e0 < p.C) {
+      float gm[8], bt[8], o[8];
+      LNIO<float>::ld8(p.gamma + e0, gm);
+      LNIO<float>::ld8(p.beta + e0, bt);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = fmaf((v[it][i] - mean) * rstd, gm[i], bt[i]);
+      LNIO<TO>::st8((TO*)p.y + row * p.y_rs + e0, o);
+    }
+  }
+  if (sub == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+}
+
+template <typename TI, typename TG, typename TO, int LPR, int NIT>
+__global__ __launch_bounds__(256) void k_ln_bwd(LNParams p) {
+  constexpr int RPW = 64 / LPR;
+  __shared__ float red[4][2][NIT * LPR * 8];
+  const int lane = threadIdx.x & 63, sub = lane % LPR, slot = lane / LPR, wave = threadIdx.x >> 6;
+  float dg[NIT][8], db[NIT][8], gm[NIT][8];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e0 = (it * LPR + sub) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dg[it][i] = 0.f; db[it][i] = 0.f; gm[it][i] = 0.f; }
+    if (e0 < p.C) LNIO<float>::ld8(p.gamma + e0, gm[it]);
+  }
+  const int64_t rows_per_pass = (int64_t)gridDim.x * 4 * RPW;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; r0 < p.rows; r0 += rows_per_pass) {
+    const int64_t row = r0 + slot;
+    const bool rok = row < p.rows;
+    const float mean = rok ? p.mean[row] : 0.f, rstd = rok ? p.rstd[row] : 0.f;
+    float xh[NIT][8], g[NIT][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e0 = (it * LPR + sub) * 8;
+      float xv[8], dyv[8];
+      if (rok && e0 < p.C) {
+        LNIO<TI>::ld8((const TI*)p.x + row * p.x_rs + e0, xv);
+        LNIO<TG>::ld8((const TG*)p.dy + row * p.dy_rs + e0, dyv);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xv[i] = mean; dyv[i] = 0.f; }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        xh[it][i] = (xv[i] - mean) * rstd;
+        g[it][i] = dyv[i] * gm[it][i];
+        s1 += g[it][i];
+        s2 = fmaf(g[it][i], xh[it][i], s2);
+        dg[it][i] = fmaf(dyv[i], xh[it][i], dg[it][i]);
+        db[it][i] += dyv[i];
+      }
+    }
+    const float m1 = row_sum<LPR>(s1) / p.C, m2 = row_sum<LPR>(s2) / p.C;
+    if (rok) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int e0 = (it * LPR + sub) * 8;
+        if (e0 < p.C) {
+          float o[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = rstd * (g[it][i] - m1 - xh[it][i] * m2);
+          LNIO<TO>::st8((TO*)p.dx + row * p.dx_rs + e0, o);
+        }
+      }
+    }
+  }
+  // reduce the RPW row slots of the wave, then the 4 waves of the block, then hand the block's
+  // partial to the second kernel
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+        dg[it][i] += __shfl_xor(dg[it][i], o, 64);
+        db[it][i] += __shfl_xor(db[it][i], o, 64);
+      }
+      if (slot == 0) {
+        red[wave][0][(it * LPR + sub) * 8 + i] = dg[it][i];
+        red[wave][1][(it * LPR + sub) * 8 + i] = db[it][i];
+      }
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * p.C; e += 256) {
+    const int w = e / p.C, c = e % p.C;
+    p.parts[((int64_t)blockIdx.x * 2 + w) * p.C + c] = red[0][w][c] + red[1][w][c] + red[2][w][c] + red[3][w][c];
+  }
+}
+
+// block = 64 columns x 16 partial groups: every thread sums nblocks/16 partials, LDS tree over the groups
+__global__ __launch_bounds__(1024) void k_ln_reduce(LNParams p) {
+  __shared__ float red[16][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + col;
+  float s = 0.f;
+  if (e < 2 * p.C) {
+    const int w = e / p.C, c = e % p.C;
+    for (int b = grp; b < p.nblocks; b += 16) s += p.parts[((int64_t)b * 2 + w) * p.C + c];
+  }
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && e < 2 * p.C) {
+#pragma unroll
+    for (int g2 = 1; g2 < 16; ++g2) s += red[g2][col];
+    const int w = e / p.C, c = e % p.C;
+    (w == 0 ? p.dgamma : p.dbeta)[c] = s;
+  }
+}
+
+// ------------------------------------------------------------------ C ABI
+static int ln_check(int64_t rows, int C, int64_t s0, int64_t s1) {
+  if (rows <= 0 || C <= 0) return VIL_E_SHAPE;
+  if (C % 8 || C > 1024) return VIL_E_HEAD_DIM;
+  if ((s0 | s1) & 7) return VIL_E_ALIGN;
+  return VIL_OK;
+}
+static int ln_blocks(int64_t rows, int rpw) {
+  int64_t need = (rows + 4 * rpw - 1) / (4 * rpw);
+  return (int)(need < 512 ? need : 512);
+}
+
+extern "C" size_t vil_layernorm_workspace_bytes(int64_t rows, int C) {
+  return (size_t)1024 * 2 * (size_t)C * sizeof(float);
+}
+
+#define LN_SHAPE_SWITCH(C_, ...)                                              \
+  if (C_ <= 128) { constexpr int LPR = 16, NIT = 1; __VA_ARGS__; }            \
+  else if (C_ <= 256) { constexpr int LPR = 32, NIT = 1; __VA_ARGS__; }       \
+  else if (C_ <= 512) { constexpr int LPR = 64, NIT = 1; __VA_ARGS__; }       \
+  else { constexpr int LPR = 64, NIT = 2; __VA_ARGS__; }
+
+extern "C" int vil_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
+                                 void* y, int y_dtype, float* mean, float* rstd, int64_t rows, int C,
+                                 int64_t x_row_stride, int64_t y_row_stride, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd) return VIL_E_NULL;
+  int e = ln_check(rows, C, x_row_stride, y_row_stride);
+  if (e) return e;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return VIL_E_ALIGN;
+  LNParams p; memset(&p, 0, sizeof(p));
+  p.x = x; p.y = y; p.gamma = gamma; p.beta = beta; p.mean = mean; p.rstd = rstd;
+  p.rows = rows; p.C = C; p.x_rs = x_row_stride; p.y_rs = y_row_stride; p.eps = eps;
+  hipStream_t s = (hipStream_t)stream;
+  const int key = x_dtype * 2 + y_dtype;
+  LN_SHAPE_SWITCH(C, {
+    const unsigned grid = (unsigned)((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)));
+    switch (key) {
+      case 0: k_ln_fwd<float, float, LPR, NIT><<<dim3(grid), dim3(256), 0, s>>>(p); break;
+      case 1: k_ln_fwd<float, vil_bf16, LPR, NIT><<<dim3(grid), dim3(256), 0, s>>>(p); break;
+      case 2: k_ln_fwd<vil_bf16, float, LPR, NIT><<<dim3(grid), dim3(256), 0, s>>>(p); break;
+      case 3: k_ln_fwd<vil_bf16, vil_bf16, LPR, NIT><<<dim3(grid), dim3(256), 0, s>>>(p); break;
+      default: return VIL_E_DTYPE;
+    }
+  });
+  return (int)hipGetLastError();
+}
+
+extern "C" int vil_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
+                                 const float* mean, const float* rstd, void* dx, int dx_dtype,
+                                 float* dgamma, float* dbeta, void* workspace, int64_t rows, int C,
+                                 int64_t dy_row_stride, int64_t x_row_stride, int64_t dx_row_stride, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return VIL_E_NULL;
+  int e = ln_check(rows, C, dy_row_stride | x_row_stride, dx_row_stride);
+  if (e) return e;
+  if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma) & 15) return VIL_E_ALIGN;
+  LNParams p; memset(&p, 0, sizeof(p));
+  p.dy = dy; p.x = x; p.gamma = gamma; p.mean = (float*)mean; p.rstd = (float*)rstd; p.dx = dx;
+  p.dgamma = dgamma; p.dbeta = dbeta; p.parts = (float*)workspace;
+  p.rows = rows; p.C = C; p.dy_rs = dy_row_stride; p.x_rs = x_row_stride; p.dx_rs = dx_row_stride;
+  hipStream_t s = (hipStream_t)stream;
+  if (dx_dtype != x_dtype) return VIL_E_DTYPE;       // dx has the dtype of x
+  const int key = x_dtype * 2 + dy_dtype;
+  LN_SHAPE_SWITCH(C, {
+    p.nblocks = ln_blocks(rows, 64 / LPR);
+    switch (key) {
+      case 0: k_ln_bwd<float, float, float, LPR, NIT><<<dim3(p.nblocks), dim3(256), 0, s>>>(p); break;
+      case 1: k_ln_bwd<float, vil_bf16, float, LPR, NIT><<<dim3(p.nblocks), dim3(256), 0, s>>>(p); break;
+      case 2: k_ln_bwd<vil_bf16, float, vil_bf16, LPR, NIT><<<dim3(p.nblocks), dim3(256), 0, s>>>(p); break;
+      case 3: k_ln_bwd<vil_bf16, vil_bf16, vil_bf16, LPR, NIT><<<dim3(p.nblocks), dim3(256), 0, s>>>(p); break;
+      default: return VIL_E_DTYPE;
+    }
+  });
+  e = (int)hipGetLastError();
+  if (e) return e;
+  k_ln_reduce<<<dim3((2 * C + 63) / 64), dim3(1024), 0, s>>>(p);
+  return (int)hipGetLastError();
+}

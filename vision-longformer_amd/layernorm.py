@@ -1,0 +1,84 @@
+"""Fused LayerNorm (HIP, libvilattn.so: vil_layernorm_fwd/_bwd) for the blocks around the hot path.
+
+`VilLayerNorm` is an `nn.LayerNorm` (same parameters / state-dict keys).  On device tensors it runs one
+fused kernel per direction; under bf16 autocast with `cast_output=True` it writes its output directly
+in bf16 -- numerically identical to PyTorch's fp32 LayerNorm followed by autocast's cast for the next
+Linear, without the cast kernels and with half the write traffic.  CPU tensors fall through to
+`nn.LayerNorm.forward` (this layer is glue, not the hot path; the CPU baseline model uses it that way)."""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+
+_DT = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16}
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class _FusedLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        L = _lib.lib()
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        w = weight.detach().float().contiguous()
+        b = bias.detach().float().contiguous()
+        y = torch.empty(rows, C, dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        with torch.cuda.device(x.device):
+            _lib.check(L.vil_layernorm_fwd(_p(x2), _DT[x2.dtype], _p(w), _p(b), _p(y), _DT[out_dtype], _p(mean), _p(rstd),
+                                           rows, C, x2.stride(0), y.stride(0), float(eps), stream))
+        ctx.save_for_backward(x2, w, mean, rstd)
+        ctx.x_shape = x.shape
+        ctx.wdtype = weight.dtype
+        return y.view(*x.shape[:-1], C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, mean, rstd = ctx.saved_tensors
+        L = _lib.lib()
+        rows, C = x2.shape
+        dy2 = dy.reshape(rows, C)
+        if dy2.stride(-1) != 1:
+            dy2 = dy2.contiguous()
+        if dy2.dtype not in _DT:
+            dy2 = dy2.float()
+        dx = torch.empty(rows, C, dtype=x2.dtype, device=x2.device)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x2.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x2.device)
+        ws = torch.empty(L.vil_layernorm_workspace_bytes(rows, C) // 4, dtype=torch.float32, device=x2.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream)
+        with torch.cuda.device(x2.device):
+            _lib.check(L.vil_layernorm_bwd(_p(dy2), _DT[dy2.dtype], _p(x2), _DT[x2.dtype], _p(w), _p(mean), _p(rstd),
+                                           _p(dx), _DT[dx.dtype], _p(dgamma), _p(dbeta), _p(ws), rows, C,
+                                           dy2.stride(0), x2.stride(0), dx.stride(0), stream))
+        return dx.view(ctx.x_shape), dgamma.to(ctx.wdtype), dbeta.to(ctx.wdtype), None, None
+
+
+class VilLayerNorm(nn.LayerNorm):
+    """cast_output=True: under autocast emit the autocast dtype (the consumer is a GEMM);
+    False: keep the residual-stream dtype (PatchEmbed's norm_embed)."""
+
+    def __init__(self, normalized_shape, eps=1e-5, cast_output=True, **kw):
+        super().__init__(normalized_shape, eps=eps, **kw)
+        self.cast_output = cast_output
+
+    def forward(self, x):
+        C = x.shape[-1]
+        if (not x.is_cuda) or x.dtype not in _DT or C % 8 or C > 1024 or not self.elementwise_affine or self.bias is None:
+            return super().forward(x)
+        out_dtype = x.dtype
+        if torch.is_autocast_enabled("cuda"):
+            ac = torch.get_autocast_dtype("cuda")
+            # PyTorch autocast runs LayerNorm in fp32 and the next GEMM casts its input to `ac`
+            out_dtype = ac if (self.cast_output and ac in _DT) else torch.float32
+        return _FusedLN.apply(x, self.weight, self.bias, self.eps, out_dtype)

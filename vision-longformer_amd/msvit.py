@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .longformer2d import Long2DSCSelfAttention, _trunc_normal_
+from .layernorm import VilLayerNorm
 
 
 class DropPath(nn.Module):
@@ -109,6 +110,8 @@ class PatchEmbed(nn.Module):
         self.patch_size = ps
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=ps, stride=ps)
         self.norm_embed = norm_layer(embed_dim) if norm_embed else None
+        if isinstance(self.norm_embed, VilLayerNorm):
+            self.norm_embed.cast_output = False       # feeds the fp32 residual stream, not a GEMM
         self.nx, self.ny, self.Nglo = nx, ny, nglo
         if nglo >= 1:
             self.cls_token = nn.Parameter(torch.zeros(1, nglo, embed_dim))
@@ -195,7 +198,7 @@ def parse_arch(arch):
 
 class MsViT(nn.Module):
     def __init__(self, arch, img_size=512, in_chans=3, num_classes=1000, qkv_bias=True, qk_scale=None,
-                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., norm_layer=partial(VilLayerNorm, eps=1e-6),
                  norm_embed=False, w=7, d=1, sharew=False, only_glo=False, share_kv=False,
                  attn_type='longformerhand', sw_exact=0, mode=0, **args):
         super().__init__()
