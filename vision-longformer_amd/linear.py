@@ -1,0 +1,64 @@
+"""`VilLinear`: an `nn.Linear` whose weight-gradient GEMM is split along the token axis.
+
+The projections around the hot path are plain library GEMMs (hipBLASLt through PyTorch).  Their
+weight gradients dW = dY^T X contract over B*N tokens (25 k ... 400 k) into a tiny (C_out x C_in)
+output; the library's heuristic launches one workgroup per output tile with no split-K, i.e. 9-144
+workgroups on a 256-CU part (measured on MI355X, tools/gemm_probe.py: 0.72-0.87 ms per stage-1
+weight gradient = 20-35 TFLOP/s).  Splitting the contraction into S batched chunks
+(`torch.bmm` -> S x (C_out x C_in) partials, summed in fp32) fills the machine: 3-4x faster.
+Forward and input-gradient GEMMs are unchanged.  Parameters / state-dict keys are nn.Linear's."""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+
+def _pick_split(T):
+    s = 1
+    while s < 64 and T % (2 * s) == 0 and T // (2 * s) >= 2048:
+        s *= 2
+    return s
+
+
+class _SplitKLinearFn(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        co, ci = weight.shape
+        dy2 = dy.reshape(-1, co)
+        x2 = x.reshape(-1, ci)
+        T = x2.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            S = _pick_split(T)
+            if S > 1 and dy2.is_contiguous() and x2.is_contiguous():
+                parts = torch.bmm(dy2.view(S, T // S, co).transpose(1, 2), x2.view(S, T // S, ci))
+                dw = parts.sum(0, dtype=torch.float32).to(weight.dtype)
+            else:
+                dw = dy2.t() @ x2
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+class VilLinear(nn.Linear):
+    def forward(self, x):
+        if x.is_cuda and x.numel() // x.shape[-1] >= 4096 and torch.is_grad_enabled():
+            if torch.is_autocast_enabled("cuda"):
+                dt = torch.get_autocast_dtype("cuda")
+                # autocast semantics of nn.Linear: inputs and parameters in the autocast dtype
+                x, w = x.to(dt), self.weight.to(dt)
+                b = self.bias.to(dt) if self.bias is not None else None
+                with torch.autocast("cuda", enabled=False):
+                    return _SplitKLinearFn.apply(x, w, b)
+            return _SplitKLinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)

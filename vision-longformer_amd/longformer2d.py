@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from .ops import vil_local_attention
+from .linear import VilLinear
 
 
 def _trunc_normal_(t, std):
@@ -64,16 +65,16 @@ class Long2DSCSelfAttention(nn.Module):
         self.mode = mode                  # 0: 3x3 chunks; -1: own chunk; >0: random-shift training
         self.backend = None               # kernel family override ("scalar" / "mfma"); None = library default
 
-        self.query = nn.Linear(dim, dim, bias=qkv_bias)
-        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
-        self.proj = nn.Linear(dim, dim)
+        self.query = VilLinear(dim, dim, bias=qkv_bias)
+        self.kv = VilLinear(dim, dim * 2, bias=qkv_bias)
+        self.proj = VilLinear(dim, dim)
         if nglo >= 1:
             if sharew:
                 self.query_global, self.kv_global, self.proj_global = self.query, self.kv, self.proj
             else:
-                self.query_global = nn.Linear(dim, dim, bias=qkv_bias)
-                self.kv_global = nn.Linear(dim, dim * 2, bias=qkv_bias)
-                self.proj_global = nn.Linear(dim, dim)
+                self.query_global = VilLinear(dim, dim, bias=qkv_bias)
+                self.kv_global = VilLinear(dim, dim * 2, bias=qkv_bias)
+                self.proj_global = VilLinear(dim, dim)
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj_drop = nn.Dropout(proj_drop)
 

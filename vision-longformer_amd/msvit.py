@@ -17,6 +17,7 @@ from torch import nn
 
 from .longformer2d import Long2DSCSelfAttention, _trunc_normal_
 from .layernorm import VilLayerNorm
+from .linear import VilLinear
 
 
 class DropPath(nn.Module):
@@ -37,9 +38,9 @@ class DropPath(nn.Module):
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
         super().__init__()
-        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc1 = VilLinear(in_features, hidden_features or in_features)
         self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.fc2 = VilLinear(hidden_features or in_features, out_features or in_features)
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
@@ -55,9 +56,9 @@ class Attention(nn.Module):
         super().__init__()
         self.num_heads = num_heads
         self.scale = qk_scale or (dim // num_heads) ** -0.5
-        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.qkv = VilLinear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim)
+        self.proj = VilLinear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         self.rpe = rpe
         if rpe:
