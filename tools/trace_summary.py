@@ -1,0 +1,37 @@
+"""Steady-state per-step summary of a rocprofv3 kernel trace of bench.py (last 3 steps)."""
+import csv, collections, sys
+path = sys.argv[1]
+rows = list(csv.DictReader(open(path)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+marker = sys.argv[2] if len(sys.argv) > 2 else "void k_mfma_fwd<2>"
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(marker)]
+per = int(sys.argv[3]) if len(sys.argv) > 3 else 1       # marker launches per step
+nsteps = 3
+s0, s1 = idx[-1 - nsteps * per], idx[-1]
+t0, t1 = int(rows[s0]["Start_Timestamp"]), int(rows[s1]["Start_Timestamp"])
+def classify(n):
+    if n.startswith("Cijk"): return "gemm(hipblaslt)"
+    if "k_mfma" in n or "k_delta" in n or "k_reduce" in n or "k_scalar" in n: return "vil hot path"
+    if "k_ln_" in n: return "vil layernorm"
+    if "layer_norm" in n or "cuCompute" in n: return "torch layernorm"
+    if "attn_fwd" in n or "bwd_kernel" in n or "attn_bwd" in n: return "sdpa (dense attn)"
+    if "bfloat16_copy" in n or "bfloat16tofloat32" in n or "copy_kernel" in n.lower(): return "casts/copies"
+    if "reduce_kernel" in n: return "reduce"
+    if "multi_tensor" in n or "adam" in n.lower(): return "optimizer"
+    if "conv" in n.lower() or "Im2d2Col" in n or "igemm" in n or "_ZN2ck" in n or "ck::" in n: return "conv"
+    if "elementwise" in n: return "elementwise"
+    if "Cat" in n or "index" in n.lower() or "gather" in n.lower(): return "cat/index"
+    return "other"
+agg = collections.defaultdict(lambda: [0, 0.0]); cat = collections.defaultdict(lambda: [0, 0.0])
+for r in rows[s0:s1]:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    a = agg[r["Kernel_Name"]]; a[0] += 1; a[1] += d
+    c = cat[classify(r["Kernel_Name"])]; c[0] += 1; c[1] += d
+tot = sum(v[1] for v in agg.values())
+print("# last %d steady-state steps: wall %.2f ms/step, kernel-busy %.2f ms/step, %d launches/step" % (
+    nsteps, (t1 - t0) / 1e6 / nsteps, tot / 1e6 / nsteps, (s1 - s0) / nsteps))
+for k, v in sorted(cat.items(), key=lambda kv: -kv[1][1]):
+    print("%-20s %5d calls/step %8.3f ms/step %5.1f%%" % (k, v[0] / nsteps, v[1] / 1e6 / nsteps, 100 * v[1] / tot))
+print("%-100s %6s %10s %9s %6s" % ("kernel", "calls", "us/call", "ms/step", "%"))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[4]) if len(sys.argv) > 4 else 40]:
+    print("%-100s %6d %10.1f %9.3f %6.1f" % (k[:100], v[0] / nsteps, v[1] / v[0] / 1e3, v[1] / 1e6 / nsteps, 100 * v[1] / tot))

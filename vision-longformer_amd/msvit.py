@@ -35,6 +35,49 @@ class DropPath(nn.Module):
         return x * (mask / keep)
 
 
+class _DropPathAdd(torch.autograd.Function):
+    """x + y * mask (mask = per-sample keep / keep_prob) as ONE kernel each way: the residual add of
+    AttnBlock / MlpBlock with stochastic depth folded in (instead of mul, then add, then their backwards)."""
+
+    @staticmethod
+    def forward(ctx, x, y, mask):
+        ctx.save_for_backward(mask)
+        ctx.ydtype = y.dtype
+        return torch.addcmul(x, y, mask)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g, (g * mask).to(ctx.ydtype), None
+
+
+def residual_drop_path(x, y, drop_prob, training):
+    """x + drop_path(y): stochastic depth per sample (reference msvit.py:313-316,336-340 with timm's DropPath)."""
+    if drop_prob == 0.0 or not training:
+        return x + y
+    keep = 1.0 - drop_prob
+    mask = torch.empty((x.shape[0],) + (1,) * (x.dim() - 1), dtype=x.dtype, device=x.device).bernoulli_(keep).div_(keep)
+    return _DropPathAdd.apply(x, y, mask)
+
+
+class _TableGather(torch.autograd.Function):
+    """table[index] whose backward is an atomic index_add_ instead of PyTorch's sort-based
+    index-put backward (a radix sort + merge kernels per dense attention layer and step)."""
+
+    @staticmethod
+    def forward(ctx, table, index):
+        ctx.save_for_backward(index)
+        ctx.shape = table.shape
+        return table[index]
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        out = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        out.index_add_(0, index, g)
+        return out, None
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
         super().__init__()
@@ -80,7 +123,7 @@ class Attention(nn.Module):
         [g2l[1] | table gather] rows for local ones (msvit.py:88-111)."""
         L = self.wx * self.wy
         assert N == self.nglo + L, "For relative position, N != self.nglo + self.wx*self.wy!"
-        loc = self.local_relative_position_bias_table[self.relative_position_index.reshape(-1)]
+        loc = _TableGather.apply(self.local_relative_position_bias_table, self.relative_position_index.reshape(-1))
         loc = loc.view(L, L, -1).permute(2, 0, 1)
         if self.nglo == 0:
             return loc
@@ -165,7 +208,8 @@ class AttnBlock(nn.Module):
 
     def forward(self, xtuple):
         x, nx, ny = xtuple
-        return x + self.drop_path(self.attn(self.norm(x), nx, ny)), nx, ny
+        p = self.drop_path.drop_prob if isinstance(self.drop_path, DropPath) else 0.0
+        return residual_drop_path(x, self.attn(self.norm(x), nx, ny), p, self.training), nx, ny
 
 
 class MlpBlock(nn.Module):
@@ -181,7 +225,8 @@ class MlpBlock(nn.Module):
 
     def forward(self, xtuple):
         x, nx, ny = xtuple
-        return self.shortcut(x) + self.drop_path(self.mlp(self.norm(x))), nx, ny
+        p = self.drop_path.drop_prob if isinstance(self.drop_path, DropPath) else 0.0
+        return residual_drop_path(self.shortcut(x), self.mlp(self.norm(x)), p, self.training), nx, ny
 
 
 def parse_arch(arch):
