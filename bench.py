@@ -101,11 +101,14 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="auto", choices=["auto", "scalar", "mfma"])
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="run the step as a hipGraph (measured on ViL-Small: no faster than eager at N=1, and it gives up "
+                         "DDP's overlapped bucketed all-reduce, so auto = off)")
     args = ap.parse_args()
 
     from vision_longformer_amd import _lib, ops
     from vision_longformer_amd.engine import (CONFIGS, init_distributed, build_vil, make_optimizer, wrap_ddp,
-                                             SyntheticBatches, train_step)
+                                             SyntheticBatches, train_step, GraphedTrainStep)
     rank, local_rank, world, device = init_distributed()
     if device.type != "cuda":
         raise SystemExit("bench.py needs a GPU: the product path is HIP-only (no CPU fallback)")
@@ -117,24 +120,42 @@ def main():
     B = args.batch or cfg_batch
     torch.manual_seed(0)
     model = build_vil(args.config).to(device).train()
-    opt = make_optimizer(model)
-    ddp = wrap_ddp(model, device, world)
+    use_graph = args.graph == "on"
+    opt = make_optimizer(model, capturable=use_graph)
     data = SyntheticBatches(B, img, device, rank)
+    if use_graph:
+        if world > 1:      # same initial weights on every rank (what DDP's constructor would do)
+            for p_ in model.parameters():
+                dist.broadcast(p_.data, 0)
+        gstep = GraphedTrainStep(model, opt, *data.next(), world=world)
+        step_fn = lambda xb, tb: gstep(xb, tb)
+    else:
+        ddp = wrap_ddp(model, device, world)
+        step_fn = lambda xb, tb: train_step(ddp, opt, xb, tb)
 
     for _ in range(args.warmup):
-        train_step(ddp, opt, *data.next())
+        step_fn(*data.next())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     cap = max(64, args.steps * 64)
-    _lib.profile_begin(cap)
+    if not use_graph:                  # (a replayed graph makes no library calls: its kernels are profiled below)
+        _lib.profile_begin(cap)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(ddp, opt, *data.next())
+        loss = step_fn(*data.next())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if use_graph:
+        # per-kernel hipEvent timing needs the library's own launches: run the SAME step eagerly,
+        # right after the timed region, on the same weights / shapes (not part of `value`)
+        ddp_e = model
+        _lib.profile_begin(cap)
+        for _ in range(min(args.steps, 5)):
+            train_step(ddp_e, opt, *data.next()) if world == 1 else gstep._body(eager=True)
+        torch.cuda.synchronize()
     recs = _lib.profile_end(cap)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -144,6 +165,7 @@ def main():
 
     if rank == 0:
         ks = kernel_stats(recs)
+        nprof = min(args.steps, 5) if use_graph else args.steps
         hot_ms = sum(k["total_ms"] for k in ks.values())
         dom = max(ks, key=lambda n: ks[n]["total_ms"]) if ks else None
         roofline = None
@@ -170,9 +192,11 @@ def main():
             "config": {"workload": f"{args.config}: ViL ({fam}) ATTN_TYPE=longformerhand rpe, {img}x{img}, "
                                    f"windows f{f1}/f{f2}, train step fwd+bwd+AdamW, random-init weights",
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "backend": args.backend, "random_shift_mode": mode},
+                       "backend": args.backend, "random_shift_mode": mode,
+                       "launch": "hipGraph replay (fwd+bwd" + ("+AdamW)" if world == 1 else "), flat-gradient RCCL all-reduce, AdamW")
+                                 if use_graph else "eager (DDP bucketed all-reduce)"},
             "roofline": roofline,
-            "hot_path_ms_per_step": round(hot_ms / args.steps, 3),
+            "hot_path_ms_per_step": round(hot_ms / nprof, 3),
             "kernels": ks,
             "final_loss": round(loss_val, 4),
         }

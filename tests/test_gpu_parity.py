@@ -378,3 +378,41 @@ def test_fused_layernorm_vs_torch(dev, C, rows, mode):
     gs = max(1.0, float(ref.weight.grad.abs().max()))
     torch.testing.assert_close(ln.weight.grad.double().cpu(), ref.weight.grad, atol=2e-3 * gs, rtol=2e-3)
     torch.testing.assert_close(ln.bias.grad.double().cpu(), ref.bias.grad, atol=2e-3 * gs, rtol=2e-3)
+
+
+# ---------------------------------------------------------------- hipGraph training step
+def test_graphed_train_step_equals_eager(dev):
+    """The captured fwd+bwd+AdamW graph must walk the same trajectory as the eager step."""
+    from vision_longformer_amd.engine import make_optimizer, train_step, GraphedTrainStep
+    from vision_longformer_amd.msvit import MsViT
+    arch = "l1,h1,d32,n1,s1,g1,p4,f4,a0_l2,h2,d64,n2,s1,g1,p2,f4,a0_l3,h2,d64,n1,s0,g1,p2,f7,a0"
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(8, 3, 64, 64, generator=g).to(dev) for _ in range(3)]
+    ts = [torch.softmax(torch.randn(8, 10, generator=g), -1).to(dev) for _ in range(3)]
+
+    def run(graphed):
+        torch.manual_seed(0)
+        m = MsViT(arch, img_size=64, num_classes=10, drop_path_rate=0.0, norm_embed=True, sharew=True).to(dev).train()
+        opt = make_optimizer(m, lr=1e-3, capturable=graphed)
+        losses = []
+        if graphed:
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+            gs = GraphedTrainStep(m, opt, xs[0], ts[0], warmup=2)
+            m.load_state_dict(sd)                       # undo the warm-up updates
+            for st in opt.state.values():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            for x, t in zip(xs, ts):
+                losses.append(float(gs(x, t)))
+        else:
+            for x, t in zip(xs, ts):
+                losses.append(float(train_step(m, opt, x, t)))
+        torch.cuda.synchronize()
+        return losses, torch.cat([p.detach().float().reshape(-1) for p in m.parameters()]).cpu()
+
+    le, pe = run(False)
+    lg, pg = run(True)
+    _report(f"     graph-vs-eager losses {le} {lg}  max|dparam| {float((pe - pg).abs().max()):.3e}")
+    assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-2
+    assert float((pe - pg).abs().max()) < 5e-3
