@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="auto", choices=["auto", "scalar", "mfma"])
+    ap.add_argument("--master-weights", default="on", choices=["on", "off"],
+                    help="bf16 working weights + fp32 master (engine.MasterWeightAdamW) instead of per-call autocast casts")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="run the step as a hipGraph (measured on ViL-Small: no faster than eager at N=1, and it gives up "
                          "DDP's overlapped bucketed all-reduce, so auto = off)")
@@ -108,7 +110,7 @@ def main():
 
     from vision_longformer_amd import _lib, ops
     from vision_longformer_amd.engine import (CONFIGS, init_distributed, build_vil, make_optimizer, wrap_ddp,
-                                             SyntheticBatches, train_step, GraphedTrainStep)
+                                             SyntheticBatches, train_step, GraphedTrainStep, MasterWeightAdamW)
     rank, local_rank, world, device = init_distributed()
     if device.type != "cuda":
         raise SystemExit("bench.py needs a GPU: the product path is HIP-only (no CPU fallback)")
@@ -121,7 +123,8 @@ def main():
     torch.manual_seed(0)
     model = build_vil(args.config).to(device).train()
     use_graph = args.graph == "on"
-    opt = make_optimizer(model, capturable=use_graph)
+    use_master = args.master_weights == "on" and not use_graph
+    opt = MasterWeightAdamW(model) if use_master else make_optimizer(model, capturable=use_graph)
     data = SyntheticBatches(B, img, device, rank)
     if use_graph:
         if world > 1:      # same initial weights on every rank (what DDP's constructor would do)
@@ -193,6 +196,8 @@ def main():
                                    f"windows f{f1}/f{f2}, train step fwd+bwd+AdamW, random-init weights",
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "backend": args.backend, "random_shift_mode": mode,
+                       "precision": "bf16 compute, fp32 master weights + fp32 AdamW state"
+                                    + (" (bf16 working copy, foreach refresh)" if use_master else " (autocast casts)"),
                        "launch": "hipGraph replay (fwd+bwd" + ("+AdamW)" if world == 1 else "), flat-gradient RCCL all-reduce, AdamW")
                                  if use_graph else "eager (DDP bucketed all-reduce)"},
             "roofline": roofline,

@@ -112,6 +112,19 @@ int vil_attn_bwd(const VilAttnDesc* d, const void* q, const void* k, const void*
                  void* dq, void* dk, void* dv, float* dbias_table, float* dg2l,
                  void* workspace, void* stream);
 
+/* ---- global-token QUERY rows (reference longformer2d.py:210-227): every one of
+ * the G global tokens attends all G+Nloc keys, bias g2g[h][g][g'] on global keys and g2l0[h][g]
+ * (= g2l_relative_position_bias[0]) on local keys.  q_g / out_g / dout_g / dq_g point at row 0 of
+ * (B, G, H*M) views addressed with the descriptor's q_ / o_ / do_ / dq_ strides; lse_g is (B,H,G).
+ * The backward ACCUMULATES into dk / dv (all G+Nloc rows; call it after vil_attn_bwd wrote them)
+ * and into dg2g / dg2l0 (caller zero-initialises), and overwrites dq_g.  G <= 4. */
+int vil_glo_attn_fwd(const VilAttnDesc* d, const void* q_g, const void* k, const void* v,
+                     const float* g2g, const float* g2l0, void* out_g, float* lse_g, void* stream);
+int vil_glo_attn_bwd(const VilAttnDesc* d, const void* q_g, const void* k, const void* v,
+                     const void* out_g, const void* dout_g, const float* lse_g,
+                     const float* g2g, const float* g2l0, void* dq_g, void* dk, void* dv,
+                     float* dg2g, float* dg2l0, void* stream);
+
 /* ---- block glue: fused LayerNorm around the attention / MLP blocks
  * (`x + drop_path(attn(norm(x), nx, ny))`, reference src/models/msvit.py:313-316,336-340).
  * x: (rows, C) fp32 or bf16 with a row stride (elements); y is written in y_dtype (bf16 feeds the

@@ -129,3 +129,31 @@ def test_ddp_gloo_world2_matches_single_process():
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     # AdamW normalises tiny gradients, so fp32 summation-order noise shows up at ~1e-5 * lr scale
     torch.testing.assert_close(flat, ret["flat"], rtol=1e-3, atol=2e-4)
+
+
+def test_master_weight_adamw_matches_plain_adamw_in_fp32():
+    """With a float32 'low' dtype the master-weight wrapper must be exactly AdamW."""
+    from vision_longformer_amd.engine import MasterWeightAdamW, train_step
+    import types
+    from oracle.cpu_model import _oracle_forward
+
+    def make():
+        torch.manual_seed(0)
+        m = MsViT(SMALL_ARCH, img_size=32, num_classes=10, drop_path_rate=0.0, norm_embed=True, sharew=True)
+        for mod in m.modules():
+            if isinstance(mod, Long2DSCSelfAttention):
+                mod.forward = types.MethodType(_oracle_forward, mod)
+        return m
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 32, 32, generator=g)
+    t = torch.softmax(torch.randn(4, 10, generator=g), -1)
+    a, b = make(), make()
+    oa = make_optimizer(a, lr=1e-2)
+    ob = MasterWeightAdamW(b, lr=1e-2, low_dtype=torch.float32)
+    assert len(ob.low) > 10 and len(ob.direct) > 5
+    for _ in range(2):
+        train_step(a, oa, x, t, amp_dtype=None)
+        train_step(b, ob, x, t, amp_dtype=None)
+    fa = torch.cat([p.detach().reshape(-1) for p in a.parameters()])
+    fb = torch.cat([p.detach().reshape(-1) for p in b.parameters()])
+    torch.testing.assert_close(fa, fb, rtol=0, atol=0)

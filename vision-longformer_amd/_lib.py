@@ -21,7 +21,8 @@ ABI_VERSION = 1
 EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_attn_workspace_bytes",
            "vil_attn_fwd", "vil_attn_bwd", "vil_geom_mask", "vil_geom_bias_index",
            "vil_attn_profile_begin", "vil_attn_profile_end", "vil_attn_kernel_name",
-           "vil_layernorm_workspace_bytes", "vil_layernorm_fwd", "vil_layernorm_bwd")
+           "vil_layernorm_workspace_bytes", "vil_layernorm_fwd", "vil_layernorm_bwd",
+           "vil_glo_attn_fwd", "vil_glo_attn_bwd")
 
 
 class VilAttnDesc(ctypes.Structure):
@@ -73,6 +74,10 @@ def lib():
         L.vil_attn_kernel_name.restype = ctypes.c_char_p
         L.vil_attn_kernel_name.argtypes = [ctypes.c_int]
         i64 = ctypes.c_int64
+        L.vil_glo_attn_fwd.restype = ctypes.c_int
+        L.vil_glo_attn_fwd.argtypes = [dp] + [vp] * 8
+        L.vil_glo_attn_bwd.restype = ctypes.c_int
+        L.vil_glo_attn_bwd.argtypes = [dp] + [vp] * 14
         L.vil_layernorm_workspace_bytes.restype = ctypes.c_size_t
         L.vil_layernorm_workspace_bytes.argtypes = [i64, ctypes.c_int]
         L.vil_layernorm_fwd.restype = ctypes.c_int

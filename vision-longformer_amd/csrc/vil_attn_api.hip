@@ -173,7 +173,7 @@ void vil_prof_end(hipStream_t s) {
 extern "C" const char* vil_attn_kernel_name(int kid) {
   static const char* names[VIL_K_COUNT] = {"k_mfma_table", "k_mfma_fwd", "k_scalar_fwd", "k_delta", "k_scalar_bwd_dq",
                                            "k_scalar_bwd_dkdv", "k_reduce_glo", "k_reduce_bias", "k_mfma_bwd_dq",
-                                           "k_mfma_bwd_dkdv"};
+                                           "k_mfma_bwd_dkdv", "k_glo_fwd", "k_glo_bwd"};
   return (kid >= 0 && kid < VIL_K_COUNT) ? names[kid] : "?";
 }
 

@@ -18,7 +18,7 @@ import random
 import torch
 from torch import nn
 
-from .ops import vil_local_attention
+from .ops import vil_local_attention, vil_full_attention, FULL_MAX_G
 from .linear import VilLinear
 
 
@@ -101,6 +101,20 @@ class Long2DSCSelfAttention(nn.Module):
         Nloc = nx * ny
         assert G + Nloc == N, "Global dimension does not match!"
         mode = self._resolve_mode()
+
+        if (1 <= G <= FULL_MAX_G and self.query_global is self.query and self.kv_global is self.kv
+                and self.proj_global is self.proj and not self.only_glo and H * M == C
+                and M in (8, 16, 32, 48, 64) and self.attn_drop.p == 0.0):
+            # shared weights (every published ViL): ONE query / kv / proj GEMM over all N tokens and one
+            # fused op for local + global rows -- no token slicing, no concatenation, and the two
+            # gradient contributions to kv are summed inside the kernels
+            out = vil_full_attention(self.query(x), self.kv(x),
+                                     self.local_relative_position_bias_table if self.rpe else None,
+                                     self.g2l_relative_position_bias if self.rpe else None,
+                                     self.g2g_relative_position_bias if self.rpe else None,
+                                     nx=nx, ny=ny, w=self.attention_window, nglo=G, num_heads=H, mode=mode,
+                                     exact=self.exact, scale=self.scale, backend=self.backend)
+            return self.proj_drop(self.proj(out))
 
         q = self.query(x[:, G:])                  # (B, Nloc, C), unscaled: the kernel applies `scale`
         kv = self.kv(x)                           # (B, N, 2C): [..., :C] keys, [..., C:] values

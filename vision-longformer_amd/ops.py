@@ -146,3 +146,102 @@ def vil_local_attention(q, kv, bias_table, g2l_bias, *, nx, ny, w, nglo, num_hea
     if nglo == 0:
         g2l_bias = None
     return _VilLocalAttention.apply(q, kv, bias_table, g2l_bias, cfg, backend or DEFAULT_BACKEND)
+
+
+class _VilFullAttention(torch.autograd.Function):
+    """Local rows (vil_attn_fwd/_bwd) AND the G global-token query rows (vil_glo_attn_fwd/_bwd) of one
+    Long2DSCSelfAttention layer on shared q / kv tensors: q_all (B, G+Nloc, C) -> out_all (B, G+Nloc, C).
+    The global rows' dk/dv contribution is accumulated in place after the local pass."""
+
+    @staticmethod
+    def forward(ctx, q_all, kv, table, g2l, g2g, cfg, backend):
+        if not q_all.is_cuda:
+            raise RuntimeError("vil_full_attention needs device tensors: the product path is the HIP "
+                               "kernels (libvilattn.so); there is no CPU fallback")
+        if q_all.dtype not in _DT or kv.dtype != q_all.dtype:
+            raise TypeError(f"vil_full_attention supports float32/bfloat16 q,kv of one dtype; got {q_all.dtype}, {kv.dtype}")
+        L = _lib.lib()
+        q_all = q_all.contiguous()
+        kv = _last_contig(kv)
+        B, N, C = q_all.shape
+        G, H = cfg["G"], cfg["H"]
+        Nloc = N - G
+        assert kv.shape == (B, N, 2 * C) and Nloc == cfg["nx"] * cfg["ny"]
+        k, v = kv[..., :C], kv[..., C:]
+        out_all = torch.empty(B, N, C, dtype=q_all.dtype, device=q_all.device)
+        lse = torch.empty(B, H, Nloc, dtype=torch.float32, device=q_all.device)
+        lse_g = torch.empty(B, H, G, dtype=torch.float32, device=q_all.device)
+        tab = table.detach().float().contiguous() if table is not None else None
+        g2l_f = g2l.detach().float().contiguous() if g2l is not None else None       # (2, H, G)
+        g2g_f = g2g.detach().float().contiguous() if g2g is not None else None       # (H, G, G)
+        q_loc, out_loc = q_all[:, G:], out_all[:, G:]
+        d = _make_desc(q_loc, k, v, out_loc, cfg, backend)
+        ws = _workspace(d, 0, q_all.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(q_all.device).cuda_stream)
+        with torch.cuda.device(q_all.device):
+            _lib.check(L.vil_attn_fwd(ctypes.byref(d), _ptr(q_loc), _ptr(k), _ptr(v), _ptr(tab),
+                                      _ptr(g2l_f[1]) if g2l_f is not None else None,
+                                      _ptr(out_loc), _ptr(lse), _ptr(ws), stream))
+            _lib.check(L.vil_glo_attn_fwd(ctypes.byref(d), _ptr(q_all), _ptr(k), _ptr(v), _ptr(g2g_f),
+                                          _ptr(g2l_f[0]) if g2l_f is not None else None,
+                                          _ptr(out_all), _ptr(lse_g), stream))
+        ctx.save_for_backward(q_all, kv, out_all, lse, lse_g, tab, g2l_f, g2g_f)
+        ctx.cfg, ctx.backend = cfg, backend
+        ctx.dts = (table.dtype if table is not None else None, g2l.dtype if g2l is not None else None,
+                   g2g.dtype if g2g is not None else None)
+        return out_all
+
+    @staticmethod
+    def backward(ctx, dout_all):
+        q_all, kv, out_all, lse, lse_g, tab, g2l_f, g2g_f = ctx.saved_tensors
+        cfg = ctx.cfg
+        L = _lib.lib()
+        B, N, C = q_all.shape
+        G, H = cfg["G"], cfg["H"]
+        M = C // H
+        dout_all = dout_all.contiguous()
+        if dout_all.dtype != q_all.dtype:
+            dout_all = dout_all.to(q_all.dtype)
+        k, v = kv[..., :C], kv[..., C:]
+        dq_all = torch.empty(B, N, C, dtype=q_all.dtype, device=q_all.device)
+        dkv = torch.empty(B, N, 2 * C, dtype=q_all.dtype, device=q_all.device)
+        dk, dv = dkv[..., :C], dkv[..., C:]
+        dtab = torch.empty_like(tab) if tab is not None else None
+        dg2l = torch.zeros_like(g2l_f) if g2l_f is not None else None
+        dg2g = torch.zeros_like(g2g_f) if g2g_f is not None else None
+        q_loc, out_loc, do_loc, dq_loc = q_all[:, G:], out_all[:, G:], dout_all[:, G:], dq_all[:, G:]
+        d = _make_desc(q_loc, k, v, out_loc, cfg, ctx.backend)
+        d.do_sb, d.do_st, d.do_sh = _strides(do_loc, M)
+        d.dq_sb, d.dq_st, d.dq_sh = _strides(dq_loc, M)
+        d.dk_sb, d.dk_st, d.dk_sh = _strides(dk, M)
+        d.dv_sb, d.dv_st, d.dv_sh = _strides(dv, M)
+        ws = _workspace(d, 1, q_all.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(q_all.device).cuda_stream)
+        with torch.cuda.device(q_all.device):
+            _lib.check(L.vil_attn_bwd(ctypes.byref(d), _ptr(q_loc), _ptr(k), _ptr(v), _ptr(out_loc), _ptr(do_loc),
+                                      _ptr(lse), _ptr(tab), _ptr(g2l_f[1]) if g2l_f is not None else None,
+                                      _ptr(dq_loc), _ptr(dk), _ptr(dv), _ptr(dtab),
+                                      _ptr(dg2l[1]) if dg2l is not None else None, _ptr(ws), stream))
+            _lib.check(L.vil_glo_attn_bwd(ctypes.byref(d), _ptr(q_all), _ptr(k), _ptr(v), _ptr(out_all), _ptr(dout_all),
+                                          _ptr(lse_g), _ptr(g2g_f), _ptr(g2l_f[0]) if g2l_f is not None else None,
+                                          _ptr(dq_all), _ptr(dk), _ptr(dv), _ptr(dg2g),
+                                          _ptr(dg2l[0]) if dg2l is not None else None, stream))
+        tdt, ldt, gdt = ctx.dts
+        return (dq_all, dkv, dtab.to(tdt) if dtab is not None else None,
+                dg2l.to(ldt) if dg2l is not None else None, dg2g.to(gdt) if dg2g is not None else None, None, None)
+
+
+FULL_MAX_G = 4      # vil_glo_attn_* bookkeeping limit
+
+
+def vil_full_attention(q_all, kv, bias_table, g2l_bias, g2g_bias, *, nx, ny, w, nglo, num_heads, mode=0, exact=0,
+                       scale=None, backend=None):
+    """All rows of one layer: q_all (B, nglo+nx*ny, C) from ONE query projection, kv (B, N, 2C);
+    g2l_bias (2, H, nglo) and g2g_bias (H, nglo, nglo) or None.  Returns (B, N, C)."""
+    if exact not in (0, 1, -1) or (exact == 1 and mode != 0):
+        raise ValueError("longsc exact should be in [0,1,-1]!")
+    assert 1 <= nglo <= FULL_MAX_G
+    C = q_all.shape[-1]
+    cfg = dict(nx=int(nx), ny=int(ny), W=int(w), G=int(nglo), H=int(num_heads), mode=int(mode), exact=int(exact),
+               only_glo=False, scale=float(scale) if scale is not None else (C // num_heads) ** -0.5, debug=0)
+    return _VilFullAttention.apply(q_all, kv, bias_table, g2l_bias, g2g_bias, cfg, backend or DEFAULT_BACKEND)
