@@ -178,8 +178,16 @@ def main():
             tot_f = sum(r[3] for r in recs if r[0] == dom)
             ai = tot_f / tot_b if tot_b else 0.0
             # the fused kernels sit just below the bf16 ridge (2.5 PF / 8 TB/s = 312 F/B) -> HBM roof
+            traffic = None
+            try:       # PMC HBM bytes per launch, collected offline with rocprofv3 --pmc (profiles/)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                if pm["config"] == args.config and pm["per_gpu_batch"] == B and dom in pm["kernels"]:
+                    traffic = round(pm["kernels"][dom]["hbm_bytes_per_launch"])
+            except (OSError, KeyError, ValueError):
+                pass
             roofline = {"kernel": dom, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(k["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(k["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": round(tot_b / k["launches"]),
                         "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
                         "arith_intensity_flop_per_byte": round(ai, 1),
                         "achieved_tflops": k["TFLOPs"],
