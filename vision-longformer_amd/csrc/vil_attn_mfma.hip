@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
     if (unit >= c.units_bh) break;
     const int wp = unit % c.NWP, ch = unit / c.NWP;
     const int cn = ch % g.my, cm = ch / g.my;
-    build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey);
+    const int nslots = build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey);
 
     // ---- query slots of this lane: column j of q-tile qt is query (x, y = 4*hq + qt)
     const int jj = wp * 16 + lj;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
       for (int dt = 0; dt < MD; ++dt) o[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    const int nsteps = c.NSP >> 5;
+    const int nsteps = nslots >> 5;
     bf16x8 kf[2][MK];
     u32x4 vr[MD];
     auto load_step = [&](int st) {

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
     if (unit < c.units_bh) {
       const int wp = unit % c.NWP, ch = unit / c.NWP;
       const int cn = ch % g.my, cm = ch / g.my;
-      build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey);
+      const int nslots = build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey);
       const int jj = wp * 16 + lj;
       const int qx = jj / c.HQ, qhq = jj % c.HQ;
       const int aq0b = (min(qx, W - 1) * c.P + 4 * qhq) * 4;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
 #pragma unroll
         for (int dt = 0; dt < MD; ++dt) dq[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-      const int nsteps = c.NSP >> 5;
+      const int nsteps = nslots >> 5;
       bf16x8 vf[2][MK];
       u32x4 kr_[MD];
       auto load_step = [&](int st) {

@@ -67,41 +67,55 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // Key-slot table of query chunk (cm,cn) in the wave's private LDS:
 //   s_koff[s] = byte offset (token * row stride) of key slot s inside the (image, head) K/V slice
-//   s_akey[s] = 4 * (Ak - aconst)   (masked slots: -4*guard0; global slot g: -4*(glo0 + g*gsz))
-// slots: [0,G) global tokens, then for each active neighbour a: W*W keys row-major, then padding.
-// Rows of the neighbourhood are distributed over lanes (one validity test per row).
-__device__ __forceinline__ void build_key_slots(const VilParams& p, const MfmaCfg& c, int cm, int cn, int lane,
-                                                int row_stride_b, int* s_koff, int* s_akey) {
+//   s_akey[s] = 4 * (Ak - aconst)   (padding slots: -4*guard0; global slot g: -4*(glo0 + g*gsz))
+// Slots are COMPACTED: [0,G) global tokens, then only the keys the chunk may attend (neighbour by
+// neighbour, row-major), then masked padding up to a multiple of 32.  Out-of-image neighbours and
+// zero-padded rows/columns therefore cost no MFMA/softmax work at all (border chunks of a 4x4 chunk
+// grid see 4-6 of 9 neighbours).  Rows of the neighbourhood are distributed over lanes (one validity
+// test per row); a wave prefix sum places each row's keys.  Returns the padded slot count.
+__device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg& c, int cm, int cn, int lane,
+                                               int row_stride_b, int* s_koff, int* s_akey) {
   const VilGeom& g = p.g;
   const int W = g.W;
-  const int own_tok = p.G + (cm * W) * g.ny + cn * W;     // always a real token
-  const int own_off = __mul24(own_tok, row_stride_b);
-  for (int s = lane; s < c.NSP; s += 64) {
-    int off = own_off, ak = -c.guard0;
-    if (s < p.G) { off = __mul24(s, row_stride_b); ak = -(c.glo0 + s * c.gsz); }
-    s_koff[s] = off; s_akey[s] = ak * 4;
+  for (int s = lane; s < p.G; s += 64) {
+    s_koff[s] = __mul24(s, row_stride_b); s_akey[s] = -(c.glo0 + s * c.gsz) * 4;
   }
-  wave_lds_fence();
   const int nrows = g.nact * W;
-  for (int rid = lane; rid < nrows; rid += 64) {
-    const int a = fdiv(rid, c.magicW), xt = rid - a * W;
-    const int a3 = (a * 11) >> 5;                           // a / 3 for a in [0, 9)
-    const int dr = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : g.adr[1]);
-    const int dc = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : g.adc[1]);
-    const int rm = cm + dr, rn = cn + dc, kr = rm * W + xt;
-    if (rm >= 0 && rm < g.mx && rn >= 0 && rn < g.my && kr < g.nx) {
-      const int kc0 = rn * W;
-      const int nvalid = min(W, g.ny - kc0);
-      int off = __mul24(p.G + kr * g.ny + kc0, row_stride_b);
-      int ak = ((dr * W + xt) * c.P + dc * W - c.aconst) * 4;
-      int s = p.G + a * g.W2 + xt * W;
-      for (int yt = 0; yt < nvalid; ++yt) {
-        s_koff[s] = off; s_akey[s] = ak;
-        ++s; off += row_stride_b; ak += 4;
+  int base = p.G;                                            // wave-uniform running slot offset
+  for (int r0 = 0; r0 < nrows; r0 += 64) {
+    const int rid = r0 + lane;
+    int nvalid = 0, off = 0, ak = 0;
+    if (rid < nrows) {
+      const int a = fdiv(rid, c.magicW), xt = rid - a * W;
+      const int a3 = (a * 11) >> 5;                           // a / 3 for a in [0, 9)
+      const int dr = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : g.adr[1]);
+      const int dc = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : g.adc[1]);
+      const int rm = cm + dr, rn = cn + dc, kr = rm * W + xt;
+      if (rm >= 0 && rm < g.mx && rn >= 0 && rn < g.my && kr < g.nx) {
+        const int kc0 = rn * W;
+        nvalid = min(W, g.ny - kc0);
+        off = __mul24(p.G + kr * g.ny + kc0, row_stride_b);
+        ak = ((dr * W + xt) * c.P + dc * W - c.aconst) * 4;
       }
     }
+    int incl = nvalid;                                        // inclusive prefix sum over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    int s = base + incl - nvalid;
+    for (int yt = 0; yt < nvalid; ++yt) {
+      s_koff[s] = off; s_akey[s] = ak;
+      ++s; off += row_stride_b; ak += 4;
+    }
+    base += __shfl(incl, 63, 64);
   }
+  const int total = base, padded = (total + 31) & ~31;
+  const int own_off = __mul24(p.G + (cm * W) * g.ny + cn * W, row_stride_b);   // always a real token
+  for (int s = total + lane; s < padded; s += 64) { s_koff[s] = own_off; s_akey[s] = -c.guard0 * 4; }
   wave_lds_fence();
+  return __builtin_amdgcn_readfirstlane(padded);
 }
 
 // host: fills the launch configuration for a descriptor
