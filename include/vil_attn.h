@@ -73,7 +73,9 @@ typedef struct VilAttnDesc {
   int32_t only_glo;         /* local rows attend the global tokens only                  */
   int32_t backend;          /* VIL_BACKEND_*                                             */
   float   scale;            /* softmax scale; scores = scale*q.k + bias                  */
-  int32_t reserved;
+  int32_t bias_side;        /* side S of the (S*S, H) bias table; 0 = 4W-1 (the sliding-chunk module).
+                               S = 2W-1 with mode -1 and W = grid side is the dense `Attention` of the
+                               s0 stages (reference msvit.py:37-120): one chunk = the whole image      */
   int64_t q_sb, q_st, q_sh; /* element strides (batch, token, head)                      */
   int64_t k_sb, k_st, k_sh;
   int64_t v_sb, v_st, v_sh;
@@ -96,7 +98,7 @@ size_t vil_attn_workspace_bytes(const VilAttnDesc* d, int pass);
 
 /* out[b,i,h,:] = softmax_j(scale*q_i.k_j + bias_ij | allowed keys) v_j ;
  * lse[(b*H+h)*Nloc + i] = natural-log-sum-exp of row i (float32).
- * bias_table: float32 ((4W-1)^2, H) row-major or NULL (rpe off);
+ * bias_table: float32 (S*S, H) row-major, S = bias_side or 4W-1, entry (dx+(S-1)/2)*S + dy+(S-1)/2, or NULL (rpe off);
  * g2l: float32 (H, G) = g2l_relative_position_bias[1] or NULL. */
 int vil_attn_fwd(const VilAttnDesc* d, const void* q, const void* k, const void* v,
                  const float* bias_table, const float* g2l,

@@ -416,3 +416,58 @@ def test_graphed_train_step_equals_eager(dev):
     _report(f"     graph-vs-eager losses {le} {lg}  max|dparam| {float((pe - pg).abs().max()):.3e}")
     assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-2
     assert float((pe - pg).abs().max()) < 5e-3
+
+
+# ---------------------------------------------------------------- dense attention (s0 stages)
+def _dense_reference(qkv, table, g2l, g2g, nx, ny, G, H, scale):
+    """fp64 restatement of the reference's dense Attention.forward (src/models/msvit.py:91-120)."""
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    M = C // H
+    q, k, v = qkv.view(B, N, 3, H, M).permute(2, 0, 3, 1, 4)
+    attn = (q @ k.transpose(-2, -1)) * scale
+    if table is not None:
+        L = nx * ny
+        ix, iy = torch.meshgrid(torch.arange(nx), torch.arange(ny), indexing="ij")
+        ix, iy = ix.reshape(-1), iy.reshape(-1)
+        rel = (ix[:, None] - ix[None, :] + nx - 1) * (2 * ny - 1) + (iy[:, None] - iy[None, :] + ny - 1)
+        loc = table[rel.reshape(-1)].view(L, L, H).permute(2, 0, 1)
+        if G > 0:
+            top = torch.cat([g2g, g2l[0].unsqueeze(-1).expand(-1, -1, L)], dim=-1)
+            bot = torch.cat([g2l[1].unsqueeze(1).expand(-1, L, -1), loc], dim=-1)
+            bias = torch.cat([top, bot], dim=1)
+        else:
+            bias = loc
+        attn = attn + bias.unsqueeze(0)
+    attn = attn.softmax(dim=-1)
+    return (attn @ v).transpose(1, 2).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("nx,G,H,M,B,rpe", [(14, 1, 6, 64, 2, True), (7, 0, 12, 64, 2, True), (24, 1, 6, 64, 1, True),
+                                             (12, 0, 12, 64, 1, True), (5, 2, 2, 16, 2, True), (14, 1, 3, 32, 2, False),
+                                             (9, 1, 2, 48, 2, True)])
+def test_dense_attention_one_chunk_vs_reference(dev, nx, G, H, M, B, rpe):
+    from vision_longformer_amd.ops import vil_dense_attention
+    g = torch.Generator().manual_seed(17)
+    N, C = G + nx * nx, H * M
+    qkv = torch.randn(B, N, 3 * C, generator=g).bfloat16().float()
+    dout = torch.randn(B, N, C, generator=g).bfloat16().float()
+    table = torch.randn((2 * nx - 1) ** 2, H, generator=g) * 0.5 if rpe else None
+    g2l = torch.randn(2, H, G, generator=g) * 0.5 if (rpe and G) else None
+    g2g = torch.randn(H, G, G, generator=g) * 0.5 if (rpe and G) else None
+    scale = M ** -0.5
+    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (qkv, table, g2l, g2g)]
+    ref = _dense_reference(leaves[0], leaves[1], leaves[2], leaves[3], nx, nx, G, H, scale)
+    (ref * dout.double()).sum().backward()
+    dl = [t.to(dev, torch.bfloat16 if i == 0 else torch.float32).requires_grad_(True) if t is not None else None
+          for i, t in enumerate((qkv, table, g2l, g2g))]
+    out = vil_dense_attention(dl[0], dl[1], dl[2], dl[3], nx=nx, ny=nx, nglo=G, num_heads=H, scale=scale, backend="mfma")
+    out.backward(dout.to(dev, torch.bfloat16))
+    torch.cuda.synchronize()
+    got = dict(out=out.detach().double().cpu(), dqkv=dl[0].grad.double().cpu())
+    want = dict(out=ref.detach(), dqkv=leaves[0].grad)
+    for nm, i in (("dtable", 1), ("dg2l", 2), ("dg2g", 3)):
+        if leaves[i] is not None:
+            got[nm] = dl[i].grad.double().cpu(); want[nm] = leaves[i].grad
+    tol = dict(out=(2e-2, 5e-2), dqkv=(5e-2, 2e-1), dtable=(2.5e-1, 1e-1), dg2l=(2.5e-1, 1e-1), dg2g=(2.5e-1, 1e-1))
+    compare(f"dense one-chunk nx{nx} G{G} H{H} M{M}", got, want, tol)

@@ -28,7 +28,7 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
 class VilAttnDesc(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_int32) for n in
                  ("B", "H", "M", "nx", "ny", "W", "G", "mode", "exact", "dtype", "only_glo", "backend")] +
-                [("scale", ctypes.c_float), ("reserved", ctypes.c_int32)] +
+                [("scale", ctypes.c_float), ("bias_side", ctypes.c_int32)] +
                 [(t + s, ctypes.c_int64) for t in ("q", "k", "v", "o", "do", "dq", "dk", "dv")
                  for s in ("_sb", "_st", "_sh")])
 

@@ -39,8 +39,10 @@ __global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out) {
   if (e < tbl * c.P) {
     const int row = e / c.P, col = e % c.P - VIL_CPAD;
     if (col >= 0 && col < tbl) {
-      if (p.has_bias) v = p.table[(int64_t)(row * tbl + col) * p.H + h] * inv;
       const int dx = row - (2 * W - 1), dy = col - (2 * W - 1);
+      const int o = p.bias_off, S = p.bias_S;      // the caller's table covers |dx|,|dy| <= o
+      if (p.has_bias && dx >= -o && dx <= o && dy >= -o && dy <= o)
+        v = p.table[(int64_t)((dx + o) * S + (dy + o)) * p.H + h] * inv;
       if (p.g.exact == 1 && (dx > W || dx < -W || dy > W || dy < -W)) v = VIL_MASK_VAL;
     }
   } else if (e < c.glo0) {
@@ -315,7 +317,7 @@ size_t vil_mfma_bwd_workspace(const VilAttnDesc* d);
 int vil_mfma_supported(const VilAttnDesc* d, int pass) {
   if (d->dtype != VIL_DTYPE_BF16) return VIL_E_DTYPE;
   if (d->M != 16 && d->M != 32 && d->M != 48 && d->M != 64) return VIL_E_HEAD_DIM;
-  if (d->W < 1 || d->W > 16) return VIL_E_WINDOW;
+  if (d->W < 1 || d->W > 32) return VIL_E_WINDOW;
   if (d->exact == -1 || d->only_glo) return VIL_E_BACKEND;   // cyclic padding / only-global: scalar family
   if (d->G > 16) return VIL_E_BACKEND;
   // 16-byte row loads: token/batch/head strides and M must keep rows 16-byte aligned

@@ -288,7 +288,9 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
     const int tbl = p.g.tbl;
     if (bin < tbl * c.P) {
       const int row = bin / c.P, col = bin % c.P - VIL_CPAD;
-      if (col >= 0 && col < tbl && p.dtable) p.dtable[(int64_t)(row * tbl + col) * p.H + h] = s;
+      const int dx = row - (2 * p.g.W - 1), dy = col - (2 * p.g.W - 1), o = p.bias_off;
+      if (col >= 0 && col < tbl && p.dtable && dx >= -o && dx <= o && dy >= -o && dy <= o)
+        p.dtable[(int64_t)((dx + o) * p.bias_S + (dy + o)) * p.H + h] = s;
     } else if (bin >= c.glo0 && p.dg2l) {
       const int gg = (bin - c.glo0) / c.gsz;
       if (gg < p.G) atomicAdd(&p.dg2l[h * p.G + gg], s);
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
   __syncthreads();
 
   char* wbase = smem + (size_t)c.tabsize * 4 + (size_t)wave * bc.kv_wave_lds;
-  int* s_tok = (int*)wbase;                       // [nqs] byte offset of each streamed query slot's Q/dO row
+  int* s_tok = (int*)wbase;                       // [nqs] token index of each streamed query slot (Q / dO row)
   int* s_aq = s_tok + bc.nqs;                     // [nqs] bias-table address term (bytes)
   float* s_lse = (float*)(s_aq + bc.nqs);         // [nqs] lse * log2(e)   (+big for padding slots)
   float* s_dlt = s_lse + bc.nqs;                  // [nqs] delta
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
   __bf16* dkb = (__bf16*)p.dk + b * p.dk_sb + h * p.dk_sh;
   __bf16* dvb = (__bf16*)p.dv + b * p.dv_sb + h * p.dv_sh;
   const int Nloc = g.nx * g.ny;
-  const int qstride_b = (int)p.q_st * 2;
+  const int qstride_b = (int)p.q_st * 2, dostride_b = (int)p.do_st * 2;
   const float c1 = p.scale * LOG2E;
   const int W = g.W, W2 = g.W2;
   const int nown = bc.nch * c.NWP;
@@ -408,13 +410,12 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
         const int qc0 = qn * W;
         const int nvalid = min(W, g.ny - qc0);
         int tok = qr * g.ny + qc0;
-        int off = __mul24(tok, qstride_b);
         int aq = glo ? 0 : ((xl - dr * W) * c.P - dc * W + c.aconst) * 4;
         int s = ci * W2 + xl * W;
         for (int yl = 0; yl < nvalid; ++yl) {
-          s_tok[s] = off; s_aq[s] = aq;
+          s_tok[s] = tok; s_aq[s] = aq;
           s_lse[s] = lse_bh[tok] * LOG2E; s_dlt[s] = dlt_bh[tok];
-          ++s; ++tok; off += qstride_b; aq += glo ? 0 : 4;
+          ++s; ++tok; aq += glo ? 0 : 4;
         }
       }
     }
@@ -464,9 +465,9 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
 #pragma unroll
       for (int it = 0; it < MD; ++it) {
         const int row = (it * 64 + lane) / VCH;
-        const int off = s_tok[st * 32 + row] + ld_off[it];
-        qr_[it] = __builtin_amdgcn_raw_buffer_load_b128(qrs, off, 0, 0);
-        dr_[it] = __builtin_amdgcn_raw_buffer_load_b128(drs, off, 0, 0);
+        const int tok = s_tok[st * 32 + row];          // Q and dO may have different row strides (fused qkv)
+        qr_[it] = __builtin_amdgcn_raw_buffer_load_b128(qrs, __mul24(tok, qstride_b) + ld_off[it], 0, 0);
+        dr_[it] = __builtin_amdgcn_raw_buffer_load_b128(drs, __mul24(tok, dostride_b) + ld_off[it], 0, 0);
       }
     };
     if (nsteps > 0) load_step(0);
@@ -656,8 +657,9 @@ static size_t kv_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.tabs
 
 int vil_mfma_bwd_supported(const VilAttnDesc* d) {
   if ((d->do_st | d->do_sb | d->do_sh) & 7) return VIL_E_ALIGN;
-  // Q and dO rows are addressed through one table of 32-bit byte offsets in the dK/dV pass
-  if (d->do_st != d->q_st || d->q_st >= (1 << 22) || d->q_st * 2 * (int64_t)d->nx * d->ny >= (1ll << 31)) return VIL_E_BACKEND;
+  // Q and dO rows are addressed with 32-bit byte offsets (24-bit token x stride) in the dK/dV pass
+  for (int64_t st : {d->q_st, d->do_st})
+    if (st >= (1 << 22) || st * 2 * (int64_t)d->nx * d->ny >= (1ll << 31)) return VIL_E_BACKEND;
   if ((d->dq_st | d->dq_sb | d->dq_sh | d->dk_st | d->dk_sb | d->dk_sh | d->dv_st | d->dv_sb | d->dv_sh) & 3) return VIL_E_ALIGN;
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   BwdCfg bc; bwd_cfg(d, c, bc);

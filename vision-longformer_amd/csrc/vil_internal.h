@@ -9,6 +9,7 @@ struct VilParams {
   VilGeom g;
   int B, H, M, G;
   int only_glo, has_bias, has_g2l;
+  int bias_S, bias_off;      // side of the caller's bias table and its centre offset (S-1)/2
   int parts;                 // backward: workgroups per (b,h) in the dQ pass
   int part_stride;           // floats per partial record
   float scale;
@@ -29,6 +30,8 @@ static inline void vil_fill_params(VilParams& p, const VilAttnDesc* d) {
   vil_geom_init(p.g, d->nx, d->ny, d->W, d->exact, d->mode);
   p.B = d->B; p.H = d->H; p.M = d->M; p.G = d->G; p.only_glo = d->only_glo;
   p.scale = d->scale;
+  p.bias_S = d->bias_side > 0 ? d->bias_side : 4 * d->W - 1;
+  p.bias_off = (p.bias_S - 1) / 2;
   p.q_sb = d->q_sb; p.q_st = d->q_st; p.q_sh = d->q_sh;
   p.k_sb = d->k_sb; p.k_st = d->k_st; p.k_sh = d->k_sh;
   p.v_sb = d->v_sb; p.v_st = d->v_st; p.v_sh = d->v_sh;
@@ -65,7 +68,7 @@ struct VilWork {
     VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
     nloc = (double)d->nx * d->ny; n = nloc + d->G; c = (double)d->H * d->M;
     e = d->dtype == VIL_DTYPE_BF16 ? 2 : 4; h = d->H; b = d->B;
-    k = d->only_glo ? d->G : (double)g.nact * g.W2 + d->G; tbl = (double)g.tbl * g.tbl;
+    k = d->only_glo ? d->G : (double)g.nact * g.W2 + d->G; tbl = d->bias_side > 0 ? (double)d->bias_side * d->bias_side : (double)g.tbl * g.tbl;
   }
   double fwd_bytes() const { return b * ((2 * nloc + 2 * n) * c * e + 4 * h * nloc + 4 * h * tbl); }
   double fwd_flops() const { return b * 4 * nloc * k * c; }

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .longformer2d import Long2DSCSelfAttention, _trunc_normal_
+from .ops import vil_dense_attention, FULL_MAX_G
 from .layernorm import VilLayerNorm
 from .linear import VilLinear
 
@@ -135,7 +136,21 @@ class Attention(nn.Module):
     def forward(self, x, nx=None, ny=None):
         B, N, C = x.shape
         H = self.num_heads
-        q, k, v = self.qkv(x).view(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
+        qkv = self.qkv(x)
+        M = C // H
+        nglo = self.nglo if self.rpe else (N - nx * ny if nx is not None else -1)
+        gx, gy = (self.wx, self.wy) if self.rpe else (nx, ny)
+        if (qkv.is_cuda and qkv.dtype == torch.bfloat16 and gx is not None and gx == gy and gx <= 32
+                and 0 <= nglo <= FULL_MAX_G and nglo + gx * gy == N and M in (16, 32, 48, 64)
+                and (self.attn_drop.p == 0.0 or not self.training)):
+            # the dense attention of the s0 stages is the one-chunk case of the fused
+            # sliding-chunk kernels (bias table gathered in-kernel, no (H,N,N) bias tensor, no SDPA mask)
+            out = vil_dense_attention(qkv, self.local_relative_position_bias_table if self.rpe else None,
+                                      self.g2l_relative_position_bias if (self.rpe and nglo > 0) else None,
+                                      self.g2g_relative_position_bias if (self.rpe and nglo > 0) else None,
+                                      nx=gx, ny=gy, nglo=nglo, num_heads=H, scale=self.scale)
+            return self.proj_drop(self.proj(out))
+        q, k, v = qkv.view(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
         mask = self._bias(N).unsqueeze(0).to(q.dtype) if self.rpe else None
         p = self.attn_drop.p if self.training else 0.0
         x = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=p, scale=self.scale)

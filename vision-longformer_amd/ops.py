@@ -49,7 +49,7 @@ def _make_desc(q, k, v, out, cfg, backend):
     d.only_glo = int(cfg["only_glo"])
     d.backend = _BACKENDS[backend]
     d.scale = float(cfg["scale"])
-    d.reserved = int(cfg.get("debug", 0))
+    d.bias_side = int(cfg.get("bias_side", 0))
     d.q_sb, d.q_st, d.q_sh = _strides(q, M)
     d.k_sb, d.k_st, d.k_sh = _strides(k, M)
     d.v_sb, d.v_st, d.v_sh = _strides(v, M)
@@ -148,6 +148,71 @@ def vil_local_attention(q, kv, bias_table, g2l_bias, *, nx, ny, w, nglo, num_hea
     return _VilLocalAttention.apply(q, kv, bias_table, g2l_bias, cfg, backend or DEFAULT_BACKEND)
 
 
+def _full_fwd(q_all, k, v, tab, g2l_f, g2g_f, cfg, backend):
+    """local rows + (G > 0) global rows; q_all/k/v are (B, N, C) views (last dim contiguous)."""
+    L = _lib.lib()
+    B, N, C = q_all.shape
+    G, H = cfg["G"], cfg["H"]
+    Nloc = N - G
+    out_all = torch.empty(B, N, C, dtype=q_all.dtype, device=q_all.device)
+    lse = torch.empty(B, H, Nloc, dtype=torch.float32, device=q_all.device)
+    lse_g = torch.empty(B, H, max(G, 1), dtype=torch.float32, device=q_all.device)
+    q_loc, out_loc = q_all[:, G:], out_all[:, G:]
+    d = _make_desc(q_loc, k, v, out_loc, cfg, backend)
+    ws = _workspace(d, 0, q_all.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(q_all.device).cuda_stream)
+    with torch.cuda.device(q_all.device):
+        _lib.check(L.vil_attn_fwd(ctypes.byref(d), _ptr(q_loc), _ptr(k), _ptr(v), _ptr(tab),
+                                  _ptr(g2l_f[1]) if g2l_f is not None else None,
+                                  _ptr(out_loc), _ptr(lse), _ptr(ws), stream))
+        if G > 0:
+            _lib.check(L.vil_glo_attn_fwd(ctypes.byref(d), _ptr(q_all), _ptr(k), _ptr(v), _ptr(g2g_f),
+                                          _ptr(g2l_f[0]) if g2l_f is not None else None,
+                                          _ptr(out_all), _ptr(lse_g), stream))
+    return out_all, lse, lse_g
+
+
+def _full_bwd(q_all, k, v, out_all, dout_all, lse, lse_g, tab, g2l_f, g2g_f, dq_all, dk, dv, cfg, backend):
+    L = _lib.lib()
+    B, N, C = q_all.shape
+    G, H = cfg["G"], cfg["H"]
+    M = C // H
+    dtab = torch.empty_like(tab) if tab is not None else None
+    dg2l = torch.zeros_like(g2l_f) if g2l_f is not None else None
+    dg2g = torch.zeros_like(g2g_f) if g2g_f is not None else None
+    q_loc, out_loc, do_loc, dq_loc = q_all[:, G:], out_all[:, G:], dout_all[:, G:], dq_all[:, G:]
+    d = _make_desc(q_loc, k, v, out_loc, cfg, backend)
+    d.do_sb, d.do_st, d.do_sh = _strides(do_loc, M)
+    d.dq_sb, d.dq_st, d.dq_sh = _strides(dq_loc, M)
+    d.dk_sb, d.dk_st, d.dk_sh = _strides(dk, M)
+    d.dv_sb, d.dv_st, d.dv_sh = _strides(dv, M)
+    ws = _workspace(d, 1, q_all.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(q_all.device).cuda_stream)
+    with torch.cuda.device(q_all.device):
+        _lib.check(L.vil_attn_bwd(ctypes.byref(d), _ptr(q_loc), _ptr(k), _ptr(v), _ptr(out_loc), _ptr(do_loc),
+                                  _ptr(lse), _ptr(tab), _ptr(g2l_f[1]) if g2l_f is not None else None,
+                                  _ptr(dq_loc), _ptr(dk), _ptr(dv), _ptr(dtab),
+                                  _ptr(dg2l[1]) if dg2l is not None else None, _ptr(ws), stream))
+        if G > 0:
+            _lib.check(L.vil_glo_attn_bwd(ctypes.byref(d), _ptr(q_all), _ptr(k), _ptr(v), _ptr(out_all), _ptr(dout_all),
+                                          _ptr(lse_g), _ptr(g2g_f), _ptr(g2l_f[0]) if g2l_f is not None else None,
+                                          _ptr(dq_all), _ptr(dk), _ptr(dv), _ptr(dg2g),
+                                          _ptr(dg2l[0]) if dg2l is not None else None, stream))
+    return dtab, dg2l, dg2g
+
+
+def _check_dev(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} needs device tensors: the product path is the HIP kernels "
+                           "(libvilattn.so); there is no CPU fallback")
+    if t.dtype not in _DT:
+        raise TypeError(f"{name} supports float32/bfloat16 tensors; got {t.dtype}")
+
+
+def _f32c(t):
+    return t.detach().float().contiguous() if t is not None else None
+
+
 class _VilFullAttention(torch.autograd.Function):
     """Local rows (vil_attn_fwd/_bwd) AND the G global-token query rows (vil_glo_attn_fwd/_bwd) of one
     Long2DSCSelfAttention layer on shared q / kv tensors: q_all (B, G+Nloc, C) -> out_all (B, G+Nloc, C).
@@ -155,83 +220,71 @@ class _VilFullAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q_all, kv, table, g2l, g2g, cfg, backend):
-        if not q_all.is_cuda:
-            raise RuntimeError("vil_full_attention needs device tensors: the product path is the HIP "
-                               "kernels (libvilattn.so); there is no CPU fallback")
-        if q_all.dtype not in _DT or kv.dtype != q_all.dtype:
-            raise TypeError(f"vil_full_attention supports float32/bfloat16 q,kv of one dtype; got {q_all.dtype}, {kv.dtype}")
-        L = _lib.lib()
-        q_all = q_all.contiguous()
-        kv = _last_contig(kv)
+        _check_dev(q_all, "vil_full_attention")
+        q_all, kv = _last_contig(q_all), _last_contig(kv)
         B, N, C = q_all.shape
-        G, H = cfg["G"], cfg["H"]
-        Nloc = N - G
-        assert kv.shape == (B, N, 2 * C) and Nloc == cfg["nx"] * cfg["ny"]
-        k, v = kv[..., :C], kv[..., C:]
-        out_all = torch.empty(B, N, C, dtype=q_all.dtype, device=q_all.device)
-        lse = torch.empty(B, H, Nloc, dtype=torch.float32, device=q_all.device)
-        lse_g = torch.empty(B, H, G, dtype=torch.float32, device=q_all.device)
-        tab = table.detach().float().contiguous() if table is not None else None
-        g2l_f = g2l.detach().float().contiguous() if g2l is not None else None       # (2, H, G)
-        g2g_f = g2g.detach().float().contiguous() if g2g is not None else None       # (H, G, G)
-        q_loc, out_loc = q_all[:, G:], out_all[:, G:]
-        d = _make_desc(q_loc, k, v, out_loc, cfg, backend)
-        ws = _workspace(d, 0, q_all.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(q_all.device).cuda_stream)
-        with torch.cuda.device(q_all.device):
-            _lib.check(L.vil_attn_fwd(ctypes.byref(d), _ptr(q_loc), _ptr(k), _ptr(v), _ptr(tab),
-                                      _ptr(g2l_f[1]) if g2l_f is not None else None,
-                                      _ptr(out_loc), _ptr(lse), _ptr(ws), stream))
-            _lib.check(L.vil_glo_attn_fwd(ctypes.byref(d), _ptr(q_all), _ptr(k), _ptr(v), _ptr(g2g_f),
-                                          _ptr(g2l_f[0]) if g2l_f is not None else None,
-                                          _ptr(out_all), _ptr(lse_g), stream))
+        assert kv.shape == (B, N, 2 * C) and kv.dtype == q_all.dtype and N - cfg["G"] == cfg["nx"] * cfg["ny"]
+        tab, g2l_f, g2g_f = _f32c(table), _f32c(g2l), _f32c(g2g)
+        out_all, lse, lse_g = _full_fwd(q_all, kv[..., :C], kv[..., C:], tab, g2l_f, g2g_f, cfg, backend)
         ctx.save_for_backward(q_all, kv, out_all, lse, lse_g, tab, g2l_f, g2g_f)
         ctx.cfg, ctx.backend = cfg, backend
-        ctx.dts = (table.dtype if table is not None else None, g2l.dtype if g2l is not None else None,
-                   g2g.dtype if g2g is not None else None)
+        ctx.dts = tuple(t.dtype if t is not None else None for t in (table, g2l, g2g))
         return out_all
 
     @staticmethod
     def backward(ctx, dout_all):
         q_all, kv, out_all, lse, lse_g, tab, g2l_f, g2g_f = ctx.saved_tensors
-        cfg = ctx.cfg
-        L = _lib.lib()
         B, N, C = q_all.shape
-        G, H = cfg["G"], cfg["H"]
-        M = C // H
-        dout_all = dout_all.contiguous()
-        if dout_all.dtype != q_all.dtype:
-            dout_all = dout_all.to(q_all.dtype)
-        k, v = kv[..., :C], kv[..., C:]
+        dout_all = _last_contig(dout_all).to(q_all.dtype)
         dq_all = torch.empty(B, N, C, dtype=q_all.dtype, device=q_all.device)
         dkv = torch.empty(B, N, 2 * C, dtype=q_all.dtype, device=q_all.device)
-        dk, dv = dkv[..., :C], dkv[..., C:]
-        dtab = torch.empty_like(tab) if tab is not None else None
-        dg2l = torch.zeros_like(g2l_f) if g2l_f is not None else None
-        dg2g = torch.zeros_like(g2g_f) if g2g_f is not None else None
-        q_loc, out_loc, do_loc, dq_loc = q_all[:, G:], out_all[:, G:], dout_all[:, G:], dq_all[:, G:]
-        d = _make_desc(q_loc, k, v, out_loc, cfg, ctx.backend)
-        d.do_sb, d.do_st, d.do_sh = _strides(do_loc, M)
-        d.dq_sb, d.dq_st, d.dq_sh = _strides(dq_loc, M)
-        d.dk_sb, d.dk_st, d.dk_sh = _strides(dk, M)
-        d.dv_sb, d.dv_st, d.dv_sh = _strides(dv, M)
-        ws = _workspace(d, 1, q_all.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(q_all.device).cuda_stream)
-        with torch.cuda.device(q_all.device):
-            _lib.check(L.vil_attn_bwd(ctypes.byref(d), _ptr(q_loc), _ptr(k), _ptr(v), _ptr(out_loc), _ptr(do_loc),
-                                      _ptr(lse), _ptr(tab), _ptr(g2l_f[1]) if g2l_f is not None else None,
-                                      _ptr(dq_loc), _ptr(dk), _ptr(dv), _ptr(dtab),
-                                      _ptr(dg2l[1]) if dg2l is not None else None, _ptr(ws), stream))
-            _lib.check(L.vil_glo_attn_bwd(ctypes.byref(d), _ptr(q_all), _ptr(k), _ptr(v), _ptr(out_all), _ptr(dout_all),
-                                          _ptr(lse_g), _ptr(g2g_f), _ptr(g2l_f[0]) if g2l_f is not None else None,
-                                          _ptr(dq_all), _ptr(dk), _ptr(dv), _ptr(dg2g),
-                                          _ptr(dg2l[0]) if dg2l is not None else None, stream))
+        dtab, dg2l, dg2g = _full_bwd(q_all, kv[..., :C], kv[..., C:], out_all, dout_all, lse, lse_g, tab, g2l_f, g2g_f,
+                                     dq_all, dkv[..., :C], dkv[..., C:], ctx.cfg, ctx.backend)
         tdt, ldt, gdt = ctx.dts
         return (dq_all, dkv, dtab.to(tdt) if dtab is not None else None,
                 dg2l.to(ldt) if dg2l is not None else None, dg2g.to(gdt) if dg2g is not None else None, None, None)
 
 
+class _VilQKVAttention(torch.autograd.Function):
+    """Same op on a packed (B, N, 3C) projection [q | k | v] (the dense `Attention` of the s0 stages,
+    reference msvit.py:91-120): the gradient comes back as ONE (B, N, 3C) tensor for the qkv GEMM."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, g2l, g2g, cfg, backend):
+        _check_dev(qkv, "vil_qkv_attention")
+        qkv = _last_contig(qkv)
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        assert N - cfg["G"] == cfg["nx"] * cfg["ny"]
+        tab, g2l_f, g2g_f = _f32c(table), _f32c(g2l), _f32c(g2g)
+        out_all, lse, lse_g = _full_fwd(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], tab, g2l_f, g2g_f, cfg, backend)
+        ctx.save_for_backward(qkv, out_all, lse, lse_g, tab, g2l_f, g2g_f)
+        ctx.cfg, ctx.backend = cfg, backend
+        ctx.dts = tuple(t.dtype if t is not None else None for t in (table, g2l, g2g))
+        return out_all
+
+    @staticmethod
+    def backward(ctx, dout_all):
+        qkv, out_all, lse, lse_g, tab, g2l_f, g2g_f = ctx.saved_tensors
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        dout_all = _last_contig(dout_all).to(qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        dtab, dg2l, dg2g = _full_bwd(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], out_all, dout_all, lse, lse_g,
+                                     tab, g2l_f, g2g_f, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:],
+                                     ctx.cfg, ctx.backend)
+        tdt, ldt, gdt = ctx.dts
+        return (dqkv, dtab.to(tdt) if dtab is not None else None, dg2l.to(ldt) if dg2l is not None else None,
+                dg2g.to(gdt) if dg2g is not None else None, None, None)
+
+
 FULL_MAX_G = 4      # vil_glo_attn_* bookkeeping limit
+
+
+def _cfg(q_last_dim, nx, ny, w, nglo, num_heads, mode, exact, scale, bias_side=0):
+    return dict(nx=int(nx), ny=int(ny), W=int(w), G=int(nglo), H=int(num_heads), mode=int(mode), exact=int(exact),
+                only_glo=False, scale=float(scale) if scale is not None else (q_last_dim // num_heads) ** -0.5,
+                debug=0, bias_side=int(bias_side))
 
 
 def vil_full_attention(q_all, kv, bias_table, g2l_bias, g2g_bias, *, nx, ny, w, nglo, num_heads, mode=0, exact=0,
@@ -241,7 +294,21 @@ def vil_full_attention(q_all, kv, bias_table, g2l_bias, g2g_bias, *, nx, ny, w, 
     if exact not in (0, 1, -1) or (exact == 1 and mode != 0):
         raise ValueError("longsc exact should be in [0,1,-1]!")
     assert 1 <= nglo <= FULL_MAX_G
-    C = q_all.shape[-1]
-    cfg = dict(nx=int(nx), ny=int(ny), W=int(w), G=int(nglo), H=int(num_heads), mode=int(mode), exact=int(exact),
-               only_glo=False, scale=float(scale) if scale is not None else (C // num_heads) ** -0.5, debug=0)
+    cfg = _cfg(q_all.shape[-1], nx, ny, w, nglo, num_heads, mode, exact, scale)
     return _VilFullAttention.apply(q_all, kv, bias_table, g2l_bias, g2g_bias, cfg, backend or DEFAULT_BACKEND)
+
+
+def vil_dense_attention(qkv, bias_table, g2l_bias, g2g_bias, *, nx, ny, nglo, num_heads, scale=None, backend=None):
+    """Dense attention over an (nglo + nx*ny)-token sequence with the Swin-style relative position bias
+    of the `s0` stages (reference msvit.py:37-120), expressed as the ONE-CHUNK case of the sliding-chunk
+    kernels: chunk side w = max(nx, ny), mode -1 (own chunk only), bias table side 2w-1.
+    qkv: (B, N, 3C) packed projection; bias_table ((2w-1)^2, H) or None.  Returns (B, N, C)."""
+    w = max(int(nx), int(ny))
+    assert 0 <= nglo <= FULL_MAX_G
+    side = 2 * w - 1 if bias_table is not None else 0
+    if bias_table is not None:
+        assert bias_table.shape[0] == side * side, "dense bias table must be ((2w-1)^2, H) with w = max(nx, ny)"
+    cfg = _cfg(qkv.shape[-1] // 3, nx, ny, w, nglo, num_heads, -1, 0, scale, bias_side=side)
+    if nglo == 0:
+        g2l_bias = g2g_bias = None
+    return _VilQKVAttention.apply(qkv, bias_table, g2l_bias, g2g_bias, cfg, backend or DEFAULT_BACKEND)
