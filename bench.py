@@ -141,7 +141,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    cap = max(64, args.steps * 64)
+    cap = max(1024, args.steps * 512)
     if not use_graph:                  # (a replayed graph makes no library calls: its kernels are profiled below)
         _lib.profile_begin(cap)
     t0 = time.perf_counter()

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from vision_longformer_amd import _lib
-from vision_longformer_amd.ops import vil_local_attention
+from vision_longformer_amd.ops import vil_local_attention, vil_dense_attention
 
 SHAPES = {  # H, M, W, nx, ny, G, mode, B
     "small_s1": (3, 32, 7, 56, 56, 1, 0, 128),
@@ -21,6 +21,11 @@ SHAPES = {  # H, M, W, nx, ny, G, mode, B
     "meddeep_s2_f12": (3, 64, 12, 48, 48, 1, 0, 32),
     "basedeep_s1_f6_rs": (3, 32, 6, 96, 96, 1, 3, 32),
     "basedeep_s2_f8_rs": (3, 64, 8, 48, 48, 1, 5, 32),
+    # dense s0 stages (one chunk = the whole grid, mode -1, (2W-1)^2 table): vil_dense_attention on fused qkv
+    "small_s3_dense": (6, 64, 14, 14, 14, 1, -1, 128),
+    "small_s4_dense": (12, 64, 7, 7, 7, 1, -1, 128),
+    "meddeep_s3_dense": (6, 64, 24, 24, 24, 1, -1, 32),
+    "meddeep_s4_dense": (12, 64, 12, 12, 12, 1, -1, 32),
 }
 
 def main():
@@ -42,8 +47,19 @@ def main():
     g2l = (torch.randn(H, G, generator=g) * 0.02).to(dev).requires_grad_(not a.fwd_only)
     dout = torch.randn(B, nx * ny, C, generator=g).to(dev, torch.bfloat16)
     kw = dict(nx=nx, ny=ny, w=W, nglo=G, num_heads=H, mode=mode, backend=a.backend)
+    dense = a.shape.endswith("_dense")
+    if dense:
+        rg = not a.fwd_only
+        qkv = torch.randn(B, G + nx * ny, 3 * C, generator=g).to(dev, torch.bfloat16).requires_grad_(rg)
+        table = (torch.randn((2 * W - 1) ** 2, H, generator=g) * 0.02).to(dev).requires_grad_(rg)
+        g2l2 = (torch.randn(2, H, G, generator=g) * 0.02).to(dev).requires_grad_(rg)
+        g2g = (torch.randn(H, G, G, generator=g) * 0.02).to(dev).requires_grad_(rg)
+        dout = torch.randn(B, G + nx * ny, C, generator=g).to(dev, torch.bfloat16)
     def step():
-        out = vil_local_attention(q, kv, table, g2l, **kw)
+        if dense:
+            out = vil_dense_attention(qkv, table, g2l2, g2g, nx=nx, ny=ny, nglo=G, num_heads=H, scale=M ** -0.5)
+        else:
+            out = vil_local_attention(q, kv, table, g2l, **kw)
         if not a.fwd_only:
             out.backward(dout)
     for _ in range(3):

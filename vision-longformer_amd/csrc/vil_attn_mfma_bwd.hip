@@ -22,6 +22,7 @@
 
 #define LSE_PAD 1.0e30f
 
+#define VIL_NORM_SLOTS 64
 struct BwdCfg {
   int nch;            // query/key chunks per (image, head) = mx*my
   int nsplit;         // global-key owner units per (image, head)
@@ -34,7 +35,8 @@ struct BwdCfg {
   float* glo_parts;   // (B*H, nsplit, G, 2, M)
   int dq_nwg;
   int hist_nmax;      // upper bound of contributions one histogram bin can receive in one workgroup
-  unsigned* norm2;    // [2]: max ||dO_q||^2, max ||v_k||^2 as float bits (written by k_mfma_delta)
+  unsigned* norm2;    // VIL_NORM_SLOTS x 32 words; slot k: [0] max ||dO_q||^2, [1] max ||v_k||^2 as float bits
+                      // (partial maxima written by k_mfma_delta); word 2 of slot 0: the histogram scale lfx
 };
 
 // ===================================================================== dQ pass
@@ -70,7 +72,12 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
   // lse (free) and taken out again in the dQ epilogue and the histogram reduce.
   int lfx = 0;
   if (bc.do_hist) {
-    const float bound = 2.0f * __builtin_sqrtf(__uint_as_float(bc.norm2[0]) * __uint_as_float(bc.norm2[1]));
+    // maxima over the slots (every lane one slot, butterfly over the wave)
+    float n0 = __uint_as_float(bc.norm2[32 * (tid & (VIL_NORM_SLOTS - 1))]);
+    float n1 = __uint_as_float(bc.norm2[32 * (tid & (VIL_NORM_SLOTS - 1)) + 1]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { n0 = fmaxf(n0, __shfl_xor(n0, o, 64)); n1 = fmaxf(n1, __shfl_xor(n1, o, 64)); }
+    const float bound = 2.0f * __builtin_sqrtf(n0 * n1);
     if (bound > 0.f && bound < 1e30f) {
       lfx = 29 - (int)ceilf(__log2f(bound * (float)bc.hist_nmax));
       lfx = max(-60, min(60, lfx));
@@ -264,9 +271,9 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
 }
 
 // d(table)[idx*H+h] and d(g2l)[h*G+g] from the per-workgroup histograms.
-// grid (ceil(tabsize/64), H), block 256 = 64 bins x 4 partial groups.
+// grid (ceil(tabsize/64), H), block 1024 = 64 bins x 16 partial groups (4 independent loads in flight each).
 __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
-  __shared__ long long red[4][64];
+  __shared__ long long red[16][64];
   const int h = blockIdx.y;
   const int bin = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
   long long si = 0;
@@ -274,26 +281,48 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
     // workgroups of head h: logical = (b*H + h)*wg_per_bh + w
     const int per = c.wg_per_bh;
     const int* parts = (const int*)bc.hist_parts;
-    for (int i = grp; i < p.B * per; i += 4) {
+    const int n = p.B * per;
+    int i = grp;
+    for (; i + 48 < n; i += 64) {
+      int v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = i + 16 * u, b = j / per, w = j % per;
+        v[u] = parts[((int64_t)(b * p.H + h) * per + w) * c.tabsize + bin];
+      }
+      si += (long long)v[0] + v[1] + v[2] + v[3];
+    }
+    for (; i < n; i += 16) {
       const int b = i / per, w = i % per;
       si += parts[((int64_t)(b * p.H + h) * per + w) * c.tabsize + bin];
     }
   }
   red[grp][threadIdx.x & 63] = si;
   __syncthreads();
-  if (grp == 0 && bin < c.tabsize) {
-    si = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (grp == 0) {            // one whole wave: the 64 bins of this block
+    si = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) si += red[u][threadIdx.x];
     const int lfx = ((const int*)bc.norm2)[2];
-    const float s = (float)((double)si * exp2((double)-lfx));
+    const float s = (float)si * __builtin_amdgcn_ldexpf(1.0f, -lfx) ;
     const int tbl = p.g.tbl;
+    int gg = -1;
     if (bin < tbl * c.P) {
       const int row = bin / c.P, col = bin % c.P - VIL_CPAD;
       const int dx = row - (2 * p.g.W - 1), dy = col - (2 * p.g.W - 1), o = p.bias_off;
       if (col >= 0 && col < tbl && p.dtable && dx >= -o && dx <= o && dy >= -o && dy <= o)
         p.dtable[(int64_t)((dx + o) * p.bias_S + (dy + o)) * p.H + h] = s;
-    } else if (bin >= c.glo0 && p.dg2l) {
-      const int gg = (bin - c.glo0) / c.gsz;
-      if (gg < p.G) atomicAdd(&p.dg2l[h * p.G + gg], s);
+    } else if (bin >= c.glo0 && bin < c.tabsize && p.dg2l) {
+      gg = (bin - c.glo0) / c.gsz;
+    }
+    // every bin of global token g's constant region adds into ONE word: reduce over the wave first
+    // (a thousand same-address atomics per head cost ~80 us)
+    for (int g_ = 0; g_ < p.G; ++g_) {
+      if (!__any(gg == g_)) continue;
+      float v = gg == g_ ? s : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (threadIdx.x == 0 && v != 0.f) atomicAdd(&p.dg2l[h * p.G + g_], v);
     }
   }
 }
@@ -584,22 +613,30 @@ __global__ void k_mfma_reduce_glo(VilParams p, BwdCfg bc) {
   *((vil_bf16*)p.dv + b * p.dv_sb + (int64_t)gk * p.dv_st + h * p.dv_sh + d) = vil_f2bf(sv);
 }
 
-// rowsum(dO * O): one thread per (image, head, token)
+// rowsum(dO * O): LPR lanes per (image, head, token) row, each lane one (or three) 16-byte pieces of the
+// row, so a wave reads whole 64..128-byte row segments (one thread per row left 7/8 of every line fetched
+// by a load instruction to the other lanes' later loads)
 // also: max_q |dO_q|^2 and max_k |v_k|^2 (float bits, atomicMax) for the histogram's fixed-point scale
 template <int MD>
 __global__ void k_mfma_delta(VilParams p, unsigned* norm2) {
   constexpr int M = 16 * MD;
+  constexpr int LPR = MD == 4 ? 8 : (MD == 2 ? 4 : 2);
+  constexpr int NL = M / (8 * LPR);
   const int Nloc = p.g.nx * p.g.ny;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  float n_do = 0.f, n_v = 0.f;
-  if (i < (int64_t)p.B * p.H * Nloc) {
-    const int tok = i % Nloc; const int bh = i / Nloc; const int b = bh / p.H, h = bh % p.H;
+  // grid (ceil(Nloc*LPR/256), B*H): no per-thread division by a run-time value
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tok = t / LPR, sub = t % LPR;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const bool live = tok < Nloc;
+  const int64_t i = (int64_t)bh * Nloc + tok;
+  float n_do = 0.f, n_v = 0.f, s = 0.f, n_vg = 0.f;
+  if (live) {
     const __bf16* op = (const __bf16*)p.out + b * p.o_sb + (int64_t)tok * p.o_st + h * p.o_sh;
     const __bf16* dp = (const __bf16*)p.dout + b * p.do_sb + (int64_t)tok * p.do_st + h * p.do_sh;
     const __bf16* vp = (const __bf16*)p.v + b * p.v_sb + (int64_t)(p.G + tok) * p.v_st + h * p.v_sh;
-    float s = 0.f;
 #pragma unroll
-    for (int d0 = 0; d0 < M; d0 += 8) {
+    for (int l = 0; l < NL; ++l) {
+      const int d0 = (sub * NL + l) * 8;
       const bf16x8 a = *(const bf16x8*)(op + d0), c = *(const bf16x8*)(dp + d0), v = *(const bf16x8*)(vp + d0);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -608,25 +645,37 @@ __global__ void k_mfma_delta(VilParams p, unsigned* norm2) {
         n_v = __builtin_fmaf((float)v[e], (float)v[e], n_v);
       }
     }
-    p.delta[i] = s;
-    if (tok < p.G) {        // the G global rows of v
+    if (tok < p.G && sub == 0) {        // the G global rows of v
       const __bf16* vg = (const __bf16*)p.v + b * p.v_sb + (int64_t)tok * p.v_st + h * p.v_sh;
-      float t = 0.f;
-      for (int d = 0; d < M; ++d) t = __builtin_fmaf((float)vg[d], (float)vg[d], t);
-      n_v = fmaxf(n_v, t);
+      for (int d = 0; d < M; ++d) n_vg = __builtin_fmaf((float)vg[d], (float)vg[d], n_vg);
     }
   }
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) {
+    s += __shfl_xor(s, o, 64);
+    n_do += __shfl_xor(n_do, o, 64);
+    n_v += __shfl_xor(n_v, o, 64);
+  }
+  n_v = fmaxf(n_v, n_vg);
+  if (live && sub == 0) p.delta[i] = s;
   if (norm2) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       n_do = fmaxf(n_do, __shfl_xor(n_do, o, 64));
       n_v = fmaxf(n_v, __shfl_xor(n_v, o, 64));
     }
-    // one atomic per wave at most, and only when it would raise the current maximum
-    if ((threadIdx.x & 63) == 0) {
-      const unsigned a = __float_as_uint(n_do), b2 = __float_as_uint(n_v);
-      if (a > __hip_atomic_load(&norm2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&norm2[0], a);
-      if (b2 > __hip_atomic_load(&norm2[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&norm2[1], b2);
+    // block maximum through LDS, then ONE atomic pair per block into one of VIL_NORM_SLOTS slots 128 bytes
+    // apart (same-address atomics serialise at ~10 ns each: one slot for every wave cost 0.17 ms)
+    __shared__ float s_n[2][4];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_n[0][wv] = n_do; s_n[1][wv] = n_v; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned a = __float_as_uint(fmaxf(fmaxf(s_n[0][0], s_n[0][1]), fmaxf(s_n[0][2], s_n[0][3])));
+      const unsigned b2 = __float_as_uint(fmaxf(fmaxf(s_n[1][0], s_n[1][1]), fmaxf(s_n[1][2], s_n[1][3])));
+      unsigned* slot = norm2 + 32 * ((blockIdx.x + blockIdx.y * 7) % VIL_NORM_SLOTS);
+      if (a > __hip_atomic_load(&slot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&slot[0], a);
+      if (b2 > __hip_atomic_load(&slot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&slot[1], b2);
     }
   }
 }
@@ -638,7 +687,9 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   bc.nch = g.mx * g.my;
   bc.nsplit = d->G > 0 ? (bc.nch + 8) / 9 : 0;
   bc.units_kv_bh = bc.nch * c.NWP + bc.nsplit;
-  bc.nqs = (9 * g.W2 + 31) & ~31;
+  // streamed query slots: an own-key unit sees <= nact query chunks, a global-key unit its share of all chunks
+  const int qch = d->G > 0 ? (bc.nch + bc.nsplit - 1) / bc.nsplit : 0;
+  bc.nqs = ((qch > g.nact ? qch : g.nact) * g.W2 + 31) & ~31;
   bc.kv_wave_lds = ((bc.nqs * 16 + 2 * 32 * d->M * 2 + 15) / 16) * 16;
   bc.kv_wpw = 4;
   while (bc.kv_wpw > 1 && (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
@@ -671,7 +722,7 @@ int vil_mfma_bwd_supported(const VilAttnDesc* d) {
 static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& bc, size_t off[5]) {
   const size_t rows = (size_t)d->B * d->H * d->nx * d->ny;
   off[0] = 0;
-  off[1] = ((rows + 3) & ~(size_t)3) + 4;      // + 4 words: norm maxima and the histogram scale
+  off[1] = ((rows + 3) & ~(size_t)3) + 32 * VIL_NORM_SLOTS;      // + norm-maxima slots and the histogram scale
   off[2] = off[1] + (size_t)d->H * c.tabsize;
   off[3] = off[2] + (size_t)bc.dq_nwg * c.tabsize;
   off[4] = off[3] + (size_t)d->B * d->H * bc.nsplit * d->G * 2 * d->M;
@@ -698,7 +749,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   bc.hist_parts = ws + off[2];
   bc.glo_parts = ws + off[3];
   bc.do_hist = (p.dtable != nullptr) || (p.dg2l != nullptr);
-  bc.norm2 = (unsigned*)(ws + off[1] - 4);
+  bc.norm2 = (unsigned*)(ws + off[1] - 32 * VIL_NORM_SLOTS);
   bc.hist_nmax = p.g.W2 * c.gpw * c.wpw;
   const VilWork w(d);
   const int64_t rows = (int64_t)p.B * p.H * p.g.nx * p.g.ny;
@@ -715,10 +766,10 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   k_mfma_table<<<dim3((c.tabsize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
-  e = (int)hipMemsetAsync(bc.norm2, 0, 16, s);
+  e = (int)hipMemsetAsync(bc.norm2, 0, 4 * 32 * VIL_NORM_SLOTS, s);
   if (e) return e;
   vil_prof_begin(VIL_K_DELTA, s, w.delta_bytes(), 0);
-  BWD_SWITCH((k_mfma_delta<MD_><<<dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s>>>(
+  BWD_SWITCH((k_mfma_delta<MD_><<<dim3((unsigned)((p.g.nx * p.g.ny * (MD_ == 4 ? 8 : (MD_ == 2 ? 4 : 2)) + 255) / 256), p.B * p.H), dim3(256), 0, s>>>(
       p, bc.do_hist ? bc.norm2 : nullptr)));
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
@@ -763,7 +814,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   }
   if (bc.do_hist) {
     vil_prof_begin(VIL_K_REDUCE_BIAS, s, 0, 0);
-    k_mfma_reduce_hist<<<dim3((unsigned)((c.tabsize + 63) / 64), p.H), dim3(256), 0, s>>>(p, c, bc);
+    k_mfma_reduce_hist<<<dim3((unsigned)((c.tabsize + 63) / 64), p.H), dim3(1024), 0, s>>>(p, c, bc);
     vil_prof_end(s);
   }
   return (int)hipGetLastError();
