@@ -127,6 +127,20 @@ int vil_glo_attn_bwd(const VilAttnDesc* d, const void* q_g, const void* k, const
                      const float* g2g, const float* g2l0, void* dq_g, void* dk, void* dv,
                      float* dg2g, float* dg2l0, void* stream);
 
+/* ---- whole-layer backward: local rows AND the G global-token query rows in ONE call (MFMA family;
+ * VIL_E_BACKEND otherwise -- call vil_attn_bwd + vil_glo_attn_bwd instead).  q_all / out_all /
+ * dout_all / dq_all point at TOKEN 0 (the global rows) of (B, G+Nloc, H*M) views with the descriptor's
+ * strides; g2l / dg2l are the reference's (2,H,G) g2l_relative_position_bias ([0]: global query ->
+ * local keys, [1]: local query -> global keys), g2g / dg2g (H,G,G).  The global rows' backward
+ * (autograd of longformer2d.py:210-227) is computed inside the dK/dV pass from the K / V fragments it
+ * already holds, so dk / dv are written once.  dg2l and dg2g must be zero on entry.  Workspace:
+ * vil_attn_workspace_bytes(d, 1).  1 <= G <= 4. */
+int vil_attn_bwd_full(const VilAttnDesc* d, const void* q_all, const void* k, const void* v,
+                      const void* out_all, const void* dout_all, const float* lse, const float* lse_g,
+                      const float* bias_table, const float* g2l, const float* g2g,
+                      void* dq_all, void* dk, void* dv, float* dbias_table, float* dg2l, float* dg2g,
+                      void* workspace, void* stream);
+
 /* ---- block glue: fused LayerNorm around the attention / MLP blocks
  * (`x + drop_path(attn(norm(x), nx, ny))`, reference src/models/msvit.py:313-316,336-340).
  * x: (rows, C) fp32 or bf16 with a row stride (elements); y is written in y_dtype (bf16 feeds the

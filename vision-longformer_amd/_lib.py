@@ -22,7 +22,7 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_attn_fwd", "vil_attn_bwd", "vil_geom_mask", "vil_geom_bias_index",
            "vil_attn_profile_begin", "vil_attn_profile_end", "vil_attn_kernel_name",
            "vil_layernorm_workspace_bytes", "vil_layernorm_fwd", "vil_layernorm_bwd",
-           "vil_glo_attn_fwd", "vil_glo_attn_bwd")
+           "vil_glo_attn_fwd", "vil_glo_attn_bwd", "vil_attn_bwd_full")
 
 
 class VilAttnDesc(ctypes.Structure):
@@ -31,6 +31,9 @@ class VilAttnDesc(ctypes.Structure):
                 [("scale", ctypes.c_float), ("bias_side", ctypes.c_int32)] +
                 [(t + s, ctypes.c_int64) for t in ("q", "k", "v", "o", "do", "dq", "dk", "dv")
                  for s in ("_sb", "_st", "_sh")])
+
+
+VIL_E_BACKEND = -10
 
 
 class VilAttnError(RuntimeError):
@@ -78,6 +81,8 @@ def lib():
         L.vil_glo_attn_fwd.argtypes = [dp] + [vp] * 8
         L.vil_glo_attn_bwd.restype = ctypes.c_int
         L.vil_glo_attn_bwd.argtypes = [dp] + [vp] * 14
+        L.vil_attn_bwd_full.restype = ctypes.c_int
+        L.vil_attn_bwd_full.argtypes = [dp] + [vp] * 18
         L.vil_layernorm_workspace_bytes.restype = ctypes.c_size_t
         L.vil_layernorm_workspace_bytes.argtypes = [i64, ctypes.c_int]
         L.vil_layernorm_fwd.restype = ctypes.c_int

@@ -111,6 +111,36 @@ extern "C" int vil_attn_bwd(const VilAttnDesc* d, const void* q, const void* k, 
                                 : vil_scalar_bwd(d, p, (hipStream_t)stream);
 }
 
+extern "C" int vil_attn_bwd_full(const VilAttnDesc* d, const void* q_all, const void* k, const void* v,
+                                 const void* out_all, const void* dout_all, const float* lse, const float* lse_g,
+                                 const float* bias_table, const float* g2l, const float* g2g,
+                                 void* dq_all, void* dk, void* dv, float* dbias_table, float* dg2l, float* dg2g,
+                                 void* workspace, void* stream) {
+  int e = check_common(d);
+  if (e) return e;
+  if (!q_all || !k || !v || !out_all || !dout_all || !lse || !lse_g || !dq_all || !dk || !dv) return VIL_E_NULL;
+  if (bias_table && !dbias_table) return VIL_E_NULL;
+  if ((g2l && !dg2l) || (g2g && !dg2g)) return VIL_E_NULL;
+  if (d->G < 1 || d->G > 4 || d->only_glo) return VIL_E_BACKEND;
+  if (d->backend == VIL_BACKEND_SCALAR || vil_mfma_supported(d, 1) != VIL_OK) return VIL_E_BACKEND;
+  if (!workspace) return VIL_E_WORKSPACE;
+  const int64_t es = 2;                                   // the MFMA family is bf16
+  VilParams p; memset(&p, 0, sizeof(p));
+  vil_fill_params(p, d);
+  const int64_t HG = (int64_t)d->H * d->G;
+  p.q = (const char*)q_all + d->G * d->q_st * es; p.out = (const char*)out_all + d->G * d->o_st * es;
+  p.dout = (const char*)dout_all + d->G * d->do_st * es; p.dq = (char*)dq_all + d->G * d->dq_st * es;
+  p.k = k; p.v = v; p.lse = (float*)lse;
+  p.table = bias_table; p.g2l = g2l ? g2l + HG : nullptr;
+  p.has_bias = bias_table != nullptr; p.has_g2l = g2l != nullptr;
+  p.dk = dk; p.dv = dv; p.dtable = dbias_table; p.dg2l = dg2l ? dg2l + HG : nullptr;
+  p.glo_rows = 1;
+  p.q_g = q_all; p.o_g = out_all; p.do_g = dout_all; p.dq_g = dq_all;
+  p.lse_g = lse_g; p.g2l0 = g2l; p.g2g = g2g; p.dg2l0 = dg2l; p.dg2g = dg2g;
+  p.delta = (float*)workspace;
+  return vil_mfma_bwd(d, p, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------ host geometry helpers
 extern "C" int vil_geom_mask(int nx, int ny, int W, int exact, int mode, uint8_t* mask) {
   if (!mask) return VIL_E_NULL;

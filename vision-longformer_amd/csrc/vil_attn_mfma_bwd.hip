@@ -33,6 +33,7 @@ struct BwdCfg {
   int do_hist;
   float* hist_parts;  // (dq workgroups, tabsize) int32
   float* glo_parts;   // (B*H, nsplit, G, 2, M)
+  float* gq_parts;    // (B*H, nch*NWP + 1, G, M + 4): per-unit partial dq of the global QUERY rows, [M] = sum of dS
   int dq_nwg;
   int hist_nmax;      // upper bound of contributions one histogram bin can receive in one workgroup
   unsigned* norm2;    // VIL_NORM_SLOTS x 32 words; slot k: [0] max ||dO_q||^2, [1] max ||v_k||^2 as float bits
@@ -329,7 +330,7 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
 
 // ===================================================================== dK/dV pass
 template <int MD>
-__global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
+__global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;
   constexpr int VCH = 2 * MD;
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
   float* s_dlt = s_lse + bc.nqs;                  // [nqs] delta
   char* s_q = (char*)(s_dlt + bc.nqs);            // [32][M] bf16 Q tile
   char* s_do = s_q + 32 * M * 2;                  // [32][M] bf16 dO tile
+  char* s_gq = s_do + 32 * M * 2;                 // [G][3][M] bf16: q, dO, out rows of the global queries
 
   const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const __bf16*)p.q + b * p.q_sb + h * p.q_sh);
   const __amdgpu_buffer_rsrc_t drs = make_rsrc((const __bf16*)p.dout + b * p.do_sb + h * p.do_sh);
@@ -404,6 +406,15 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
     // ---- streamed query slot table: defaults (padding), then one neighbourhood row per lane
     for (int s = lane; s < bc.nqs; s += 64) {
       s_tok[s] = 0; s_aq[s] = glo ? 0 : c.aconst * 4; s_lse[s] = LSE_PAD; s_dlt[s] = 0.f;
+    }
+    if (p.glo_rows) {       // staged now so that the unit's tail does not wait on HBM with one wave per SIMD
+      for (int i = lane; i < p.G * 3 * (M / 8); i += 64) {
+        const int c8 = i % (M / 8), wh = (i / (M / 8)) % 3, gq = i / (3 * (M / 8));
+        const __bf16* src = wh == 0 ? (const __bf16*)p.q_g + b * p.q_sb + (int64_t)gq * p.q_st + h * p.q_sh
+                          : wh == 1 ? (const __bf16*)p.do_g + b * p.do_sb + (int64_t)gq * p.do_st + h * p.do_sh
+                                    : (const __bf16*)p.o_g + b * p.o_sb + (int64_t)gq * p.o_st + h * p.o_sh;
+        *(bf16x8*)(s_gq + i * 16) = *(const bf16x8*)(src + c8 * 8);
+      }
     }
     wave_lds_fence();
     int nchunks;
@@ -566,6 +577,106 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
       wave_lds_fence();
     }
 
+    // ---- global-token QUERY rows (vil_attn_bwd_full): G extra queries that attend every key.  The unit's
+    // K / V fragments are still in registers: scores by VALU dot products (G is 1..4, no MFMA tile to
+    // fill), dK/dV added straight into the accumulators, the unit's share of dq_g / d(bias) to a partial
+    // record.  Replaces a separate pass that re-read k, v, dk, dv and rewrote dk, dv.
+    if (p.glo_rows && (!glo || split == 0)) {
+      float* rec = bc.gq_parts + ((int64_t)bh * (nown + 1) + (glo ? nown : unit)) * p.G * (M + 4);
+      for (int gq = 0; gq < p.G; ++gq) {
+        const __bf16* qg = (const __bf16*)(s_gq + gq * 3 * M * 2);
+        const __bf16* dg = qg + M;
+        const __bf16* og = dg + M;
+        bf16x8 qf[MK], df[MK];
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < MK; ++ks) {
+          const int d0 = ks * 32 + lg * 8;
+          bf16x8 z = {};
+          qf[ks] = z; df[ks] = z;
+          if (d0 < M) {
+            qf[ks] = *(const bf16x8*)(qg + d0); df[ks] = *(const bf16x8*)(dg + d0);
+            const bf16x8 of = *(const bf16x8*)(og + d0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl = __builtin_fmaf((float)df[ks][e], (float)of[e], dl);
+          }
+        }
+        dl += __shfl_xor(dl, 16, 64); dl += __shfl_xor(dl, 32, 64);
+        const float lg2 = p.lse_g[(int64_t)bh * p.G + gq] * LOG2E;
+        float bias = 0.f;
+        if (glo) { if (p.g2g) bias = p.g2g[((int64_t)h * p.G + gq) * p.G + min(lj, p.G - 1)]; }
+        else if (p.g2l0) bias = p.g2l0[h * p.G + gq];
+        bias *= LOG2E;
+        // (staged so that few values are live at once: this kernel has no registers to spare)
+        float pr[4], ds[4], bsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          float sc = 0.f, dp = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < MK; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              sc = __builtin_fmaf((float)qf[ks][e], (float)kfb[ks][kt][e], sc);
+              dp = __builtin_fmaf((float)df[ks][e], (float)vfb[ks][kt][e], dp);
+            }
+          sc += __shfl_xor(sc, 16, 64); sc += __shfl_xor(sc, 32, 64);
+          dp += __shfl_xor(dp, 16, 64); dp += __shfl_xor(dp, 32, 64);
+          pr[kt] = kreal[kt] ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc, c1, bias - lg2)) : 0.f;
+          ds[kt] = pr[kt] * (dp - dl);
+          if (!glo) bsum += ds[kt];
+        }
+        if (glo && kreal[0] && lg == 0 && p.dg2g) atomicAdd(&p.dg2g[((int64_t)h * p.G + gq) * p.G + lj], ds[0]);
+        float dqp[MK][8];
+#pragma unroll
+        for (int ks = 0; ks < MK; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) t = __builtin_fmaf(ds[kt], (float)kfb[ks][kt][e], t);
+            dqp[ks][e] = t;
+          }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+          for (int ks = 0; ks < MK; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dqp[ks][e] += __shfl_xor(dqp[ks][e], o, 64);
+          bsum += __shfl_xor(bsum, o, 64);
+        }
+        if (lj == 0) {
+#pragma unroll
+          for (int ks = 0; ks < MK; ++ks) {
+            const int d0 = ks * 32 + lg * 8;
+            if (d0 < M) {
+              *(f32x4*)(rec + gq * (M + 4) + d0) = (f32x4){dqp[ks][0], dqp[ks][1], dqp[ks][2], dqp[ks][3]};
+              *(f32x4*)(rec + gq * (M + 4) + d0 + 4) = (f32x4){dqp[ks][4], dqp[ks][5], dqp[ks][6], dqp[ks][7]};
+            }
+          }
+          if (lg == 0) rec[gq * (M + 4) + M] = bsum;
+        }
+        // dK/dV of the unit's keys: on the MFMA like every other query (the accumulators never leave
+        // their registers): the global query is query 0 of an otherwise empty 32-query step
+        bf16x8 pb0[4], dsb0[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          bf16x8 z = {};
+          pb0[kt] = z; dsb0[kt] = z;
+          if (lg == 0) { pb0[kt][0] = (__bf16)pr[kt]; dsb0[kt][0] = (__bf16)ds[kt]; }
+        }
+#pragma unroll
+        for (int dt = 0; dt < MD; ++dt) {
+          bf16x8 qt0 = {}, dt0 = {};
+          if (lg == 0) { qt0[0] = qg[dt * 16 + lj]; dt0[0] = dg[dt * 16 + lj]; }
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt0, pb0[kt], dv[dt][kt], 0, 0, 0);
+            dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt0, dsb0[kt], dk[dt][kt], 0, 0, 0);
+          }
+        }
+      }
+    }
+
     // ---- epilogue
     if (!glo) {
 #pragma unroll
@@ -597,20 +708,54 @@ __global__ __launch_bounds__(256, 1) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
   }
 }
 
-// dk/dv rows of the G global tokens = sum over the splits' fp32 partials
-__global__ void k_mfma_reduce_glo(VilParams p, BwdCfg bc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int M = p.M;
-  if (i >= p.B * p.H * p.G * M) return;
-  const int d = i % M; const int gk = (i / M) % p.G; const int bh = i / (M * p.G);
+// One workgroup per (image, head, global token gk):
+//   dk/dv rows of global KEY gk   = sum over the splits' fp32 partials (glo_parts)
+//   dq row of global QUERY gk     = scale * sum over the units' partials (gq_parts), and its d(g2l[0]) share
+__global__ __launch_bounds__(256) void k_mfma_reduce_glo(VilParams p, BwdCfg bc, int nslots) {
+  __shared__ float red[4][2][64];
+  const int M = p.M, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int gk = blockIdx.x % p.G, bh = blockIdx.x / p.G;
   const int b = bh / p.H, h = bh % p.H;
-  float sk = 0.f, sv = 0.f;
-  for (int s = 0; s < bc.nsplit; ++s) {
-    const float* rec = bc.glo_parts + ((((int64_t)bh * bc.nsplit + s) * p.G + gk) * 2) * M;
-    sk += rec[d]; sv += rec[M + d];
+  if (tid < 2 * M) {
+    float sk = 0.f;
+    for (int s = 0; s < bc.nsplit; ++s) sk += bc.glo_parts[((((int64_t)bh * bc.nsplit + s) * p.G + gk) * 2) * M + tid];
+    vil_bf16* dst = tid < M ? (vil_bf16*)p.dk + b * p.dk_sb + (int64_t)gk * p.dk_st + h * p.dk_sh + tid
+                            : (vil_bf16*)p.dv + b * p.dv_sb + (int64_t)gk * p.dv_st + h * p.dv_sh + (tid - M);
+    *dst = vil_f2bf(sk);
   }
-  *((vil_bf16*)p.dk + b * p.dk_sb + (int64_t)gk * p.dk_st + h * p.dk_sh + d) = vil_f2bf(sk);
-  *((vil_bf16*)p.dv + b * p.dv_sb + (int64_t)gk * p.dv_st + h * p.dv_sh + d) = vil_f2bf(sv);
+  if (!p.glo_rows) return;
+  const int RS = M + 4;
+  const float* base = bc.gq_parts + ((int64_t)bh * nslots * p.G + gk) * RS;
+  const int64_t sstride = (int64_t)p.G * RS;
+  const bool c1ok = lane + 64 <= M;                 // second column of this lane (only M = 64: the dS sum)
+  float a0 = 0.f, a1 = 0.f;
+  int s = wv;
+  for (; s + 12 < nslots; s += 16) {
+    float v0[4], v1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* r = base + (s + 4 * u) * sstride;
+      v0[u] = lane <= M ? r[lane] : 0.f;
+      v1[u] = c1ok ? r[lane + 64] : 0.f;
+    }
+    a0 += (v0[0] + v0[1]) + (v0[2] + v0[3]);
+    a1 += (v1[0] + v1[1]) + (v1[2] + v1[3]);
+  }
+  for (; s < nslots; s += 4) {
+    const float* r = base + s * sstride;
+    a0 += lane <= M ? r[lane] : 0.f;
+    a1 += c1ok ? r[lane + 64] : 0.f;
+  }
+  red[wv][0][lane] = a0; red[wv][1][lane] = a1;
+  __syncthreads();
+  if (wv == 0) {
+    a0 = red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane];
+    a1 = red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane];
+    vil_bf16* dq = (vil_bf16*)p.dq_g + b * p.dq_sb + (int64_t)gk * p.dq_st + h * p.dq_sh;
+    if (lane < M) dq[lane] = vil_f2bf(a0 * p.scale);
+    const float bs = M == 64 ? a1 : a0;              // column M
+    if (p.dg2l0 && lane == (M & 63)) atomicAdd(&p.dg2l0[h * p.G + gk], bs);
+  }
 }
 
 // rowsum(dO * O): LPR lanes per (image, head, token) row, each lane one (or three) 16-byte pieces of the
@@ -690,7 +835,8 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   // streamed query slots: an own-key unit sees <= nact query chunks, a global-key unit its share of all chunks
   const int qch = d->G > 0 ? (bc.nch + bc.nsplit - 1) / bc.nsplit : 0;
   bc.nqs = ((qch > g.nact ? qch : g.nact) * g.W2 + 31) & ~31;
-  bc.kv_wave_lds = ((bc.nqs * 16 + 2 * 32 * d->M * 2 + 15) / 16) * 16;
+  // slot tables + Q/dO tiles + the q / dO / out rows of the G global queries (vil_attn_bwd_full)
+  bc.kv_wave_lds = ((bc.nqs * 16 + 2 * 32 * d->M * 2 + d->G * 3 * d->M * 2 + 15) / 16) * 16;
   bc.kv_wpw = 4;
   while (bc.kv_wpw > 1 && (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
   const int groups = (bc.units_kv_bh + bc.kv_wpw - 1) / bc.kv_wpw;
@@ -719,26 +865,27 @@ int vil_mfma_bwd_supported(const VilAttnDesc* d) {
 }
 
 // floats: [delta | table copies | hist partials | global-key partials]
-static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& bc, size_t off[5]) {
+static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& bc, size_t off[6]) {
   const size_t rows = (size_t)d->B * d->H * d->nx * d->ny;
   off[0] = 0;
   off[1] = ((rows + 3) & ~(size_t)3) + 32 * VIL_NORM_SLOTS;      // + norm-maxima slots and the histogram scale
   off[2] = off[1] + (size_t)d->H * c.tabsize;
   off[3] = off[2] + (size_t)bc.dq_nwg * c.tabsize;
   off[4] = off[3] + (size_t)d->B * d->H * bc.nsplit * d->G * 2 * d->M;
+  off[5] = off[4] + (size_t)d->B * d->H * (bc.nch * c.NWP + 1) * d->G * (d->M + 4);
 }
 
 size_t vil_mfma_bwd_workspace(const VilAttnDesc* d) {
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   BwdCfg bc; bwd_cfg(d, c, bc);
-  size_t off[5]; bwd_ws_layout(d, c, bc, off);
-  return off[4] * sizeof(float) + 64;
+  size_t off[6]; bwd_ws_layout(d, c, bc, off);
+  return off[5] * sizeof(float) + 64;
 }
 
 int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   BwdCfg bc; bwd_cfg(d, c, bc);
-  size_t off[5]; bwd_ws_layout(d, c, bc, off);
+  size_t off[6]; bwd_ws_layout(d, c, bc, off);
   float* ws = (float*)p.delta;
   if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.dout | (uintptr_t)p.out | (uintptr_t)ws) & 15)
     return VIL_E_ALIGN;
@@ -748,6 +895,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   c.tabws = tabws;
   bc.hist_parts = ws + off[2];
   bc.glo_parts = ws + off[3];
+  bc.gq_parts = ws + off[4];
   bc.do_hist = (p.dtable != nullptr) || (p.dg2l != nullptr);
   bc.norm2 = (unsigned*)(ws + off[1] - 32 * VIL_NORM_SLOTS);
   bc.hist_nmax = p.g.W2 * c.gpw * c.wpw;
@@ -808,7 +956,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   }
   if (p.G > 0) {
     vil_prof_begin(VIL_K_REDUCE_GLO, s, 0, 0);
-    k_mfma_reduce_glo<<<dim3((unsigned)((p.B * p.H * p.G * p.M + 255) / 256)), dim3(256), 0, s>>>(p, bc);
+    k_mfma_reduce_glo<<<dim3((unsigned)(p.B * p.H * p.G)), dim3(256), 0, s>>>(p, bc, bc.nch * c.NWP + 1);
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
   }

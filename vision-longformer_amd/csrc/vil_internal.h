@@ -24,6 +24,14 @@ struct VilParams {
   float* dtable; float* dg2l;
   float* delta;              // workspace: rowsum(dO*O), (B*H*Nloc)
   float* partials;           // workspace: per-workgroup partial reductions
+  // vil_attn_bwd_full: the backward of the G global-token QUERY rows rides in the dK/dV pass
+  int glo_rows;
+  const void* q_g; const void* do_g; const void* o_g;   // token 0 of the all-token q / dout / out tensors
+  void* dq_g;                                            // token 0 of the all-token dq tensor
+  const float* lse_g;        // (B,H,G)
+  const float* g2l0;         // (H,G) bias global query -> local keys, or null
+  const float* g2g;          // (H,G,G) or null
+  float* dg2l0; float* dg2g;
 };
 
 static inline void vil_fill_params(VilParams& p, const VilAttnDesc* d) {

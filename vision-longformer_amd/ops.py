@@ -189,6 +189,15 @@ def _full_bwd(q_all, k, v, out_all, dout_all, lse, lse_g, tab, g2l_f, g2g_f, dq_
     ws = _workspace(d, 1, q_all.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(q_all.device).cuda_stream)
     with torch.cuda.device(q_all.device):
+        if G > 0 and backend != "scalar":
+            # one call: the global rows' backward rides in the dK/dV pass (MFMA family)
+            rc = L.vil_attn_bwd_full(ctypes.byref(d), _ptr(q_all), _ptr(k), _ptr(v), _ptr(out_all), _ptr(dout_all),
+                                     _ptr(lse), _ptr(lse_g), _ptr(tab), _ptr(g2l_f), _ptr(g2g_f),
+                                     _ptr(dq_all), _ptr(dk), _ptr(dv), _ptr(dtab), _ptr(dg2l), _ptr(dg2g), _ptr(ws), stream)
+            if rc == 0:
+                return dtab, dg2l, dg2g
+            if rc != _lib.VIL_E_BACKEND:
+                _lib.check(rc)
         _lib.check(L.vil_attn_bwd(ctypes.byref(d), _ptr(q_loc), _ptr(k), _ptr(v), _ptr(out_loc), _ptr(do_loc),
                                   _ptr(lse), _ptr(tab), _ptr(g2l_f[1]) if g2l_f is not None else None,
                                   _ptr(dq_loc), _ptr(dk), _ptr(dv), _ptr(dtab),
