@@ -28,6 +28,7 @@ struct BwdCfg {
   int nsplit;         // global-key owner units per (image, head)
   int units_kv_bh;    // nch*NWP + (G ? nsplit : 0)
   int kv_wg_per_bh, kv_gpw, kv_wpw;
+  int kv_KT, kv_HQ, kv_NWP;   // dK/dV pass: key tiles per wave, key quads (pairs) per chunk row, waves per chunk
   int nqs;            // streamed query slots per owner unit (padded to 32)
   int kv_wave_lds, dq_wave_lds;
   int do_hist;
@@ -329,8 +330,10 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
 }
 
 // ===================================================================== dK/dV pass
-template <int MD>
-__global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
+// KT = key tiles (of 16 columns) per wave: 4 (64 keys) for M <= 32; 2 (32 keys) for M >= 48, where 64 keys'
+// accumulators (128 registers) + K/V fragments (64) pinned the kernel at one latency-bound wave per SIMD.
+template <int MD, int KT>
+__global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;
   constexpr int VCH = 2 * MD;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilPar
   const int qstride_b = (int)p.q_st * 2, dostride_b = (int)p.do_st * 2;
   const float c1 = p.scale * LOG2E;
   const int W = g.W, W2 = g.W2;
-  const int nown = bc.nch * c.NWP;
+  const int nown = bc.nch * bc.kv_NWP;
   const float* lse_bh = p.lse + (int64_t)bh * Nloc;
   const float* dlt_bh = p.delta + (int64_t)bh * Nloc;
 
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilPar
     if (unit >= bc.units_kv_bh) break;
     const bool glo = unit >= nown;                 // global-key owner unit
     const int split = unit - nown;
-    const int wp = glo ? 0 : unit % c.NWP, ch = glo ? 0 : unit / c.NWP;
+    const int wp = glo ? 0 : unit % bc.kv_NWP, ch = glo ? 0 : unit / bc.kv_NWP;
     const int kn = ch % g.my, km = ch / g.my;
 
     // ---- streamed query slot table: defaults (padding), then one neighbourhood row per lane
@@ -461,28 +464,28 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilPar
     }
     const int nsteps = (nchunks * W2 + 31) >> 5;
 
-    // ---- this lane's key slots: column j of key-tile kt is key (x, y = 4*hq + 3 - kt)
+    // ---- this lane's key slots: column j of key-tile kt is key (x, y = KT*hq + KT-1 - kt)
     const int jj = wp * 16 + lj;
-    const int kx = jj / c.HQ, khq = jj % c.HQ;
+    const int kx = jj / bc.kv_HQ, khq = jj % bc.kv_HQ;
     const int akl = glo ? -(c.glo0 + min(lj, max(p.G - 1, 0)) * c.gsz) * 4
-                        : (min(kx, W - 1) * c.P + 4 * khq + 3) * 4;
-    int ktok[4];
-    bool kreal[4];
+                        : (min(kx, W - 1) * c.P + KT * khq + KT - 1) * 4;
+    int ktok[KT];
+    bool kreal[KT];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < KT; ++kt) {
       if (glo) {
         kreal[kt] = kt == 0 && lj < p.G;
         ktok[kt] = kreal[kt] ? lj : 0;
       } else {
-        const int ky = 4 * khq + 3 - kt;
+        const int ky = KT * khq + KT - 1 - kt;
         const int kr = km * W + kx, kc = kn * W + ky;
         kreal[kt] = kx < W && ky < W && kr < g.nx && kc < g.ny;
         ktok[kt] = p.G + (kreal[kt] ? kr * g.ny + kc : (km * W) * g.ny + kn * W);
       }
     }
-    bf16x8 kfb[MK][4], vfb[MK][4];
+    bf16x8 kfb[MK][KT], vfb[MK][KT];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int ks = 0; ks < MK; ++ks) {
         const int d0 = ks * 32 + lg * 8;
@@ -490,9 +493,9 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilPar
         kfb[ks][kt] = d0 < M ? *(const bf16x8*)(kb + (int64_t)ktok[kt] * p.k_st + d0) : z;
         vfb[ks][kt] = d0 < M ? *(const bf16x8*)(vb + (int64_t)ktok[kt] * p.v_st + d0) : z;
       }
-    f32x4 dk[MD][4], dv[MD][4];
+    f32x4 dk[MD][KT], dv[MD][KT];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int dt = 0; dt < MD; ++dt) {
         dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilPar
       if (st + 1 < nsteps) load_step(st + 1);
       wave_lds_fence();
 
-      bf16x8 pb[4], dsb[4];
+      bf16x8 pb[KT], dsb[KT];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         bf16x8 qa[MK], da[MK];
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilPar
 #pragma unroll
         for (int r = 0; r < 4; ++r) tb[r] = (const float*)((const char*)tab + (aq4[r] - akl));
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < KT; ++kt) {
           f32x4 acc = {tb[0][kt], tb[1][kt], tb[2][kt], tb[3][kt]};
           f32x4 dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilPar
           for (int e = 0; e < 4; ++e) { qt_[hf * 4 + e] = tq[e]; dt_[hf * 4 + e] = td[e]; }
         }
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < KT; ++kt) {
           dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt_, pb[kt], dv[dt][kt], 0, 0, 0);
           dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsb[kt], dk[dt][kt], 0, 0, 0);
         }
@@ -608,9 +611,9 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilPar
         else if (p.g2l0) bias = p.g2l0[h * p.G + gq];
         bias *= LOG2E;
         // (staged so that few values are live at once: this kernel has no registers to spare)
-        float pr[4], ds[4], bsum = 0.f;
+        float pr[KT], ds[KT], bsum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < KT; ++kt) {
           float sc = 0.f, dp = 0.f;
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks)
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilPar
           for (int e = 0; e < 8; ++e) {
             float t = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) t = __builtin_fmaf(ds[kt], (float)kfb[ks][kt][e], t);
+            for (int kt = 0; kt < KT; ++kt) t = __builtin_fmaf(ds[kt], (float)kfb[ks][kt][e], t);
             dqp[ks][e] = t;
           }
 #pragma unroll
@@ -657,9 +660,9 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilPar
         }
         // dK/dV of the unit's keys: on the MFMA like every other query (the accumulators never leave
         // their registers): the global query is query 0 of an otherwise empty 32-query step
-        bf16x8 pb0[4], dsb0[4];
+        bf16x8 pb0[KT], dsb0[KT];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < KT; ++kt) {
           bf16x8 z = {};
           pb0[kt] = z; dsb0[kt] = z;
           if (lg == 0) { pb0[kt][0] = (__bf16)pr[kt]; dsb0[kt][0] = (__bf16)ds[kt]; }
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilPar
           bf16x8 qt0 = {}, dt0 = {};
           if (lg == 0) { qt0[0] = qg[dt * 16 + lj]; dt0[0] = dg[dt * 16 + lj]; }
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
+          for (int kt = 0; kt < KT; ++kt) {
             dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt0, pb0[kt], dv[dt][kt], 0, 0, 0);
             dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt0, dsb0[kt], dk[dt][kt], 0, 0, 0);
           }
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dkdv(VilPar
     // ---- epilogue
     if (!glo) {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < KT; ++kt)
         if (kreal[kt]) {
 #pragma unroll
           for (int dt = 0; dt < MD; ++dt) {
@@ -831,7 +834,10 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
   bc.nch = g.mx * g.my;
   bc.nsplit = d->G > 0 ? (bc.nch + 8) / 9 : 0;
-  bc.units_kv_bh = bc.nch * c.NWP + bc.nsplit;
+  bc.kv_KT = d->M >= 48 ? 2 : 4;
+  bc.kv_HQ = (g.W + bc.kv_KT - 1) / bc.kv_KT;
+  bc.kv_NWP = (g.W * bc.kv_HQ + 15) / 16;
+  bc.units_kv_bh = bc.nch * bc.kv_NWP + bc.nsplit;
   // streamed query slots: an own-key unit sees <= nact query chunks, a global-key unit its share of all chunks
   const int qch = d->G > 0 ? (bc.nch + bc.nsplit - 1) / bc.nsplit : 0;
   bc.nqs = ((qch > g.nact ? qch : g.nact) * g.W2 + 31) & ~31;
@@ -872,7 +878,7 @@ static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& 
   off[2] = off[1] + (size_t)d->H * c.tabsize;
   off[3] = off[2] + (size_t)bc.dq_nwg * c.tabsize;
   off[4] = off[3] + (size_t)d->B * d->H * bc.nsplit * d->G * 2 * d->M;
-  off[5] = off[4] + (size_t)d->B * d->H * (bc.nch * c.NWP + 1) * d->G * (d->M + 4);
+  off[5] = off[4] + (size_t)d->B * d->H * (bc.nch * bc.kv_NWP + 1) * d->G * (d->M + 4);
 }
 
 size_t vil_mfma_bwd_workspace(const VilAttnDesc* d) {
@@ -945,18 +951,18 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     vil_prof_begin(VIL_K_MFMA_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
     BWD_SWITCH({
       if (lds > 64 * 1024) {
-        hipError_t he = hipFuncSetAttribute((const void*)k_mfma_bwd_dkdv<MD_>,
+        hipError_t he = hipFuncSetAttribute((const void*)k_mfma_bwd_dkdv<MD_, (MD_ >= 3 ? 2 : 4)>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (he != hipSuccess) return (int)he;
       }
-      k_mfma_bwd_dkdv<MD_><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
+      k_mfma_bwd_dkdv<MD_, (MD_ >= 3 ? 2 : 4)><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
   }
   if (p.G > 0) {
     vil_prof_begin(VIL_K_REDUCE_GLO, s, 0, 0);
-    k_mfma_reduce_glo<<<dim3((unsigned)(p.B * p.H * p.G)), dim3(256), 0, s>>>(p, bc, bc.nch * c.NWP + 1);
+    k_mfma_reduce_glo<<<dim3((unsigned)(p.B * p.H * p.G)), dim3(256), 0, s>>>(p, bc, bc.nch * bc.kv_NWP + 1);
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
   }
