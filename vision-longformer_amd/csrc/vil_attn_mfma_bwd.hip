@@ -28,6 +28,7 @@ struct BwdCfg {
   int nsplit;         // global-key owner units per (image, head)
   int units_kv_bh;    // nch*NWP + (G ? nsplit : 0)
   int kv_wg_per_bh, kv_gpw, kv_wpw;
+  int dq_QT, dq_HQ, dq_NWP, dq_units_bh, dq_wg_per_bh, dq_gpw, dq_wpw;   // dQ pass: query tiles per wave, ...
   int kv_KT, kv_HQ, kv_NWP;   // dK/dV pass: key tiles per wave, key quads (pairs) per chunk row, waves per chunk
   int nqs;            // streamed query slots per owner unit (padded to 32)
   int kv_wave_lds, dq_wave_lds;
@@ -42,8 +43,10 @@ struct BwdCfg {
 };
 
 // ===================================================================== dQ pass
-template <int MD>
-__global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, BwdCfg bc) {
+// QT = query tiles (of 16 columns) per wave: 4 (64 query slots) for M <= 32, 2 for M >= 48 (two waves per
+// SIMD instead of one; same reasoning as KT of the dK/dV pass)
+template <int MD, int QT>
+__global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, BwdCfg bc) {
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;
   constexpr int VCH = 2 * MD;
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
   const int lj = lane & 15, lg = lane >> 4;
 
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = logical / c.wg_per_bh, wgi = logical % c.wg_per_bh;
+  const int bh = logical / bc.dq_wg_per_bh, wgi = logical % bc.dq_wg_per_bh;
   const int b = bh / p.H, h = bh % p.H;
 
   float* tab = (float*)smem;
@@ -123,21 +126,21 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
   }
   const int lgo = lg * 16;
 
-  for (int gi = 0; gi < c.gpw; ++gi) {
-    const int unit = (wgi * c.gpw + gi) * c.wpw + wave;
-    if (unit < c.units_bh) {
-      const int wp = unit % c.NWP, ch = unit / c.NWP;
+  for (int gi = 0; gi < bc.dq_gpw; ++gi) {
+    const int unit = (wgi * bc.dq_gpw + gi) * bc.dq_wpw + wave;
+    if (unit < bc.dq_units_bh) {
+      const int wp = unit % bc.dq_NWP, ch = unit / bc.dq_NWP;
       const int cn = ch % g.my, cm = ch / g.my;
       const int nslots = build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey);
       const int jj = wp * 16 + lj;
-      const int qx = jj / c.HQ, qhq = jj % c.HQ;
-      const int aq0b = (min(qx, W - 1) * c.P + 4 * qhq) * 4;
-      int qtok[4];
-      bool qreal[4];
-      float lse2[4], dlt[4];
+      const int qx = jj / bc.dq_HQ, qhq = jj % bc.dq_HQ;
+      const int aq0b = (min(qx, W - 1) * c.P + QT * qhq) * 4;
+      int qtok[QT];
+      bool qreal[QT];
+      float lse2[QT], dlt[QT];
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt) {
-        const int qy = 4 * qhq + qt;
+      for (int qt = 0; qt < QT; ++qt) {
+        const int qy = QT * qhq + qt;
         const int qr = cm * W + qx, qc = cn * W + qy;
         qreal[qt] = qx < W && qy < W && qr < g.nx && qc < g.ny;
         qtok[qt] = qreal[qt] ? qr * g.ny + qc : (cm * W) * g.ny + cn * W;
@@ -145,9 +148,9 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
         lse2[qt] = qreal[qt] ? p.lse[(int64_t)bh * Nloc + qtok[qt]] * LOG2E - (float)lfx : LSE_PAD;
         dlt[qt] = qreal[qt] ? p.delta[(int64_t)bh * Nloc + qtok[qt]] : 0.f;
       }
-      bf16x8 qf[MK][4], dof[MK][4];
+      bf16x8 qf[MK][QT], dof[MK][QT];
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt)
+      for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int ks = 0; ks < MK; ++ks) {
           const int d0 = ks * 32 + lg * 8;
@@ -155,9 +158,9 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
           qf[ks][qt] = d0 < M ? *(const bf16x8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
           dof[ks][qt] = d0 < M ? *(const bf16x8*)(dob + (int64_t)qtok[qt] * p.do_st + d0) : z;
         }
-      f32x4 dq[MD][4];
+      f32x4 dq[MD][QT];
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt)
+      for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int dt = 0; dt < MD; ++dt) dq[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
         if (st + 1 < nsteps) load_step(st + 1);
         wave_lds_fence();
 
-        bf16x8 dsb[4];
+        bf16x8 dsb[QT];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           // K rows of this half as the A operand (natural layout, from the LDS tile)
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
             tb[r] = (const float*)((const char*)tab + i0[r]);
           }
 #pragma unroll
-          for (int qt = 0; qt < 4; ++qt) {
+          for (int qt = 0; qt < QT; ++qt) {
             f32x4 acc = {tb[0][qt], tb[1][qt], tb[2][qt], tb[3][qt]};
             f32x4 dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -244,13 +247,13 @@ __global__ __launch_bounds__(256, (MD <= 2 ? 2 : 1)) void k_mfma_bwd_dq(VilParam
             for (int e = 0; e < 4; ++e) kt_[hf * 4 + e] = tb[e];
           }
 #pragma unroll
-          for (int qt = 0; qt < 4; ++qt)
+          for (int qt = 0; qt < QT; ++qt)
             dq[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsb[qt], dq[dt][qt], 0, 0, 0);
         }
         wave_lds_fence();
       }
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt)
+      for (int qt = 0; qt < QT; ++qt)
         if (qreal[qt]) {
 #pragma unroll
           for (int dt = 0; dt < MD; ++dt) {
@@ -281,7 +284,7 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
   long long si = 0;
   if (bin < c.tabsize) {
     // workgroups of head h: logical = (b*H + h)*wg_per_bh + w
-    const int per = c.wg_per_bh;
+    const int per = bc.dq_wg_per_bh;
     const int* parts = (const int*)bc.hist_parts;
     const int n = p.B * per;
     int i = grp;
@@ -852,10 +855,24 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   bc.kv_gpw = gpw;
   bc.kv_wg_per_bh = (groups + gpw - 1) / gpw;
   bc.dq_wave_lds = ((c.NSP * 8 + 32 * d->M * 2 + 15) / 16) * 16;
-  bc.dq_nwg = d->B * d->H * c.wg_per_bh;
+  bc.dq_QT = d->M >= 48 ? 2 : 4;
+  bc.dq_HQ = (g.W + bc.dq_QT - 1) / bc.dq_QT;
+  bc.dq_NWP = (g.W * bc.dq_HQ + 15) / 16;
+  bc.dq_units_bh = bc.nch * bc.dq_NWP;
+  bc.dq_wpw = 4;
+  while (bc.dq_wpw > 1 && (size_t)c.tabsize * 8 + (size_t)bc.dq_wpw * bc.dq_wave_lds > 160 * 1024) bc.dq_wpw >>= 1;
+  {
+    const int dgroups = (bc.dq_units_bh + bc.dq_wpw - 1) / bc.dq_wpw;
+    int dgpw = (int)(((int64_t)d->B * d->H * dgroups) / 2048);
+    if (dgpw < 1) dgpw = 1;
+    if (dgpw > dgroups) dgpw = dgroups;
+    bc.dq_gpw = dgpw;
+    bc.dq_wg_per_bh = (dgroups + dgpw - 1) / dgpw;
+  }
+  bc.dq_nwg = d->B * d->H * bc.dq_wg_per_bh;
 }
 
-static size_t dq_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.tabsize * 8 + (size_t)c.wpw * bc.dq_wave_lds; }
+static size_t dq_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.tabsize * 8 + (size_t)bc.dq_wpw * bc.dq_wave_lds; }
 static size_t kv_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds; }
 
 int vil_mfma_bwd_supported(const VilAttnDesc* d) {
@@ -904,7 +921,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   bc.gq_parts = ws + off[4];
   bc.do_hist = (p.dtable != nullptr) || (p.dg2l != nullptr);
   bc.norm2 = (unsigned*)(ws + off[1] - 32 * VIL_NORM_SLOTS);
-  bc.hist_nmax = p.g.W2 * c.gpw * c.wpw;
+  bc.hist_nmax = p.g.W2 * bc.dq_gpw * bc.dq_wpw;
   const VilWork w(d);
   const int64_t rows = (int64_t)p.B * p.H * p.g.nx * p.g.ny;
   int e;
@@ -936,11 +953,11 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     vil_prof_begin(VIL_K_MFMA_DQ, s, w.dq_bytes(), w.dq_flops());
     BWD_SWITCH({
       if (lds > 64 * 1024) {
-        hipError_t he = hipFuncSetAttribute((const void*)k_mfma_bwd_dq<MD_>,
+        hipError_t he = hipFuncSetAttribute((const void*)k_mfma_bwd_dq<MD_, (MD_ >= 3 ? 2 : 4)>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (he != hipSuccess) return (int)he;
       }
-      k_mfma_bwd_dq<MD_><<<dim3((unsigned)bc.dq_nwg), dim3(64 * c.wpw), lds, s>>>(p, c, bc);
+      k_mfma_bwd_dq<MD_, (MD_ >= 3 ? 2 : 4)><<<dim3((unsigned)bc.dq_nwg), dim3(64 * bc.dq_wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
