@@ -855,7 +855,7 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   bc.kv_gpw = gpw;
   bc.kv_wg_per_bh = (groups + gpw - 1) / gpw;
   bc.dq_wave_lds = ((c.NSP * 8 + 32 * d->M * 2 + 15) / 16) * 16;
-  bc.dq_QT = d->M >= 48 ? 2 : 4;
+  bc.dq_QT = d->M >= 32 ? 2 : 4;
   bc.dq_HQ = (g.W + bc.dq_QT - 1) / bc.dq_QT;
   bc.dq_NWP = (g.W * bc.dq_HQ + 15) / 16;
   bc.dq_units_bh = bc.nch * bc.dq_NWP;
@@ -953,11 +953,11 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     vil_prof_begin(VIL_K_MFMA_DQ, s, w.dq_bytes(), w.dq_flops());
     BWD_SWITCH({
       if (lds > 64 * 1024) {
-        hipError_t he = hipFuncSetAttribute((const void*)k_mfma_bwd_dq<MD_, (MD_ >= 3 ? 2 : 4)>,
+        hipError_t he = hipFuncSetAttribute((const void*)k_mfma_bwd_dq<MD_, (MD_ >= 2 ? 2 : 4)>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (he != hipSuccess) return (int)he;
       }
-      k_mfma_bwd_dq<MD_, (MD_ >= 3 ? 2 : 4)><<<dim3((unsigned)bc.dq_nwg), dim3(64 * bc.dq_wpw), lds, s>>>(p, c, bc);
+      k_mfma_bwd_dq<MD_, (MD_ >= 2 ? 2 : 4)><<<dim3((unsigned)bc.dq_nwg), dim3(64 * bc.dq_wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
