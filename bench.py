@@ -104,8 +104,8 @@ def main():
     ap.add_argument("--master-weights", default="on", choices=["on", "off"],
                     help="bf16 working weights + fp32 master (engine.MasterWeightAdamW) instead of per-call autocast casts")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="run the step as a hipGraph (measured on ViL-Small: no faster than eager at N=1, and it gives up "
-                         "DDP's overlapped bucketed all-reduce, so auto = off)")
+                    help="run the step as hipGraphs (auto: on unless the config draws a random-shift mode per step); "
+                         "off = eager step under DDP (bucketed all-reduce overlapped with backward)")
     args = ap.parse_args()
 
     from vision_longformer_amd import _lib, ops
@@ -122,15 +122,34 @@ def main():
     B = args.batch or cfg_batch
     torch.manual_seed(0)
     model = build_vil(args.config).to(device).train()
-    use_graph = args.graph == "on"
-    use_master = args.master_weights == "on" and not use_graph
-    opt = MasterWeightAdamW(model) if use_master else make_optimizer(model, capturable=use_graph)
+    use_graph = args.graph == "on" or (args.graph == "auto" and mode <= 0)
+    use_master = args.master_weights == "on"
+    opt = MasterWeightAdamW(model, capturable=use_graph) if use_master else make_optimizer(model, capturable=use_graph)
     data = SyntheticBatches(B, img, device, rank)
     if use_graph:
-        if world > 1:      # same initial weights on every rank (what DDP's constructor would do)
-            for p_ in model.parameters():
-                dist.broadcast(p_.data, 0)
-        gstep = GraphedTrainStep(model, opt, *data.next(), world=world)
+        ok = 1
+        try:
+            if world > 1:      # same initial weights on every rank (what DDP's constructor would do)
+                for p_ in model.parameters():
+                    dist.broadcast(p_.data, 0)
+                if use_master:
+                    for m_ in opt.master:
+                        dist.broadcast(m_, 0)
+            gstep = GraphedTrainStep(model, opt, *data.next(), world=world)
+        except Exception as exc:          # capture refused: every rank falls back to the eager DDP step together
+            print(f"[rank {rank}] hipGraph capture failed ({exc!r}); falling back to the eager step", file=sys.stderr)
+            ok = 0
+        if world > 1:
+            flag = torch.tensor([ok], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            use_graph = False
+            torch.cuda.synchronize()
+            torch.manual_seed(0)
+            model = build_vil(args.config).to(device).train()
+            opt = MasterWeightAdamW(model) if use_master else make_optimizer(model)
+    if use_graph:
         step_fn = lambda xb, tb: gstep(xb, tb)
     else:
         ddp = wrap_ddp(model, device, world)
@@ -154,10 +173,9 @@ def main():
     if use_graph:
         # per-kernel hipEvent timing needs the library's own launches: run the SAME step eagerly,
         # right after the timed region, on the same weights / shapes (not part of `value`)
-        ddp_e = model
         _lib.profile_begin(cap)
         for _ in range(min(args.steps, 5)):
-            train_step(ddp_e, opt, *data.next()) if world == 1 else gstep._body(eager=True)
+            gstep._body(eager=True)
         torch.cuda.synchronize()
     recs = _lib.profile_end(cap)
     if world > 1:
@@ -206,7 +224,8 @@ def main():
                        "backend": args.backend, "random_shift_mode": mode,
                        "precision": "bf16 compute, fp32 master weights + fp32 AdamW state"
                                     + (" (bf16 working copy, foreach refresh)" if use_master else " (autocast casts)"),
-                       "launch": "hipGraph replay (fwd+bwd" + ("+AdamW)" if world == 1 else "), flat-gradient RCCL all-reduce, AdamW")
+                       "launch": "hipGraph replay (fwd+bwd" + ("+AdamW)" if world == 1 else "), flat-gradient RCCL all-reduce, "
+                                                                     "hipGraph replay (AdamW)")
                                  if use_graph else "eager (DDP bucketed all-reduce)"},
             "roofline": roofline,
             "hot_path_ms_per_step": round(hot_ms / nprof, 3),

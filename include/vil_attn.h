@@ -178,6 +178,14 @@ int vil_geom_mask(int nx, int ny, int W, int exact, int mode, uint8_t* mask);
  * key slot s (longformer2d.py:67-100 with the mode's column subset :164-173). */
 int vil_geom_bias_index(int W, int mode, int32_t* rel);
 
+/* ---- bias gradient of the projections around the hot path: out[c] = sum_r x[r*row_stride + c] over a
+ * (rows x C) bf16 matrix (autograd of nn.Linear's bias; reference msvit.py:91-120, 236-255).  C % 8 == 0,
+ * 16-byte aligned rows; out is C floats (out_bf16 = 0) or C bf16 (1); workspace of
+ * vil_colsum_workspace_bytes(C) bytes. */
+size_t vil_colsum_workspace_bytes(int C);
+int vil_colsum_bf16(const void* x, int64_t rows, int C, int64_t row_stride, void* out, int out_bf16,
+                    void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

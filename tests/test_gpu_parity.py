@@ -381,9 +381,11 @@ def test_fused_layernorm_vs_torch(dev, C, rows, mode):
 
 
 # ---------------------------------------------------------------- hipGraph training step
-def test_graphed_train_step_equals_eager(dev):
-    """The captured fwd+bwd+AdamW graph must walk the same trajectory as the eager step."""
-    from vision_longformer_amd.engine import make_optimizer, train_step, GraphedTrainStep
+@pytest.mark.parametrize("master", [False, True])
+def test_graphed_train_step_equals_eager(dev, master):
+    """The captured fwd+bwd+AdamW graph must walk the same trajectory as the eager step
+    (plain fused AdamW, and bf16 working weights + fp32 master AdamW)."""
+    from vision_longformer_amd.engine import make_optimizer, train_step, GraphedTrainStep, MasterWeightAdamW
     from vision_longformer_amd.msvit import MsViT
     arch = "l1,h1,d32,n1,s1,g1,p4,f4,a0_l2,h2,d64,n2,s1,g1,p2,f4,a0_l3,h2,d64,n1,s0,g1,p2,f7,a0"
     g = torch.Generator().manual_seed(5)
@@ -393,13 +395,18 @@ def test_graphed_train_step_equals_eager(dev):
     def run(graphed):
         torch.manual_seed(0)
         m = MsViT(arch, img_size=64, num_classes=10, drop_path_rate=0.0, norm_embed=True, sharew=True).to(dev).train()
-        opt = make_optimizer(m, lr=1e-3, capturable=graphed)
+        opt = MasterWeightAdamW(m, lr=1e-3, capturable=graphed) if master else make_optimizer(m, lr=1e-3, capturable=graphed)
         losses = []
         if graphed:
             sd = {k: v.clone() for k, v in m.state_dict().items()}
+            msd = [mm.clone() for mm in opt.master] if master else []
             gs = GraphedTrainStep(m, opt, xs[0], ts[0], warmup=2)
-            m.load_state_dict(sd)                       # undo the warm-up updates
-            for st in opt.state.values():
+            with torch.no_grad():                       # undo the warm-up updates (in place: the graph holds the buffers)
+                for k, v in m.state_dict().items():
+                    v.copy_(sd[k])
+                for mm, v in zip(opt.master if master else [], msd):
+                    mm.copy_(v)
+            for st in (opt.opt if master else opt).state.values():
                 for k, v in st.items():
                     if torch.is_tensor(v):
                         v.zero_()
@@ -471,3 +478,21 @@ def test_dense_attention_one_chunk_vs_reference(dev, nx, G, H, M, B, rpe):
             got[nm] = dl[i].grad.double().cpu(); want[nm] = leaves[i].grad
     tol = dict(out=(2e-2, 5e-2), dqkv=(5e-2, 2e-1), dtable=(2.5e-1, 1e-1), dg2l=(2.5e-1, 1e-1), dg2g=(2.5e-1, 1e-1))
     compare(f"dense one-chunk nx{nx} G{G} H{H} M{M}", got, want, tol)
+
+
+@pytest.mark.parametrize("rows,C", [(25216, 384), (1000, 96), (6400, 3072), (777, 1152), (5, 8)])
+def test_colsum_bias_gradient(dev, rows, C):
+    """db of the projections (vil_colsum_bf16) against an fp64 column sum."""
+    from vision_longformer_amd.linear import _colsum
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(rows, C, generator=g).bfloat16()
+    got = _colsum(x.to(dev)).float().cpu().double()
+    want = x.double().sum(0)
+    err = (got - want).abs().max().item()
+    tol = 4e-3 * max(1.0, want.abs().max().item())          # bf16 output rounding
+    assert err <= tol, (err, tol)
+    # strided view (a column slice of a wider matrix), as dY of a fused qkv projection would be
+    wide = torch.randn(rows, 2 * C, generator=g).bfloat16()
+    got = _colsum(wide.to(dev)[:, C:]).float().cpu().double()
+    want = wide[:, C:].double().sum(0)
+    assert (got - want).abs().max().item() <= 4e-3 * max(1.0, want.abs().max().item())

@@ -81,7 +81,8 @@ class MasterWeightAdamW:
     step, profiles/); here the refresh is a handful of multi-tensor (foreach) kernels per step, and
     DDP all-reduces the bf16 gradients (half the bytes over xGMI)."""
 
-    def __init__(self, model, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999), low_dtype=torch.bfloat16):
+    def __init__(self, model, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999), low_dtype=torch.bfloat16,
+                 capturable=False):
         skip = model.no_weight_decay()
         names = {id(p): n for n, p in model.named_parameters()}
         masters = {}
@@ -108,7 +109,8 @@ class MasterWeightAdamW:
             (no_decay if (p.ndim <= 1 or any(s in n for s in skip)) else decay).append(tgt)
         fused = next(model.parameters()).is_cuda
         self.opt = torch.optim.AdamW([{"params": decay, "weight_decay": weight_decay},
-                                      {"params": no_decay, "weight_decay": 0.0}], lr=lr, betas=betas, fused=fused)
+                                      {"params": no_decay, "weight_decay": 0.0}], lr=lr, betas=betas, fused=fused,
+                                     capturable=bool(capturable and fused))
         self.param_groups = self.opt.param_groups
 
     def zero_grad(self, set_to_none=True):
@@ -177,32 +179,40 @@ def train_step(model, optimizer, images, targets, amp_dtype=torch.bfloat16):
 
 
 class GraphedTrainStep:
-    """The training step as a hipGraph (HIP streams + graphs instead of per-op eager launches).
+    """The training step as hipGraphs (HIP streams + graphs instead of per-op eager launches).
 
-    A ViL step is ~1500 kernel launches; at ~17 us of host work per launch the CPU, not the GPU, bounds
-    the step (measured: ViL-Tiny at batch 2 and ViL-Small at batch 128 both take ~26-31 ms).  The graph
-    holds forward + backward (+ the fused AdamW step when world == 1) on static buffers:
-      * gradients live in ONE flat fp32 buffer (every p.grad is a view into it), zeroed inside the graph;
-      * for world > 1 the graph contains NO collective: after the replay the flat gradient buffer is
-        all-reduced (mean) in a single RCCL call over xGMI, then the fused optimizer step runs.  This
-        gives up comm/compute overlap (99 MB fp32 for ViL-Small: ~1 ms of ring time per step) for a
-        capture that is robust on any world size.
+    A ViL-Small step is ~900 kernel launches; once the hot path and the glue kernels are fast the host,
+    not the GPU, bounds the eager step (measured on MI355X: 23.4 ms of kernel time in a 24.8-26 ms step).
+    Graph A holds zero-grad + forward + backward on static buffers, graph B the optimizer step
+    (fp32-master AdamW or the capturable fused AdamW):
+      * gradients live in ONE flat buffer per dtype (every p.grad is a 16-byte aligned view into it),
+        zeroed inside graph A;
+      * world == 1: A and B are one graph;
+      * world > 1: neither graph contains a collective: replay A, all-reduce (mean) the flat buffers in
+        one RCCL call each over xGMI (bf16 gradients of the working weights: ~50 MB for ViL-Small), replay
+        B.  This gives up comm/compute overlap (~0.5 ms of ring time per step) for no host launch cost.
     Not usable when a layer draws a new random-shift neighbour every step (mode > 0): kernel arguments
-    must be static, the caller falls back to the eager step."""
+    must be static, the caller falls back to the eager DDP step."""
 
     def __init__(self, model, optimizer, images, targets, world=1, amp_dtype=torch.bfloat16, warmup=3):
         self.model, self.opt, self.world, self.amp = model, optimizer, world, amp_dtype
         dev = images.device
         self.x = torch.empty_like(images)
         self.t = torch.empty_like(targets)
-        params = [p for p in model.parameters() if p.requires_grad]
-        self.flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
-        off = 0
-        for p in params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        by_dt = {}
+        for p in model.parameters():
+            if p.requires_grad:
+                by_dt.setdefault(p.dtype, []).append(p)
+        self.flats = []
+        for dt, ps in by_dt.items():
+            sizes = [(p.numel() + 7) // 8 * 8 for p in ps]
+            flat = torch.zeros(sum(sizes), dtype=dt, device=dev)
+            off = 0
+            for p, n in zip(ps, sizes):
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += n
+            self.flats.append(flat)
         self.loss = None
-        self.opt_in_graph = world == 1
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -213,24 +223,39 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self._body(eager=False)
+            self._fwd_bwd()
+            if world == 1:
+                self.opt.step()
+        self.opt_graph = None
+        if world > 1:
+            self.opt_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.opt_graph):
+                self.opt.step()
 
-    def _body(self, eager):
-        self.flat.zero_()
+    def _fwd_bwd(self):
+        for f in self.flats:
+            f.zero_()
         with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
             loss = soft_target_cross_entropy(self.model(self.x), self.t)
         loss.backward()
-        if self.opt_in_graph or eager:
-            if eager and self.world > 1:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
-            self.opt.step()
         self.loss = loss.detach()
+
+    def _allreduce(self):
+        for f in self.flats:
+            dist.all_reduce(f, op=dist.ReduceOp.AVG)
+
+    def _body(self, eager):
+        """the same step launched op by op (warm-up, and the per-kernel profile of bench.py)"""
+        self._fwd_bwd()
+        if self.world > 1:
+            self._allreduce()
+        self.opt.step()
 
     def __call__(self, images, targets):
         self.x.copy_(images, non_blocking=True)
         self.t.copy_(targets, non_blocking=True)
         self.graph.replay()
-        if not self.opt_in_graph:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
-            self.opt.step()
+        if self.opt_graph is not None:
+            self._allreduce()
+            self.opt_graph.replay()
         return self.loss

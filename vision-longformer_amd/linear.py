@@ -19,6 +19,30 @@ def _pick_split(T):
     return s
 
 
+_CS_WS = {}
+
+
+def _colsum(dy2):
+    """db = dy2.sum(0) through libvilattn's HBM-rate column-sum kernel (bf16, C % 8 == 0)."""
+    T, co = dy2.shape
+    if not (dy2.is_cuda and dy2.dtype == torch.bfloat16 and co % 8 == 0 and dy2.stride(1) == 1
+            and dy2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0):
+        return dy2.sum(0)
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    key = (dy2.device, co)
+    ws = _CS_WS.get(key)
+    if ws is None:
+        ws = _CS_WS[key] = torch.empty(L.vil_colsum_workspace_bytes(co) // 4, dtype=torch.float32, device=dy2.device)
+    out = torch.empty(co, dtype=torch.bfloat16, device=dy2.device)
+    with torch.cuda.device(dy2.device):
+        _lib.check(L.vil_colsum_bf16(ctypes.c_void_p(dy2.data_ptr()), T, co, dy2.stride(0),
+                                     ctypes.c_void_p(out.data_ptr()), 1, ctypes.c_void_p(ws.data_ptr()),
+                                     ctypes.c_void_p(torch.cuda.current_stream(dy2.device).cuda_stream)))
+    return out
+
+
 class _SplitKLinearFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
@@ -46,7 +70,7 @@ class _SplitKLinearFn(torch.autograd.Function):
             else:
                 dw = dy2.t() @ x2
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0)
+            db = _colsum(dy2)
         return dx, dw, db
 
 
