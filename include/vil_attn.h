@@ -186,6 +186,15 @@ size_t vil_colsum_workspace_bytes(int C);
 int vil_colsum_bf16(const void* x, int64_t rows, int C, int64_t row_stride, void* out, int out_bf16,
                     void* workspace, void* stream);
 
+/* ---- fused weight + bias gradient of a projection y = x W^T + b (autograd of nn.Linear; reference
+ * msvit.py:91-120, 236-255, longformer2d.py:47-62): dW[co][ci] = sum_t dy[t][co] x[t][ci] (row-major
+ * (CO, CI), like nn.Linear.weight) and, when db != NULL, db[co] = sum_t dy[t][co].  dy is (T, CO) and x
+ * (T, CI) bf16 with the given row strides (elements); CO, CI and the strides multiples of 8, 16-byte
+ * aligned bases.  Outputs bf16 (out_bf16 = 1) or fp32.  Workspace: vil_linear_wgrad_workspace_bytes. */
+size_t vil_linear_wgrad_workspace_bytes(int64_t T, int CO, int CI);
+int vil_linear_wgrad(const void* dy, const void* x, int64_t T, int CO, int CI, int64_t dy_stride, int64_t x_stride,
+                     void* dw, void* db, int out_bf16, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -496,3 +496,30 @@ def test_colsum_bias_gradient(dev, rows, C):
     got = _colsum(wide.to(dev)[:, C:]).float().cpu().double()
     want = wide[:, C:].double().sum(0)
     assert (got - want).abs().max().item() <= 4e-3 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("T,CO,CI", [(25216, 1536, 384), (25216, 384, 1536), (6272, 3072, 768), (100480, 192, 576),
+                                      (40000, 96, 288), (1031, 40, 72), (4096, 1000, 768)])
+def test_linear_wgrad_fused(dev, T, CO, CI):
+    """dW = dY^T X and db = colsum(dY) (vil_linear_wgrad) against fp64 on the same bf16 inputs."""
+    from vision_longformer_amd.linear import _wgrad
+    g = torch.Generator().manual_seed(9)
+    dy = (torch.randn(T, CO, generator=g) * 0.1).bfloat16()
+    x = torch.randn(T, CI, generator=g).bfloat16()
+    res = _wgrad(dy.to(dev), x.to(dev), True)
+    assert res is not None
+    dw, db = res
+    torch.cuda.synchronize()
+    sub = slice(0, min(CO, 256))                               # fp64 reference on a slab of output rows (CPU time)
+    want = dy[:, sub].double().t() @ x.double()
+    got = dw[sub].float().cpu().double()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 6e-3 * scale, ((got - want).abs().max().item(), scale)
+    wdb = dy.double().sum(0)
+    assert (db.float().cpu().double() - wdb).abs().max().item() <= 6e-3 * max(1.0, wdb.abs().max().item())
+    # strided operands: column slices of wider matrices (dY of a packed projection)
+    wide = (torch.randn(T, 2 * CO, generator=g) * 0.1).bfloat16()
+    res = _wgrad(wide.to(dev)[:, CO:], x.to(dev), False)
+    want = wide[:, CO:][:, sub].double().t() @ x.double()
+    got = res[0][sub].float().cpu().double()
+    assert (got - want).abs().max().item() <= 6e-3 * want.abs().max().item()

@@ -21,12 +21,12 @@ __global__ __launch_bounds__(256) void k_colsum(ColsumParams p) {
   if (r0 < p.rpi && c0 < p.C) {
     const int64_t step = (int64_t)gridDim.x * p.rpi;
     int64_t r = (int64_t)blockIdx.x * p.rpi + r0;
-    for (; r + 3 * step < p.rows; r += 4 * step) {     // four independent 16-byte loads in flight
-      cs_bf16x8 v[4];
+    for (; r + 7 * step < p.rows; r += 8 * step) {     // eight independent 16-byte loads in flight
+      cs_bf16x8 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *(const cs_bf16x8*)(p.x + (r + u * step) * p.stride + c0);
+      for (int u = 0; u < 8; ++u) v[u] = *(const cs_bf16x8*)(p.x + (r + u * step) * p.stride + c0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += (float)v[u][e];
     }
@@ -85,8 +85,8 @@ extern "C" int vil_colsum_bf16(const void* x, int64_t rows, int C, int64_t row_s
   const int tcols = C / 8;
   p.tc = tcols < 256 ? tcols : 256;
   p.rpi = 256 / p.tc;
-  int64_t need = (rows + (int64_t)p.rpi * 16 - 1) / ((int64_t)p.rpi * 16);
-  p.nblocks = (int)(need < 256 ? (need < 1 ? 1 : need) : 256);
+  int64_t need = (rows + (int64_t)p.rpi * 8 - 1) / ((int64_t)p.rpi * 8);
+  p.nblocks = (int)(need < 512 ? (need < 1 ? 1 : need) : 512);
   p.parts = (float*)workspace; p.out = out; p.out_bf16 = out_bf16;
   hipStream_t s = (hipStream_t)stream;
   k_colsum<<<dim3(p.nblocks, (tcols + 255) / 256), dim3(256), 0, s>>>(p);

@@ -43,6 +43,34 @@ def _colsum(dy2):
     return out
 
 
+_WG_WS = {}
+
+
+def _wgrad(dy2, x2, want_db):
+    """(dW, db) of y = x W^T + b through libvilattn's fused MFMA weight/bias-gradient kernel, or None
+    when the operands do not fit its contract (then the caller uses library GEMMs)."""
+    T, co = dy2.shape
+    ci = x2.shape[1]
+    if not (dy2.is_cuda and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and co % 8 == 0 and ci % 8 == 0
+            and dy2.stride(1) == 1 and x2.stride(1) == 1 and dy2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0
+            and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0 and T >= 1024):
+        return None
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    need = L.vil_linear_wgrad_workspace_bytes(T, co, ci)
+    ws = _WG_WS.get(dy2.device)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _WG_WS[dy2.device] = torch.empty(max(need // 4 + 64, 1 << 22), dtype=torch.float32, device=dy2.device)
+    dw = torch.empty(co, ci, dtype=torch.bfloat16, device=dy2.device)
+    db = torch.empty(co, dtype=torch.bfloat16, device=dy2.device) if want_db else None
+    vp = ctypes.c_void_p
+    _lib.check(L.vil_linear_wgrad(vp(dy2.data_ptr()), vp(x2.data_ptr()), T, co, ci, dy2.stride(0), x2.stride(0),
+                                  vp(dw.data_ptr()), vp(db.data_ptr()) if want_db else None, 1, vp(ws.data_ptr()),
+                                  vp(torch.cuda.current_stream(dy2.device).cuda_stream)))
+    return dw, db
+
+
 class _SplitKLinearFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
@@ -62,7 +90,11 @@ class _SplitKLinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = (dy2 @ weight).view(x.shape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
+            fused = _wgrad(dy2, x2, want_db)
+            if fused is not None:
+                return dx, fused[0].to(weight.dtype), (fused[1] if want_db else None)
             S = _pick_split(T)
             if S > 1 and dy2.is_contiguous() and x2.is_contiguous():
                 parts = torch.bmm(dy2.view(S, T // S, co).transpose(1, 2), x2.view(S, T // S, ci))
