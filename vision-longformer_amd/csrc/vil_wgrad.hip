@@ -65,24 +65,26 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradParams p) {
   int ld_row[2], ld_col[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) { const int c = tid + 256 * u; ld_row[u] = c >> 4; ld_col[u] = (c & 15) * 8; }
-  wg_u32x4 ra[2], rb[2];
-  auto gload = [&](int st) {
+  // two steps of global loads in flight per workgroup (register sets 0 / 1): with one, a step's compute
+  // (~0.2 us) had to cover a full HBM round trip and the kernel ran latency-bound at ~1 us per step
+  wg_u32x4 ra[2][2], rb[2][2];
+  auto gload = [&](int st, wg_u32x4 (&qa)[2], wg_u32x4 (&qb)[2]) {
     const int64_t t0 = t_begin + (int64_t)st * WG_ROWS;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int64_t t = t0 + ld_row[u];
       const wg_u32x4 z = {0u, 0u, 0u, 0u};
-      ra[u] = (t < t_end && co0 + ld_col[u] < p.CO) ? *(const wg_u32x4*)(p.dy + t * p.sdy + co0 + ld_col[u]) : z;
-      rb[u] = (t < t_end && ci0 + ld_col[u] < p.CI) ? *(const wg_u32x4*)(p.x + t * p.sx + ci0 + ld_col[u]) : z;
+      qa[u] = (t < t_end && co0 + ld_col[u] < p.CO) ? *(const wg_u32x4*)(p.dy + t * p.sdy + co0 + ld_col[u]) : z;
+      qb[u] = (t < t_end && ci0 + ld_col[u] < p.CI) ? *(const wg_u32x4*)(p.x + t * p.sx + ci0 + ld_col[u]) : z;
     }
   };
-  auto sstore = [&](int stage) {
+  auto sstore = [&](int stage, const wg_u32x4 (&qa)[2], const wg_u32x4 (&qb)[2]) {
     char* A = smem + stage * 2 * WG_TILE_BYTES;
     char* B = A + WG_TILE_BYTES;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      *(wg_u32x4*)(A + ld_row[u] * WG_PITCH + ld_col[u] * 2) = ra[u];
-      *(wg_u32x4*)(B + ld_row[u] * WG_PITCH + ld_col[u] * 2) = rb[u];
+      *(wg_u32x4*)(A + ld_row[u] * WG_PITCH + ld_col[u] * 2) = qa[u];
+      *(wg_u32x4*)(B + ld_row[u] * WG_PITCH + ld_col[u] * 2) = qb[u];
     }
   };
   // transposed-read offsets: lane (lj, lg) gets rows {4*lg + e} (first read) and {16 + 4*lg + e} (second)
@@ -99,11 +101,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradParams p) {
   float dbs[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_db = p.dbparts != nullptr && tci == 0 && cw == 0;
 
-  if (nsteps > 0) { gload(0); sstore(0); }
-  __syncthreads();
-  for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps) gload(st + 1);
-    const char* A = smem + (st & 1) * 2 * WG_TILE_BYTES;
+  auto compute = [&](int stage) {
+    const char* A = smem + stage * 2 * WG_TILE_BYTES;
     const char* B = A + WG_TILE_BYTES;
     wg_bf16x8 a[4], b[4];
 #pragma unroll
@@ -122,7 +121,22 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) dbs[i] += (float)a[i][e];
     }
-    if (st + 1 < nsteps) sstore((st + 1) & 1);
+  };
+  // step st computes from LDS stage st&1, stores step st+1 (register set (st+1)&1) and issues the loads of
+  // step st+2 into the register set it has just freed
+  if (nsteps > 0) gload(0, ra[0], rb[0]);
+  if (nsteps > 1) gload(1, ra[1], rb[1]);
+  if (nsteps > 0) sstore(0, ra[0], rb[0]);
+  __syncthreads();
+  for (int st = 0; st < nsteps; st += 2) {
+    if (st + 2 < nsteps) gload(st + 2, ra[0], rb[0]);
+    compute(0);
+    if (st + 1 < nsteps) sstore(1, ra[1], rb[1]);
+    __syncthreads();
+    if (st + 1 >= nsteps) break;
+    if (st + 3 < nsteps) gload(st + 3, ra[1], rb[1]);
+    compute(1);
+    if (st + 2 < nsteps) sstore(0, ra[0], rb[0]);
     __syncthreads();
   }
 
@@ -151,21 +165,32 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradParams p) {
   }
 }
 
-// dW / db = sum over the splits' partials: 4 consecutive elements per thread (16-byte loads), four splits
-// in flight.  (CO*CI is a multiple of 64.)
-__global__ void k_wgrad_reduce(WgradParams p) {
+// dW / db = sum over the splits' partials: block (64, 4): 4 consecutive elements per thread (16-byte loads),
+// the splits dealt over the 4 thread groups (four loads in flight each), LDS sum.  (CO*CI % 64 == 0.)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(WgradParams p) {
+  __shared__ wg_f32x4 red[4][64];
   const int64_t n = (int64_t)p.CO * p.CI, n4 = n >> 2;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + tx;
+  wg_f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i < n4) {
     const wg_f32x4* src = (const wg_f32x4*)p.parts + i;
-    wg_f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 3 < p.nsplit; k += 4) {
-      const wg_f32x4 v0 = src[(int64_t)k * n4], v1 = src[(int64_t)(k + 1) * n4];
-      const wg_f32x4 v2 = src[(int64_t)(k + 2) * n4], v3 = src[(int64_t)(k + 3) * n4];
+    int k = ty;
+    for (; k + 12 < p.nsplit; k += 16) {
+      const wg_f32x4 v0 = src[(int64_t)k * n4], v1 = src[(int64_t)(k + 4) * n4];
+      const wg_f32x4 v2 = src[(int64_t)(k + 8) * n4], v3 = src[(int64_t)(k + 12) * n4];
       s += (v0 + v1) + (v2 + v3);
     }
-    for (; k < p.nsplit; ++k) s += src[(int64_t)k * n4];
+    for (; k < p.nsplit; k += 4) s += src[(int64_t)k * n4];
+  } else if (p.dbparts && i < n4 + p.CO) {
+    const int c = (int)(i - n4);
+    for (int k = ty; k < p.nsplit; k += 4) s[0] += p.dbparts[(int64_t)k * p.CO + c];
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty != 0) return;
+  s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  if (i < n4) {
     if (p.out_bf16) {
       wg_bf16x4 o;
 #pragma unroll
@@ -174,16 +199,14 @@ __global__ void k_wgrad_reduce(WgradParams p) {
     } else ((wg_f32x4*)p.dw)[i] = s;
   } else if (p.dbparts && i < n4 + p.CO) {
     const int c = (int)(i - n4);
-    float s = 0.f;
-    for (int k = 0; k < p.nsplit; ++k) s += p.dbparts[(int64_t)k * p.CO + c];
-    if (p.out_bf16) ((vil_bf16*)p.db)[c] = vil_f2bf(s); else ((float*)p.db)[c] = s;
+    if (p.out_bf16) ((vil_bf16*)p.db)[c] = vil_f2bf(s[0]); else ((float*)p.db)[c] = s[0];
   }
 }
 
 static void wgrad_plan(int64_t T, int CO, int CI, int& tiles_co, int& tiles_ci, int& nsplit, int64_t& rps) {
   tiles_co = (CO + WG_TILE - 1) / WG_TILE; tiles_ci = (CI + WG_TILE - 1) / WG_TILE;
   const int tiles = tiles_co * tiles_ci;
-  int64_t s = ((384 + tiles - 1) / tiles + 7) / 8 * 8;           // ~1.5-2 workgroups per CU, whole XCD rounds
+  int64_t s = ((512 + tiles - 1) / tiles + 7) / 8 * 8;           // ~2 workgroups per CU, whole XCD rounds
   const int64_t max_by_rows = (T + 4 * WG_ROWS - 1) / (4 * WG_ROWS);   // >= 4 steps per workgroup
   const int64_t max_by_ws = ((int64_t)96 << 20) / ((int64_t)CO * CI * 4);
   if (s > max_by_rows) s = max_by_rows;
@@ -220,6 +243,6 @@ extern "C" int vil_linear_wgrad(const void* dy, const void* x, int64_t T, int CO
   int e = (int)hipGetLastError();
   if (e) return e;
   const int64_t n = (int64_t)CO * CI / 4 + (db ? CO : 0);
-  k_wgrad_reduce<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(p);
+  k_wgrad_reduce<<<dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s>>>(p);
   return (int)hipGetLastError();
 }
