@@ -136,6 +136,12 @@ def main():
                     for m_ in opt.master:
                         dist.broadcast(m_, 0)
             gstep = GraphedTrainStep(model, opt, *data.next(), world=world)
+            # pre-flight: a replayed step must behave like a training step (finite, sane loss) -- on this
+            # stack hipGraph replay mis-orders hipMemsetAsync nodes, which broke PyTorch's multi-block
+            # reductions before every such reduction was moved onto the library's kernels
+            pre = [float(gstep(*data.next())) for _ in range(4)]
+            if not all(v == v and 0.0 < v < 30.0 for v in pre):
+                raise RuntimeError(f"graph replay pre-flight losses {pre}")
         except Exception as exc:          # capture refused: every rank falls back to the eager DDP step together
             print(f"[rank {rank}] hipGraph capture failed ({exc!r}); falling back to the eager step", file=sys.stderr)
             ok = 0

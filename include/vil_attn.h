@@ -185,6 +185,9 @@ int vil_geom_bias_index(int W, int mode, int32_t* rel);
 size_t vil_colsum_workspace_bytes(int C);
 int vil_colsum_bf16(const void* x, int64_t rows, int C, int64_t row_stride, void* out, int out_bf16,
                     void* workspace, void* stream);
+/* same for an fp32 matrix (gradients that live on the fp32 residual stream: cls-token rows) */
+int vil_colsum_f32(const void* x, int64_t rows, int C, int64_t row_stride, void* out, int out_bf16,
+                   void* workspace, void* stream);
 
 /* ---- fused weight + bias gradient of a projection y = x W^T + b (autograd of nn.Linear; reference
  * msvit.py:91-120, 236-255, longformer2d.py:47-62): dW[co][ci] = sum_t dy[t][co] x[t][ci] (row-major

@@ -23,7 +23,7 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_attn_profile_begin", "vil_attn_profile_end", "vil_attn_kernel_name",
            "vil_layernorm_workspace_bytes", "vil_layernorm_fwd", "vil_layernorm_bwd",
            "vil_glo_attn_fwd", "vil_glo_attn_bwd", "vil_attn_bwd_full",
-           "vil_colsum_workspace_bytes", "vil_colsum_bf16",
+           "vil_colsum_workspace_bytes", "vil_colsum_bf16", "vil_colsum_f32",
            "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad")
 
 
@@ -89,6 +89,8 @@ def lib():
         L.vil_colsum_workspace_bytes.argtypes = [ctypes.c_int]
         L.vil_colsum_bf16.restype = ctypes.c_int
         L.vil_colsum_bf16.argtypes = [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, vp, ctypes.c_int, vp, vp]
+        L.vil_colsum_f32.restype = ctypes.c_int
+        L.vil_colsum_f32.argtypes = [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, vp, ctypes.c_int, vp, vp]
         L.vil_linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
         L.vil_linear_wgrad_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
         L.vil_linear_wgrad.restype = ctypes.c_int

@@ -831,6 +831,15 @@ __global__ void k_mfma_delta(VilParams p, unsigned* norm2) {
   }
 }
 
+// Zeroing is a KERNEL, not hipMemsetAsync: memset nodes of a captured hipGraph were observed (ROCm 7.2, gfx950)
+// to run out of order with their neighbouring kernel nodes on replay (tools/graph_op_check.py: maxima zeroed
+// after k_mfma_delta had written them -> garbage histogram scale).
+__global__ void k_zero_words(unsigned* a, int na, unsigned* b, int nb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < na) a[i] = 0u;
+  else if (i - na < nb) b[i - na] = 0u;
+}
+
 // ===================================================================== host side
 static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   memset(&bc, 0, sizeof(bc));
@@ -937,17 +946,16 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   k_mfma_table<<<dim3((c.tabsize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
-  e = (int)hipMemsetAsync(bc.norm2, 0, 4 * 32 * VIL_NORM_SLOTS, s);
-  if (e) return e;
+  {
+    const int na = 32 * VIL_NORM_SLOTS, nb = p.dg2l ? p.H * p.G : 0;
+    k_zero_words<<<dim3((na + nb + 255) / 256), dim3(256), 0, s>>>(bc.norm2, na, (unsigned*)p.dg2l, nb);
+    if ((e = (int)hipGetLastError())) return e;
+  }
   vil_prof_begin(VIL_K_DELTA, s, w.delta_bytes(), 0);
   BWD_SWITCH((k_mfma_delta<MD_><<<dim3((unsigned)((p.g.nx * p.g.ny * (MD_ == 4 ? 8 : (MD_ == 2 ? 4 : 2)) + 255) / 256), p.B * p.H), dim3(256), 0, s>>>(
       p, bc.do_hist ? bc.norm2 : nullptr)));
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
-  if (p.dg2l) {
-    e = (int)hipMemsetAsync(p.dg2l, 0, sizeof(float) * p.H * p.G, s);
-    if (e) return e;
-  }
   {
     const size_t lds = dq_lds(c, bc);
     vil_prof_begin(VIL_K_MFMA_DQ, s, w.dq_bytes(), w.dq_flops());

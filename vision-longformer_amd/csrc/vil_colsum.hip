@@ -7,12 +7,32 @@
 
 typedef __bf16 cs_bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef float cs_f32x4 __attribute__((ext_vector_type(4)));
+
 struct ColsumParams {
-  const __bf16* x; int64_t rows, stride; int C, tc, rpi, nblocks;
+  const void* x; int64_t rows, stride; int C, tc, rpi, nblocks;
   float* parts; void* out; int out_bf16;
 };
 
+template <typename T> struct CsLoad;
+template <> struct CsLoad<__bf16> {
+  static __device__ __forceinline__ void ld(const __bf16* p, float (&v)[8]) {
+    const cs_bf16x8 t = *(const cs_bf16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+  }
+};
+template <> struct CsLoad<float> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[8]) {
+    const cs_f32x4 a = *(const cs_f32x4*)p, b = *(const cs_f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+  }
+};
+
+template <typename T>
 __global__ __launch_bounds__(256) void k_colsum(ColsumParams p) {
+  const T* px = (const T*)p.x;
   __shared__ float red[256][9];
   const int tid = threadIdx.x;
   const int ci = tid % p.tc, r0 = tid / p.tc;          // column group, row lane
@@ -22,18 +42,19 @@ __global__ __launch_bounds__(256) void k_colsum(ColsumParams p) {
     const int64_t step = (int64_t)gridDim.x * p.rpi;
     int64_t r = (int64_t)blockIdx.x * p.rpi + r0;
     for (; r + 7 * step < p.rows; r += 8 * step) {     // eight independent 16-byte loads in flight
-      cs_bf16x8 v[8];
+      float v[8][8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *(const cs_bf16x8*)(p.x + (r + u * step) * p.stride + c0);
+      for (int u = 0; u < 8; ++u) CsLoad<T>::ld(px + (r + u * step) * p.stride + c0, v[u]);
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += (float)v[u][e];
+        for (int e = 0; e < 8; ++e) acc[e] += v[u][e];
     }
     for (; r < p.rows; r += step) {
-      const cs_bf16x8 v = *(const cs_bf16x8*)(p.x + r * p.stride + c0);
+      float v[8];
+      CsLoad<T>::ld(px + r * p.stride + c0, v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
   }
 #pragma unroll
@@ -75,13 +96,13 @@ __global__ __launch_bounds__(1024) void k_colsum_final(ColsumParams p) {
 
 extern "C" size_t vil_colsum_workspace_bytes(int C) { return (size_t)512 * (size_t)C * sizeof(float); }
 
-extern "C" int vil_colsum_bf16(const void* x, int64_t rows, int C, int64_t row_stride, void* out, int out_bf16,
-                               void* workspace, void* stream) {
+static int colsum_launch(const void* x, int in_f32, int64_t rows, int C, int64_t row_stride, void* out, int out_bf16,
+                         void* workspace, void* stream) {
   if (!x || !out || !workspace) return VIL_E_NULL;
   if (rows <= 0 || C <= 0) return VIL_E_SHAPE;
   if ((C & 7) || (row_stride & 7) || ((uintptr_t)x & 15)) return VIL_E_ALIGN;
   ColsumParams p;
-  p.x = (const __bf16*)x; p.rows = rows; p.stride = row_stride; p.C = C;
+  p.x = x; p.rows = rows; p.stride = row_stride; p.C = C;
   const int tcols = C / 8;
   p.tc = tcols < 256 ? tcols : 256;
   p.rpi = 256 / p.tc;
@@ -89,9 +110,20 @@ extern "C" int vil_colsum_bf16(const void* x, int64_t rows, int C, int64_t row_s
   p.nblocks = (int)(need < 512 ? (need < 1 ? 1 : need) : 512);
   p.parts = (float*)workspace; p.out = out; p.out_bf16 = out_bf16;
   hipStream_t s = (hipStream_t)stream;
-  k_colsum<<<dim3(p.nblocks, (tcols + 255) / 256), dim3(256), 0, s>>>(p);
+  if (in_f32) k_colsum<float><<<dim3(p.nblocks, (tcols + 255) / 256), dim3(256), 0, s>>>(p);
+  else k_colsum<__bf16><<<dim3(p.nblocks, (tcols + 255) / 256), dim3(256), 0, s>>>(p);
   int e = (int)hipGetLastError();
   if (e) return e;
   k_colsum_final<<<dim3((C + 63) / 64), dim3(1024), 0, s>>>(p);
   return (int)hipGetLastError();
+}
+
+extern "C" int vil_colsum_bf16(const void* x, int64_t rows, int C, int64_t row_stride, void* out, int out_bf16,
+                               void* workspace, void* stream) {
+  return colsum_launch(x, 0, rows, C, row_stride, out, out_bf16, workspace, stream);
+}
+
+extern "C" int vil_colsum_f32(const void* x, int64_t rows, int C, int64_t row_stride, void* out, int out_bf16,
+                              void* workspace, void* stream) {
+  return colsum_launch(x, 1, rows, C, row_stride, out, out_bf16, workspace, stream);
 }

@@ -23,10 +23,13 @@ _CS_WS = {}
 
 
 def _colsum(dy2):
-    """db = dy2.sum(0) through libvilattn's HBM-rate column-sum kernel (bf16, C % 8 == 0)."""
+    """dy2.sum(0) through libvilattn's HBM-rate column-sum kernels (bf16 or fp32 rows, C % 8 == 0).  Also the
+    only column sum that is safe inside a captured hipGraph on this stack: PyTorch's multi-block reductions
+    zero a semaphore buffer with hipMemsetAsync, and memset nodes were observed to run out of order on replay
+    (tools/graph_reduce_check.py: wrong sums in 199 of 200 replays for a (1600, 2304) bias gradient)."""
     T, co = dy2.shape
-    if not (dy2.is_cuda and dy2.dtype == torch.bfloat16 and co % 8 == 0 and dy2.stride(1) == 1
-            and dy2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0):
+    if not (dy2.is_cuda and dy2.dtype in (torch.bfloat16, torch.float32) and co % 8 == 0 and dy2.stride(1) == 1
+            and dy2.stride(0) % 8 == 0 and dy2.data_ptr() % 16 == 0 and T >= 1):
         return dy2.sum(0)
     import ctypes
     from . import _lib
@@ -35,11 +38,12 @@ def _colsum(dy2):
     ws = _CS_WS.get(key)
     if ws is None:
         ws = _CS_WS[key] = torch.empty(L.vil_colsum_workspace_bytes(co) // 4, dtype=torch.float32, device=dy2.device)
-    out = torch.empty(co, dtype=torch.bfloat16, device=dy2.device)
-    with torch.cuda.device(dy2.device):
-        _lib.check(L.vil_colsum_bf16(ctypes.c_void_p(dy2.data_ptr()), T, co, dy2.stride(0),
-                                     ctypes.c_void_p(out.data_ptr()), 1, ctypes.c_void_p(ws.data_ptr()),
-                                     ctypes.c_void_p(torch.cuda.current_stream(dy2.device).cuda_stream)))
+    f32 = dy2.dtype == torch.float32
+    out = torch.empty(co, dtype=dy2.dtype, device=dy2.device)
+    fn = L.vil_colsum_f32 if f32 else L.vil_colsum_bf16
+    _lib.check(fn(ctypes.c_void_p(dy2.data_ptr()), T, co, dy2.stride(0), ctypes.c_void_p(out.data_ptr()),
+                  0 if f32 else 1, ctypes.c_void_p(ws.data_ptr()),
+                  ctypes.c_void_p(torch.cuda.current_stream(dy2.device).cuda_stream)))
     return out
 
 
@@ -95,7 +99,7 @@ class _SplitKLinearFn(torch.autograd.Function):
             fused = _wgrad(dy2, x2, want_db)
             if fused is not None:
                 return dx, fused[0].to(weight.dtype), (fused[1] if want_db else None)
-            S = _pick_split(T)
+            S = _pick_split(T) if T >= 4096 else 1
             if S > 1 and dy2.is_contiguous() and x2.is_contiguous():
                 parts = torch.bmm(dy2.view(S, T // S, co).transpose(1, 2), x2.view(S, T // S, ci))
                 dw = parts.sum(0, dtype=torch.float32).to(weight.dtype)
@@ -106,15 +110,43 @@ class _SplitKLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+def vil_linear(x, weight, bias):
+    """F.linear with the library's weight / bias gradient on device tensors (any number of tokens: every bias
+    gradient must stay off PyTorch's multi-block reductions, see _colsum)."""
+    if x.is_cuda and torch.is_grad_enabled():
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            # autocast semantics of nn.Linear: inputs and parameters in the autocast dtype
+            x, w = x.to(dt), weight.to(dt)
+            b = bias.to(dt) if bias is not None else None
+            with torch.autocast("cuda", enabled=False):
+                return _SplitKLinearFn.apply(x, w, b)
+        return _SplitKLinearFn.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
 class VilLinear(nn.Linear):
     def forward(self, x):
-        if x.is_cuda and x.numel() // x.shape[-1] >= 4096 and torch.is_grad_enabled():
-            if torch.is_autocast_enabled("cuda"):
-                dt = torch.get_autocast_dtype("cuda")
-                # autocast semantics of nn.Linear: inputs and parameters in the autocast dtype
-                x, w = x.to(dt), self.weight.to(dt)
-                b = self.bias.to(dt) if self.bias is not None else None
-                with torch.autocast("cuda", enabled=False):
-                    return _SplitKLinearFn.apply(x, w, b)
-            return _SplitKLinearFn.apply(x, self.weight, self.bias)
-        return super().forward(x)
+        return vil_linear(x, self.weight, self.bias)
+
+
+class _ExpandRows(torch.autograd.Function):
+    """t (1, G, C) -> (B, G, C) (the cls tokens prepended to every image, msvit.py:198); the backward's sum
+    over the batch is a column sum of the (B, G*C) gradient."""
+
+    @staticmethod
+    def forward(ctx, t, B):
+        ctx.shape = t.shape
+        return t.expand(B, -1, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        B = g.shape[0]
+        g2 = g.reshape(B, -1)
+        if g2.stride(-1) != 1:
+            g2 = g2.contiguous()
+        return _colsum(g2).view(ctx.shape), None
+
+
+def expand_rows(t, B):
+    return _ExpandRows.apply(t, B) if t.is_cuda else t.expand(B, -1, -1)

@@ -18,7 +18,7 @@ from torch import nn
 from .longformer2d import Long2DSCSelfAttention, _trunc_normal_
 from .ops import vil_dense_attention, FULL_MAX_G
 from .layernorm import VilLayerNorm
-from .linear import VilLinear
+from .linear import VilLinear, vil_linear, expand_rows
 
 
 class DropPath(nn.Module):
@@ -186,15 +186,31 @@ class PatchEmbed(nn.Module):
                 _trunc_normal_(t, .02)
         self.pos_drop = nn.Dropout(p=drop_rate)
 
+    def _embed(self, img):
+        """The strided conv of non-overlapping patches IS a Linear over (c, py, px) patch vectors: on the device
+        it runs as one GEMM with the library's weight/bias gradient (token-major output, no transpose; and no
+        multi-block bias-gradient reduction, which hipGraph replay gets wrong on this stack)."""
+        ph, pw = self.patch_size
+        B, Cin, Hh, Ww = img.shape
+        if not img.is_cuda or Hh % ph or Ww % pw or (Cin * ph * pw) % 8 or self.proj.out_channels % 8:
+            x = self.proj(img)
+            nx, ny = x.shape[2], x.shape[3]
+            return x.flatten(2).transpose(1, 2), nx, ny
+        nx, ny = Hh // ph, Ww // pw
+        if torch.is_autocast_enabled("cuda"):
+            img = img.to(torch.get_autocast_dtype("cuda"))
+        patches = img.view(B, Cin, nx, ph, ny, pw).permute(0, 2, 4, 1, 3, 5).reshape(B * nx * ny, Cin * ph * pw)
+        y = vil_linear(patches, self.proj.weight.view(self.proj.out_channels, -1), self.proj.bias)
+        return y.view(B, nx * ny, -1), nx, ny
+
     def forward(self, xtuple):
-        x = self.proj(xtuple[0])
-        B, _, nx, ny = x.shape
+        x, nx, ny = self._embed(xtuple[0])
+        B = x.shape[0]
         assert nx == self.nx and ny == self.ny, "Fix input size!"
-        x = x.flatten(2).transpose(1, 2)
         if self.norm_embed is not None:
             x = self.norm_embed(x)
         if self.cls_token is not None:
-            x = torch.cat((self.cls_token.expand(B, -1, -1).to(x.dtype), x), dim=1)
+            x = torch.cat((expand_rows(self.cls_token, B).to(x.dtype), x), dim=1)
         if self.ape:
             grid = torch.cat([self.x_pos_embed.unsqueeze(2).expand(-1, -1, ny, -1),
                               self.y_pos_embed.unsqueeze(1).expand(-1, nx, -1, -1)], dim=-1).flatten(1, 2)
@@ -236,7 +252,7 @@ class MlpBlock(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio), out_dim, act_layer=act_layer, drop=drop)
         self.shortcut = nn.Identity()
         if out_dim is not None and out_dim != dim:
-            self.shortcut = nn.Sequential(nn.Linear(dim, out_dim), nn.Dropout(drop))
+            self.shortcut = nn.Sequential(VilLinear(dim, out_dim), nn.Dropout(drop))
 
     def forward(self, xtuple):
         x, nx, ny = xtuple
@@ -299,7 +315,7 @@ class MsViT(nn.Module):
         if self.num_layers == 3:
             self.layer4 = None
         self.norm = norm_layer(self.out_planes)
-        self.head = nn.Linear(self.out_planes, num_classes) if num_classes > 0 else nn.Identity()
+        self.head = VilLinear(self.out_planes, num_classes) if num_classes > 0 else nn.Identity()
         self.apply(self._init_weights)
 
     @staticmethod
