@@ -198,6 +198,19 @@ size_t vil_linear_wgrad_workspace_bytes(int64_t T, int CO, int CI);
 int vil_linear_wgrad(const void* dy, const void* x, int64_t T, int CO, int CI, int64_t dy_stride, int64_t x_stride,
                      void* dw, void* db, int out_bf16, void* workspace, void* stream);
 
+/* ---- fused residual add + LayerNorm on the fp32 residual stream (block glue of msvit.py:313-316,336-340:
+ * `x = x + drop_path(branch)` of one block fused with `norm(x)` of the next).  Contiguous (rows, C) tensors.
+ *   forward : x_out = x + rscale[row / rows_per_sample] * res  (rscale NULL: 1);  y = LN(x_out)
+ *   backward: dx = gres (NULL: 0) + LNbwd(dy);  gbranch = rscale[...] * dx in the branch's dtype
+ * (dx is the gradient of x AND of x_out's producer; gbranch the gradient of res). */
+int vil_resln_fwd(const float* x, const void* res, int res_dtype, const float* rscale, int64_t rows_per_sample,
+                  const float* gamma, const float* beta, float* x_out, void* y, int y_dtype,
+                  float* mean, float* rstd, int64_t rows, int C, float eps, void* stream);
+int vil_resln_bwd(const void* dy, int dy_dtype, const float* gres, const float* x, const float* gamma,
+                  const float* mean, const float* rstd, const float* rscale, int64_t rows_per_sample,
+                  float* dx, void* gbranch, int gb_dtype, float* dgamma, float* dbeta, void* workspace,
+                  int64_t rows, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

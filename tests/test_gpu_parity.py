@@ -565,3 +565,40 @@ def test_graphed_train_step_vil_small_shapes(dev):
     assert all(math.isfinite(v) for v in lg)
     # bf16 training from the same state: the trajectories separate slowly (atomics order), not by O(1)
     assert abs(le[0] - lg[0]) < 1e-2 and max(abs(a - b) for a, b in zip(le, lg)) < 0.5
+
+
+@pytest.mark.parametrize("B,N,C,bdt", [(4, 197, 384, torch.bfloat16), (2, 50, 768, torch.bfloat16), (3, 785, 192, torch.float32),
+                                        (2, 3137, 96, torch.bfloat16)])
+def test_residual_layernorm_fused(dev, B, N, C, bdt):
+    """vil_resln_fwd/_bwd: (x + s*branch, LN(x + s*branch)) and all gradients against fp64."""
+    from vision_longformer_amd.layernorm import VilLayerNorm, res_layernorm
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, N, C, generator=g)
+    br = torch.randn(B, N, C, generator=g).to(bdt).float()
+    sc = torch.tensor([0.0, 1.25, 1.25, 0.0][:B])
+    ln = VilLayerNorm(C, eps=1e-6).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * torch.randn(C, generator=g)); ln.bias.copy_(0.1 * torch.randn(C, generator=g))
+    gx = torch.randn(B, N, C, generator=g)
+    gy = torch.randn(B, N, C, generator=g).bfloat16().float()
+    # fp64 reference
+    xr, brr = x.double().requires_grad_(True), br.double().requires_grad_(True)
+    wr, b_r = ln.weight.detach().double().cpu().requires_grad_(True), ln.bias.detach().double().cpu().requires_grad_(True)
+    xn_r = xr + sc.double().view(B, 1, 1) * brr
+    y_r = torch.nn.functional.layer_norm(xn_r, (C,), wr, b_r, 1e-6)
+    ((xn_r * gx.double()).sum() + (y_r * gy.double()).sum()).backward()
+    # fused
+    xd, brd = x.to(dev).requires_grad_(True), br.to(dev, bdt).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        xn, y = res_layernorm(xd, brd, sc.to(dev), ln)
+    assert y.dtype == torch.bfloat16 and xn.dtype == torch.float32
+    ((xn * gx.to(dev)).sum() + (y.float() * gy.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(xn.detach().double().cpu(), xn_r.detach(), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(y.detach().double().cpu(), y_r.detach(), atol=3e-2, rtol=1e-2)
+    torch.testing.assert_close(xd.grad.double().cpu(), xr.grad, atol=1e-4, rtol=1e-4)
+    tolb = dict(atol=2e-2, rtol=1e-2) if bdt == torch.bfloat16 else dict(atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(brd.grad.double().cpu(), brr.grad, **tolb)
+    gs = float(wr.grad.abs().max())
+    torch.testing.assert_close(ln.weight.grad.double().cpu(), wr.grad, atol=2e-3 * gs, rtol=2e-3)
+    torch.testing.assert_close(ln.bias.grad.double().cpu(), b_r.grad, atol=2e-3 * float(b_r.grad.abs().max()), rtol=2e-3)

@@ -24,7 +24,8 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_layernorm_workspace_bytes", "vil_layernorm_fwd", "vil_layernorm_bwd",
            "vil_glo_attn_fwd", "vil_glo_attn_bwd", "vil_attn_bwd_full",
            "vil_colsum_workspace_bytes", "vil_colsum_bf16", "vil_colsum_f32",
-           "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad")
+           "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad",
+           "vil_resln_fwd", "vil_resln_bwd")
 
 
 class VilAttnDesc(ctypes.Structure):
@@ -96,6 +97,12 @@ def lib():
         L.vil_linear_wgrad.restype = ctypes.c_int
         L.vil_linear_wgrad.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                        vp, vp, ctypes.c_int, vp, vp]
+        L.vil_resln_fwd.restype = ctypes.c_int
+        L.vil_resln_fwd.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int64, vp, vp, vp, vp, ctypes.c_int, vp, vp,
+                                    ctypes.c_int64, ctypes.c_int, ctypes.c_float, vp]
+        L.vil_resln_bwd.restype = ctypes.c_int
+        L.vil_resln_bwd.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_int64, vp, vp, ctypes.c_int, vp, vp, vp,
+                                    ctypes.c_int64, ctypes.c_int, vp]
         L.vil_layernorm_workspace_bytes.restype = ctypes.c_size_t
         L.vil_layernorm_workspace_bytes.argtypes = [i64, ctypes.c_int]
         L.vil_layernorm_fwd.restype = ctypes.c_int

@@ -60,6 +60,13 @@ struct LNParams {
   int64_t rows, x_rs, y_rs, dy_rs, dx_rs;
   int C, nblocks;
   float eps;
+  // fused residual (vil_resln_*): forward x' = x + rscale[row / rps] * res, y = LN(x'), x' written to xout;
+  // backward dx = gres + LNbwd(dy) and gbranch = rscale[row / rps] * dx in the branch's dtype
+  const void* res; int res_bf16; int64_t res_rs;
+  const float* rscale; int64_t rps;
+  float* xout; int64_t xout_rs;
+  const float* gres; int64_t gres_rs;
+  void* gbranch; int gb_bf16; int64_t gb_rs;
 };
 
 template <typename TI, typename TO, int LPR, int NIT>
@@ -73,8 +80,18 @@ __global__ __launch_bounds__(256) void k_ln_fwd(LNParams p) {
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int e0 = (it * LPR + sub) * 8;
-    if (rok && e0 < p.C) LNIO<TI>::ld8((const TI*)p.x + row * p.x_rs + e0, v[it]);
-    else {
+    if (rok && e0 < p.C) {
+      LNIO<TI>::ld8((const TI*)p.x + row * p.x_rs + e0, v[it]);
+      if (p.res) {                     // fused residual add (stochastic-depth scale per sample)
+        float r[8];
+        if (p.res_bf16) LNIO<vil_bf16>::ld8((const vil_bf16*)p.res + row * p.res_rs + e0, r);
+        else LNIO<float>::ld8((const float*)p.res + row * p.res_rs + e0, r);
+        const float sc = p.rscale ? p.rscale[row / p.rps] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[it][i] = fmaf(sc, r[i], v[it][i]);
+        LNIO<float>::st8(p.xout + row * p.xout_rs + e0, v[it]);
+      }
+    } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[it][i] = 0.f;
     }
@@ -158,7 +175,21 @@ __global__ __launch_bounds__(256) void k_ln_bwd(LNParams p) {
           float o[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] = rstd * (g[it][i] - m1 - xh[it][i] * m2);
+          if (p.gres) {                // + the gradient arriving on the residual stream
+            float r[8];
+            LNIO<float>::ld8(p.gres + row * p.gres_rs + e0, r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] += r[i];
+          }
           LNIO<TO>::st8((TO*)p.dx + row * p.dx_rs + e0, o);
+          if (p.gbranch) {             // gradient of the branch that was added in the forward
+            const float sc = p.rscale ? p.rscale[row / p.rps] : 1.0f;
+            float b[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) b[i] = o[i] * sc;
+            if (p.gb_bf16) LNIO<vil_bf16>::st8((vil_bf16*)p.gbranch + row * p.gb_rs + e0, b);
+            else LNIO<float>::st8((float*)p.gbranch + row * p.gb_rs + e0, b);
+          }
         }
       }
     }
@@ -228,6 +259,9 @@ extern "C" size_t vil_layernorm_workspace_bytes(int64_t rows, int C) {
   else if (C_ <= 512) { constexpr int LPR = 64, NIT = 1; __VA_ARGS__; }       \
   else { constexpr int LPR = 64, NIT = 2; __VA_ARGS__; }
 
+static int ln_fwd_launch(LNParams& p, int x_dtype, int y_dtype, hipStream_t s);
+static int ln_bwd_launch(LNParams& p, int x_dtype, int dy_dtype, hipStream_t s);
+
 extern "C" int vil_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
                                  void* y, int y_dtype, float* mean, float* rstd, int64_t rows, int C,
                                  int64_t x_row_stride, int64_t y_row_stride, float eps, void* stream) {
@@ -238,7 +272,11 @@ extern "C" int vil_layernorm_fwd(const void* x, int x_dtype, const float* gamma,
   LNParams p; memset(&p, 0, sizeof(p));
   p.x = x; p.y = y; p.gamma = gamma; p.beta = beta; p.mean = mean; p.rstd = rstd;
   p.rows = rows; p.C = C; p.x_rs = x_row_stride; p.y_rs = y_row_stride; p.eps = eps;
-  hipStream_t s = (hipStream_t)stream;
+  return ln_fwd_launch(p, x_dtype, y_dtype, (hipStream_t)stream);
+}
+
+static int ln_fwd_launch(LNParams& p, int x_dtype, int y_dtype, hipStream_t s) {
+  const int64_t rows = p.rows; const int C = p.C;
   const int key = x_dtype * 2 + y_dtype;
   LN_SHAPE_SWITCH(C, {
     const unsigned grid = (unsigned)((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)));
@@ -265,8 +303,13 @@ extern "C" int vil_layernorm_bwd(const void* dy, int dy_dtype, const void* x, in
   p.dy = dy; p.x = x; p.gamma = gamma; p.mean = (float*)mean; p.rstd = (float*)rstd; p.dx = dx;
   p.dgamma = dgamma; p.dbeta = dbeta; p.parts = (float*)workspace;
   p.rows = rows; p.C = C; p.dy_rs = dy_row_stride; p.x_rs = x_row_stride; p.dx_rs = dx_row_stride;
-  hipStream_t s = (hipStream_t)stream;
   if (dx_dtype != x_dtype) return VIL_E_DTYPE;       // dx has the dtype of x
+  return ln_bwd_launch(p, x_dtype, dy_dtype, (hipStream_t)stream);
+}
+
+static int ln_bwd_launch(LNParams& p, int x_dtype, int dy_dtype, hipStream_t s) {
+  const int64_t rows = p.rows; const int C = p.C;
+  int e;
   const int key = x_dtype * 2 + dy_dtype;
   LN_SHAPE_SWITCH(C, {
     p.nblocks = ln_blocks(rows, 64 / LPR);
@@ -282,4 +325,39 @@ extern "C" int vil_layernorm_bwd(const void* dy, int dy_dtype, const void* x, in
   if (e) return e;
   k_ln_reduce<<<dim3((2 * C + 63) / 64), dim3(1024), 0, s>>>(p);
   return (int)hipGetLastError();
+}
+
+// ---- fused residual + LayerNorm on the fp32 residual stream (contiguous rows)
+extern "C" int vil_resln_fwd(const float* x, const void* res, int res_dtype, const float* rscale, int64_t rows_per_sample,
+                             const float* gamma, const float* beta, float* x_out, void* y, int y_dtype,
+                             float* mean, float* rstd, int64_t rows, int C, float eps, void* stream) {
+  if (!x || !res || !gamma || !beta || !x_out || !y || !mean || !rstd) return VIL_E_NULL;
+  int e = ln_check(rows, C, C, C);
+  if (e) return e;
+  if (rows_per_sample <= 0) return VIL_E_SHAPE;
+  if (((uintptr_t)x | (uintptr_t)res | (uintptr_t)x_out | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return VIL_E_ALIGN;
+  LNParams p; memset(&p, 0, sizeof(p));
+  p.x = x; p.y = y; p.gamma = gamma; p.beta = beta; p.mean = mean; p.rstd = rstd;
+  p.rows = rows; p.C = C; p.x_rs = C; p.y_rs = C; p.eps = eps;
+  p.res = res; p.res_bf16 = res_dtype == VIL_DTYPE_BF16; p.res_rs = C; p.rscale = rscale; p.rps = rows_per_sample;
+  p.xout = x_out; p.xout_rs = C;
+  return ln_fwd_launch(p, VIL_DTYPE_F32, y_dtype, (hipStream_t)stream);
+}
+
+extern "C" int vil_resln_bwd(const void* dy, int dy_dtype, const float* gres, const float* x, const float* gamma,
+                             const float* mean, const float* rstd, const float* rscale, int64_t rows_per_sample,
+                             float* dx, void* gbranch, int gb_dtype, float* dgamma, float* dbeta, void* workspace,
+                             int64_t rows, int C, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !gbranch || !dgamma || !dbeta || !workspace) return VIL_E_NULL;
+  int e = ln_check(rows, C, C, C);
+  if (e) return e;
+  if (rows_per_sample <= 0) return VIL_E_SHAPE;
+  if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)gres | (uintptr_t)gbranch) & 15) return VIL_E_ALIGN;
+  LNParams p; memset(&p, 0, sizeof(p));
+  p.dy = dy; p.x = x; p.gamma = gamma; p.mean = (float*)mean; p.rstd = (float*)rstd; p.dx = dx;
+  p.dgamma = dgamma; p.dbeta = dbeta; p.parts = (float*)workspace;
+  p.rows = rows; p.C = C; p.dy_rs = C; p.x_rs = C; p.dx_rs = C;
+  p.gres = gres; p.gres_rs = C; p.gbranch = gbranch; p.gb_bf16 = gb_dtype == VIL_DTYPE_BF16; p.gb_rs = C;
+  p.rscale = rscale; p.rps = rows_per_sample;
+  return ln_bwd_launch(p, VIL_DTYPE_F32, dy_dtype, (hipStream_t)stream);
 }

@@ -64,6 +64,82 @@ class _FusedLN(torch.autograd.Function):
         return dx.view(ctx.x_shape), dgamma.to(ctx.wdtype), dbeta.to(ctx.wdtype), None, None
 
 
+class _ResLN(torch.autograd.Function):
+    """x_new = x + rscale[b] * branch;  y = LayerNorm(x_new)   (vil_resln_fwd / _bwd).
+    One kernel each way for the residual add of one block and the norm of the next; the backward also
+    emits the branch gradient (stochastic-depth scale and cast included), so the add / mul / cast kernels
+    of the unfused graph disappear."""
+
+    @staticmethod
+    def forward(ctx, x, branch, rscale, weight, bias, eps, out_dtype):
+        L = _lib.lib()
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        br2 = branch.reshape(-1, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        if not br2.is_contiguous():
+            br2 = br2.contiguous()
+        rows = x2.shape[0]
+        rps = rows // x.shape[0]
+        w = weight.detach().float().contiguous()
+        b = bias.detach().float().contiguous()
+        xn = torch.empty(rows, C, dtype=torch.float32, device=x.device)
+        y = torch.empty(rows, C, dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(L.vil_resln_fwd(_p(x2), _p(br2), _DT[br2.dtype], _p(rscale) if rscale is not None else None, rps,
+                                   _p(w), _p(b), _p(xn), _p(y), _DT[out_dtype], _p(mean), _p(rstd), rows, C,
+                                   float(eps), stream))
+        ctx.save_for_backward(xn, w, mean, rstd, rscale)
+        ctx.shape, ctx.wdtype, ctx.bdtype, ctx.rps = x.shape, weight.dtype, branch.dtype, rps
+        return xn.view(x.shape), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g_x, g_y):
+        xn, w, mean, rstd, rscale = ctx.saved_tensors
+        L = _lib.lib()
+        rows, C = xn.shape
+        if g_y is None:
+            g_y = torch.zeros(rows, C, dtype=torch.bfloat16, device=xn.device)
+        dy2 = g_y.reshape(rows, C)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        if dy2.dtype not in _DT:
+            dy2 = dy2.float()
+        gres = None
+        if g_x is not None:
+            gres = g_x.reshape(rows, C)
+            if gres.dtype != torch.float32 or not gres.is_contiguous():
+                gres = gres.float().contiguous()
+        dx = torch.empty(rows, C, dtype=torch.float32, device=xn.device)
+        gb = torch.empty(rows, C, dtype=ctx.bdtype, device=xn.device)
+        dgamma = torch.empty(C, dtype=torch.float32, device=xn.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=xn.device)
+        ws = torch.empty(L.vil_layernorm_workspace_bytes(rows, C) // 4, dtype=torch.float32, device=xn.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(xn.device).cuda_stream)
+        _lib.check(L.vil_resln_bwd(_p(dy2), _DT[dy2.dtype], _p(gres) if gres is not None else None, _p(xn), _p(w),
+                                   _p(mean), _p(rstd), _p(rscale) if rscale is not None else None, ctx.rps,
+                                   _p(dx), _p(gb), _DT[gb.dtype], _p(dgamma), _p(dbeta), _p(ws), rows, C, stream))
+        return (dx.view(ctx.shape), gb.view(ctx.shape), None, dgamma.to(ctx.wdtype), dbeta.to(ctx.wdtype), None, None)
+
+
+def res_layernorm_ok(x, branch, norm):
+    C = x.shape[-1]
+    return (isinstance(norm, VilLayerNorm) and x.is_cuda and x.dtype == torch.float32 and branch.dtype in _DT
+            and branch.shape == x.shape and C % 8 == 0 and C <= 1024 and norm.elementwise_affine and norm.bias is not None)
+
+
+def res_layernorm(x, branch, rscale, norm):
+    """(x + rscale * branch, norm(x + rscale * branch)) with `norm` a VilLayerNorm; rscale (B,) fp32 or None."""
+    out_dtype = x.dtype
+    if torch.is_autocast_enabled("cuda"):
+        ac = torch.get_autocast_dtype("cuda")
+        out_dtype = ac if (norm.cast_output and ac in _DT) else torch.float32
+    return _ResLN.apply(x, branch, rscale, norm.weight, norm.bias, norm.eps, out_dtype)
+
+
 class VilLayerNorm(nn.LayerNorm):
     """cast_output=True: under autocast emit the autocast dtype (the consumer is a GEMM);
     False: keep the residual-stream dtype (PatchEmbed's norm_embed)."""

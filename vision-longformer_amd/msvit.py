@@ -17,7 +17,7 @@ from torch import nn
 
 from .longformer2d import Long2DSCSelfAttention, _trunc_normal_
 from .ops import vil_dense_attention, FULL_MAX_G
-from .layernorm import VilLayerNorm
+from .layernorm import VilLayerNorm, res_layernorm, res_layernorm_ok
 from .linear import VilLinear, vil_linear, expand_rows
 
 
@@ -335,15 +335,61 @@ class MsViT(nn.Module):
     def get_classifier(self):
         return self.head
 
+    @staticmethod
+    def _drop_scale(blk, B, device):
+        p = blk.drop_path.drop_prob if isinstance(blk.drop_path, DropPath) else 0.0
+        if p == 0.0 or not blk.training:
+            return None
+        return torch.empty(B, dtype=torch.float32, device=device).bernoulli_(1.0 - p).div_(1.0 - p)
+
+    @staticmethod
+    def _settle(x, pend):
+        """materialise a deferred `x + drop_path(branch)`"""
+        if pend is None:
+            return x
+        br, sc = pend
+        return x + br if sc is None else _DropPathAdd.apply(x, br, sc.view(-1, 1, 1).to(x.dtype))
+
+    def _run_stage(self, layer, xtuple):
+        """One stage with the residual add of every block DEFERRED into the next block's LayerNorm
+        (vil_resln_*: one kernel each way instead of add + norm, and norm-backward + add + mask-mul + cast).
+        Same arithmetic as `layer(xtuple)` (msvit.py:313-316,336-340); returns the last add still pending."""
+        x, nx, ny = layer[0](xtuple)
+        B = x.shape[0]
+        pend = None
+        for blk in list(layer)[1:]:
+            attn = isinstance(blk, AttnBlock)
+            if not (attn or (isinstance(blk, MlpBlock) and isinstance(blk.shortcut, nn.Identity))):
+                x, nx, ny = blk((self._settle(x, pend), nx, ny))
+                pend = None
+                continue
+            if pend is not None and res_layernorm_ok(x, pend[0], blk.norm):
+                x, y = res_layernorm(x, pend[0], pend[1], blk.norm)
+            else:
+                x = self._settle(x, pend)
+                y = blk.norm(x)
+            br = blk.attn(y, nx, ny) if attn else blk.mlp(y)
+            pend = (br, self._drop_scale(blk, B, x.device))
+        return x, pend, nx, ny
+
     def forward_features(self, x):
         B = x.shape[0]
         nx = ny = None
+        pend = None
         for i in range(self.num_layers):
             layer = getattr(self, "layer%d" % (i + 1))
             if i > 0:   # drop the previous stage's global tokens, back to an image
+                x = self._settle(x, pend)
                 x = x[:, self.Nglos[i - 1]:].transpose(-2, -1).reshape(B, -1, nx, ny)
-            x, nx, ny = layer((x, nx, ny))
-        x = self.norm(x)
+            if x.is_cuda:
+                x, pend, nx, ny = self._run_stage(layer, (x, nx, ny))
+            else:
+                x, nx, ny = layer((x, nx, ny))
+                pend = None
+        if pend is not None and res_layernorm_ok(x, pend[0], self.norm):
+            _, x = res_layernorm(x, pend[0], pend[1], self.norm)
+        else:
+            x = self.norm(self._settle(x, pend))
         if self.Nglos[-1] > 0 and not self.avg_pool:
             return x[:, 0]
         return torch.mean(x, dim=1)
