@@ -203,8 +203,30 @@ class PatchEmbed(nn.Module):
         y = vil_linear(patches, self.proj.weight.view(self.proj.out_channels, -1), self.proj.bias)
         return y.view(B, nx * ny, -1), nx, ny
 
-    def forward(self, xtuple):
-        x, nx, ny = self._embed(xtuple[0])
+    def _embed_tokens(self, xt, pnx, pny):
+        """Same projection fed from the previous stage's TOKEN-major output (B, pnx*pny, Cin): the patch
+        vectors are gathered in (py, px, c) order with one cast+permute copy (contiguous Cin-chunks) and the
+        weight is permuted to match, instead of materialising the (B, Cin, pnx, pny) image first."""
+        ph, pw = self.patch_size
+        B, _, Cin = xt.shape
+        nx, ny = pnx // ph, pny // pw
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else xt.dtype
+        pv = xt.reshape(B, nx, ph, ny, pw, Cin).permute(0, 1, 3, 2, 4, 5)
+        patches = pv.contiguous() if xt.dtype == dt else pv.to(dtype=dt, memory_format=torch.contiguous_format)
+        w = self.proj.weight.permute(0, 2, 3, 1).reshape(self.proj.out_channels, ph * pw * Cin)
+        y = vil_linear(patches.reshape(B * nx * ny, ph * pw * Cin), w, self.proj.bias)
+        return y.view(B, nx * ny, -1), nx, ny
+
+    def tokens_ok(self, xt, pnx, pny):
+        ph, pw = self.patch_size
+        return (xt.is_cuda and pnx % ph == 0 and pny % pw == 0 and (xt.shape[-1] * ph * pw) % 8 == 0
+                and self.proj.out_channels % 8 == 0)
+
+    def forward(self, xtuple, tokens=False):
+        if tokens:
+            x, nx, ny = self._embed_tokens(*xtuple)
+        else:
+            x, nx, ny = self._embed(xtuple[0])
         B = x.shape[0]
         assert nx == self.nx and ny == self.ny, "Fix input size!"
         if self.norm_embed is not None:
@@ -350,11 +372,11 @@ class MsViT(nn.Module):
         br, sc = pend
         return x + br if sc is None else _DropPathAdd.apply(x, br, sc.view(-1, 1, 1).to(x.dtype))
 
-    def _run_stage(self, layer, xtuple):
+    def _run_stage(self, layer, xtuple, tokens=False):
         """One stage with the residual add of every block DEFERRED into the next block's LayerNorm
         (vil_resln_*: one kernel each way instead of add + norm, and norm-backward + add + mask-mul + cast).
         Same arithmetic as `layer(xtuple)` (msvit.py:313-316,336-340); returns the last add still pending."""
-        x, nx, ny = layer[0](xtuple)
+        x, nx, ny = layer[0](xtuple, tokens=tokens)
         B = x.shape[0]
         pend = None
         for blk in list(layer)[1:]:
@@ -378,11 +400,15 @@ class MsViT(nn.Module):
         pend = None
         for i in range(self.num_layers):
             layer = getattr(self, "layer%d" % (i + 1))
+            tokens = False
             if i > 0:   # drop the previous stage's global tokens, back to an image
                 x = self._settle(x, pend)
-                x = x[:, self.Nglos[i - 1]:].transpose(-2, -1).reshape(B, -1, nx, ny)
+                x = x[:, self.Nglos[i - 1]:]
+                tokens = layer[0].tokens_ok(x, nx, ny)
+                if not tokens:
+                    x = x.transpose(-2, -1).reshape(B, -1, nx, ny)
             if x.is_cuda:
-                x, pend, nx, ny = self._run_stage(layer, (x, nx, ny))
+                x, pend, nx, ny = self._run_stage(layer, (x, nx, ny), tokens)
             else:
                 x, nx, ny = layer((x, nx, ny))
                 pend = None
