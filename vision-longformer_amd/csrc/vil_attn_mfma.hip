@@ -33,13 +33,13 @@ __global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out) {
   const int h = blockIdx.y;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= c.tabsize) return;
-  const int tbl = p.g.tbl, W = p.g.W;
+  const int tbl = c.trows, W = p.g.W;
   const float inv = 1.0f / p.scale;
   float v = 0.f;
   if (e < tbl * c.P) {
     const int row = e / c.P, col = e % c.P - VIL_CPAD;
     if (col >= 0 && col < tbl) {
-      const int dx = row - (2 * W - 1), dy = col - (2 * W - 1);
+      const int dx = row - c.tcen, dy = col - c.tcen;
       const int o = p.bias_off, S = p.bias_S;      // the caller's table covers |dx|,|dy| <= o
       if (p.has_bias && dx >= -o && dx <= o && dy >= -o && dy <= o)
         v = p.table[(int64_t)((dx + o) * S + (dy + o)) * p.H + h] * inv;
@@ -283,15 +283,17 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   const int W = d->W;
   c.HQ = (W + 3) / 4;
   c.NWP = (W * c.HQ + 15) / 16;
-  int P = 4 * W + 2 + 2 * VIL_CPAD;
+  c.trows = d->mode == -1 ? 2 * W - 1 : 4 * W - 1;
+  c.tcen = (c.trows - 1) / 2;
+  int P = c.trows + 3 + 2 * VIL_CPAD;
   while ((P & 31) != 11) ++P;
   c.P = P;
   const int aqmax = (W - 1) * P + 4 * (c.HQ - 1) + 3;
   c.gsz = ((aqmax + 8) / 4) * 4;
-  c.guard0 = ((g.tbl * P + 3) / 4) * 4;
+  c.guard0 = ((c.trows * P + 3) / 4) * 4;
   c.glo0 = c.guard0 + c.gsz;
   c.tabsize = ((c.glo0 + d->G * c.gsz + 4 + 3) / 4) * 4;
-  c.aconst = (2 * W - 1) * (P + 1) + VIL_CPAD;
+  c.aconst = c.tcen * (P + 1) + VIL_CPAD;
   c.magicW = (unsigned)(0x100000000ull / (unsigned)W) + 1;
   c.magicW2 = (unsigned)(0x100000000ull / (unsigned)(W * W)) + 1;
   c.NS = d->G + g.nact * g.W2;

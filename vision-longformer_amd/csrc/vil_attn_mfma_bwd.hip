@@ -310,11 +310,11 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
     for (int u = 0; u < 16; ++u) si += red[u][threadIdx.x];
     const int lfx = ((const int*)bc.norm2)[2];
     const float s = (float)si * __builtin_amdgcn_ldexpf(1.0f, -lfx) ;
-    const int tbl = p.g.tbl;
+    const int tbl = c.trows;
     int gg = -1;
     if (bin < tbl * c.P) {
       const int row = bin / c.P, col = bin % c.P - VIL_CPAD;
-      const int dx = row - (2 * p.g.W - 1), dy = col - (2 * p.g.W - 1), o = p.bias_off;
+      const int dx = row - c.tcen, dy = col - c.tcen, o = p.bias_off;
       if (col >= 0 && col < tbl && p.dtable && dx >= -o && dx <= o && dy >= -o && dy <= o)
         p.dtable[(int64_t)((dx + o) * p.bias_S + (dy + o)) * p.H + h] = s;
     } else if (bin >= c.glo0 && bin < c.tabsize && p.dg2l) {
@@ -950,6 +950,11 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     const int na = 32 * VIL_NORM_SLOTS, nb = p.dg2l ? p.H * p.G : 0;
     k_zero_words<<<dim3((na + nb + 255) / 256), dim3(256), 0, s>>>(bc.norm2, na, (unsigned*)p.dg2l, nb);
     if ((e = (int)hipGetLastError())) return e;
+    if (p.dtable && c.trows < p.bias_S) {       // the LDS image covers only part of the caller's table: rest is 0
+      const int nt = p.bias_S * p.bias_S * p.H;
+      k_zero_words<<<dim3((nt + 255) / 256), dim3(256), 0, s>>>((unsigned*)p.dtable, nt, nullptr, 0);
+      if ((e = (int)hipGetLastError())) return e;
+    }
   }
   vil_prof_begin(VIL_K_DELTA, s, w.delta_bytes(), 0);
   BWD_SWITCH((k_mfma_delta<MD_><<<dim3((unsigned)((p.g.nx * p.g.ny * (MD_ == 4 ? 8 : (MD_ == 2 ? 4 : 2)) + 255) / 256), p.B * p.H), dim3(256), 0, s>>>(

@@ -17,14 +17,16 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define LOG2E 1.4426950408889634f
 
 // LDS bias table of one head (floats):
-//   [ (4W-1) rows x P : bias/scale at column CPAD + (dy + 2W-1); exact==1: -1e30 outside the window |
+//   [ trows rows x P : bias/scale at column CPAD + (dy + tcen); exact==1: -1e30 outside the window |
 //     gsz x -1e30 : where masked / padded key slots point |
 //     G x gsz x g2l[h][g]/scale : where the global key slots point ]
 // The table entry of (query (xq,yq), key (X,Y) in the query chunk's frame) is at
-//   Aq - Ak + aconst,  Aq = xq*P + yq,  Ak = X*P + Y,  aconst = (2W-1)*(P+1) + CPAD,
+//   Aq - Ak + aconst,  Aq = xq*P + yq,  Ak = X*P + Y,  aconst = tcen*(P+1) + CPAD,
 // so a lane gathers it with one v_sub (per key) and an immediate offset (per query of its quad).
 // P == 11 (mod 32) spreads the 16 query columns of a wave (x*P + 4*hq) over distinct banks.
 struct MfmaCfg {
+  int trows, tcen;   // rows (= columns) of the LDS bias image and its centre: 4W-1 / 2W-1, or 2W-1 / W-1 when the
+                     // chunk attends only itself (mode -1: |dx|,|dy| <= W-1 -- a 5x smaller image for the dense stages)
   int P;             // row pitch (floats)
   int tabsize;       // floats per head (multiple of 4)
   int guard0;        // start of the all-masked region
