@@ -225,7 +225,12 @@ __global__ __launch_bounds__(1024) void k_ln_reduce(LNParams p) {
   float s = 0.f;
   if (e < 2 * p.C) {
     const int w = e / p.C, c = e % p.C;
-    for (int b = grp; b < p.nblocks; b += 16) s += p.parts[((int64_t)b * 2 + w) * p.C + c];
+    const float* src = p.parts + (int64_t)w * p.C + c;
+    const int64_t st = 2 * (int64_t)p.C;
+    int b = grp;
+    for (; b + 48 < p.nblocks; b += 64)              // four independent loads in flight
+      s += (src[b * st] + src[(b + 16) * st]) + (src[(b + 32) * st] + src[(b + 48) * st]);
+    for (; b < p.nblocks; b += 16) s += src[b * st];
   }
   red[grp][col] = s;
   __syncthreads();
