@@ -602,3 +602,51 @@ def test_residual_layernorm_fused(dev, B, N, C, bdt):
     gs = float(wr.grad.abs().max())
     torch.testing.assert_close(ln.weight.grad.double().cpu(), wr.grad, atol=2e-3 * gs, rtol=2e-3)
     torch.testing.assert_close(ln.bias.grad.double().cpu(), b_r.grad, atol=2e-3 * float(b_r.grad.abs().max()), rtol=2e-3)
+
+
+def test_graphed_train_step_multi_rank_path(dev, monkeypatch):
+    """The world > 1 flavour of the graphed step (graph A: fwd+bwd+pack into flat buffers, all-reduce, graph B:
+    AdamW) on one GPU with the collective stubbed out (the mean over one rank is the identity): must follow the
+    eager trajectory exactly like the single-graph flavour."""
+    import vision_longformer_amd.engine as E
+    calls = []
+    monkeypatch.setattr(E.dist, "all_reduce", lambda t, op=None: calls.append(t.numel()))
+    arch = "l1,h1,d32,n1,s1,g1,p4,f4,a0_l2,h2,d64,n2,s1,g1,p2,f4,a0_l3,h2,d64,n1,s0,g1,p2,f7,a0"
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(8, 3, 64, 64, generator=g).to(dev) for _ in range(3)]
+    ts = [torch.softmax(torch.randn(8, 16, generator=g), -1).to(dev) for _ in range(3)]
+
+    def run(graphed):
+        torch.manual_seed(0)
+        m = E.MsViT(arch, img_size=64, num_classes=16, drop_path_rate=0.0, norm_embed=True, sharew=True).to(dev).train()
+        opt = E.MasterWeightAdamW(m, lr=1e-3, capturable=graphed)
+        losses = []
+        if graphed:
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+            msd = [mm.clone() for mm in opt.master]
+            gs = E.GraphedTrainStep(m, opt, xs[0], ts[0], world=2, warmup=2)
+            assert gs.opt_graph is not None and len(gs.flats) >= 2
+            with torch.no_grad():
+                for k, v in m.state_dict().items():
+                    v.copy_(sd[k])
+                for mm, v in zip(opt.master, msd):
+                    mm.copy_(v)
+            for st in opt.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            n0 = len(calls)
+            for x, t in zip(xs, ts):
+                losses.append(float(gs(x, t)))
+            assert len(calls) - n0 == 3 * len(gs.flats)          # one collective per flat buffer and step
+        else:
+            for x, t in zip(xs, ts):
+                losses.append(float(E.train_step(m, opt, x, t)))
+        torch.cuda.synchronize()
+        return losses, torch.cat([p.detach().float().reshape(-1) for p in m.parameters()]).cpu()
+
+    le, pe = run(False)
+    lg, pg = run(True)
+    _report(f"     graph(world>1 path)-vs-eager losses {le} {lg}  max|dparam| {float((pe - pg).abs().max()):.3e}")
+    assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-2
+    assert float((pe - pg).abs().max()) < 2e-2
