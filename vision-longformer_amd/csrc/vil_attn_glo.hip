@@ -21,6 +21,27 @@ template <> struct GIO<vil_bf16> {
   static __device__ __forceinline__ void st(vil_bf16* p, float v) { *p = vil_f2bf(v); }
 };
 
+// DPL consecutive elements of one row into registers: 16-byte loads where the layout allows (bf16, DPL % 8 == 0;
+// rows are 16-byte aligned by the descriptor checks), element loads otherwise
+template <typename T, int DPL>
+__device__ __forceinline__ void glo_ld(const T* p, float (&v)[DPL]) {
+  if constexpr (sizeof(T) == 2 && DPL % 8 == 0) {
+    typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int c = 0; c < DPL / 8; ++c) {
+      const gu32x4 a = *(const gu32x4*)(p + c * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[c * 8 + 2 * i] = __uint_as_float(a[i] << 16);
+        v[c * 8 + 2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) v[d] = GIO<T>::ld(p + d);
+  }
+}
+
 #define GLO_MAXG 4          // global tokens handled per pass (loops over G in chunks)
 #define GLO_THREADS 256
 #define GLO_NEG (-1.0e30f)
@@ -61,11 +82,8 @@ __global__ __launch_bounds__(GLO_THREADS) void k_glo_fwd(GloParams p, int g0) {
   }
   for (int j = rowl; j < N; j += GLO_THREADS / 4) {
     float kk[DPL], vv[DPL];
-#pragma unroll
-    for (int d = 0; d < DPL; ++d) {
-      kk[d] = GIO<T>::ld(kb + (int64_t)j * p.k_st + sub * DPL + d);
-      vv[d] = GIO<T>::ld(vb + (int64_t)j * p.v_st + sub * DPL + d);
-    }
+    glo_ld<T, DPL>(kb + (int64_t)j * p.k_st + sub * DPL, kk);
+    glo_ld<T, DPL>(vb + (int64_t)j * p.v_st + sub * DPL, vv);
 #pragma unroll
     for (int g = 0; g < GLO_MAXG; ++g) {
       if (g < ng) {
@@ -94,6 +112,7 @@ __global__ __launch_bounds__(GLO_THREADS) void k_glo_fwd(GloParams p, int g0) {
   const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
   for (int g = 0; g < GLO_MAXG; ++g) {
+    if (g >= ng) break;                            // (wave-uniform) G is 1 in every published model
 #pragma unroll
     for (int off = 4; off < 64; off <<= 1) {
       const float m2 = __shfl_xor(m[g], off, 64), l2 = __shfl_xor(l[g], off, 64);
@@ -245,6 +264,9 @@ static int glo_check(const VilAttnDesc* d) {
   if (d->G > GLO_MAXG) return VIL_E_BACKEND;      // bias-gradient bookkeeping is sized for G <= 4
   switch (d->M) { case 8: case 16: case 32: case 48: case 64: break; default: return VIL_E_HEAD_DIM; }
   if (d->dtype != VIL_DTYPE_F32 && d->dtype != VIL_DTYPE_BF16) return VIL_E_DTYPE;
+  // 16-byte row loads of K / V in the bf16 kernels with M % 32 == 0
+  if (d->dtype == VIL_DTYPE_BF16 && d->M % 32 == 0 &&
+      ((d->k_st | d->k_sb | d->k_sh | d->v_st | d->v_sb | d->v_sh) & 7)) return VIL_E_ALIGN;
   return VIL_OK;
 }
 
@@ -277,6 +299,7 @@ extern "C" int vil_glo_attn_fwd(const VilAttnDesc* d, const void* q_g, const voi
   int e = glo_check(d);
   if (e) return e;
   if (!q_g || !k || !v || !out_g || !lse_g) return VIL_E_NULL;
+  if (d->dtype == VIL_DTYPE_BF16 && (((uintptr_t)k | (uintptr_t)v) & 15)) return VIL_E_ALIGN;
   GloParams p; glo_fill(p, d);
   p.q = q_g; p.k = k; p.v = v; p.o = out_g; p.lse = lse_g; p.g2g = g2g; p.g2l0 = g2l0;
   hipStream_t s = (hipStream_t)stream;
