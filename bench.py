@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--master-weights", default="on", choices=["on", "off"],
                     help="bf16 working weights + fp32 master (engine.MasterWeightAdamW) instead of per-call autocast casts")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="run the step as hipGraphs (auto: on unless the config draws a random-shift mode per step); "
+                    help="run the step as hipGraphs (auto = on; random-shift neighbours are device-side words refreshed per replay); "
                          "off = eager step under DDP (bucketed all-reduce overlapped with backward)")
     args = ap.parse_args()
 
@@ -122,7 +122,7 @@ def main():
     B = args.batch or cfg_batch
     torch.manual_seed(0)
     model = build_vil(args.config).to(device).train()
-    use_graph = args.graph == "on" or (args.graph == "auto" and mode <= 0)
+    use_graph = args.graph in ("on", "auto")
     use_master = args.master_weights == "on"
     opt = MasterWeightAdamW(model, capturable=use_graph) if use_master else make_optimizer(model, capturable=use_graph)
     data = SyntheticBatches(B, img, device, rank)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VIL_ATTN_ABI_VERSION 1
+#define VIL_ATTN_ABI_VERSION 2
 
 enum { VIL_DTYPE_F32 = 0, VIL_DTYPE_BF16 = 1 };
 
@@ -84,6 +84,9 @@ typedef struct VilAttnDesc {
   int64_t dq_sb, dq_st, dq_sh;
   int64_t dk_sb, dk_st, dk_sh;
   int64_t dv_sb, dv_st, dv_sh;
+  const int32_t* mode_dev;  /* NULL, or (random shift, mode in 1..8) a DEVICE int32 holding the neighbour 1..8 the
+                               kernels read at launch time instead of `mode`: lets a captured hipGraph draw a new
+                               neighbour per replay (reference longformer2d.py:114-123).  MFMA family only.        */
 } VilAttnDesc;
 
 int vil_attn_abi_version(void);

@@ -24,14 +24,14 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.vil_attn_abi_version() == 1
+    assert L.vil_attn_abi_version() == _lib.ABI_VERSION == 2
     assert L.vil_attn_strerror(0) == b"ok"
     assert b"exact" in L.vil_attn_strerror(-6)
 
 
 def test_desc_struct_matches_header_size():
-    # 12 int32 + float + int32 + 24 int64
-    assert ctypes.sizeof(_lib.VilAttnDesc) == 14 * 4 + 24 * 8
+    # 12 int32 + float + int32 + 24 int64 + 1 pointer (mode_dev)
+    assert ctypes.sizeof(_lib.VilAttnDesc) == 14 * 4 + 24 * 8 + 8
 
 
 def _desc(**kw):

@@ -650,3 +650,37 @@ def test_graphed_train_step_multi_rank_path(dev, monkeypatch):
     _report(f"     graph(world>1 path)-vs-eager losses {le} {lg}  max|dparam| {float((pe - pg).abs().max()):.3e}")
     assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-2
     assert float((pe - pg).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("nx,W,M,H", [(16, 4, 32, 2), (20, 7, 64, 3), (21, 6, 32, 2)])
+def test_device_side_random_shift_mode(dev, nx, W, M, H):
+    """VilAttnDesc.mode_dev: the neighbour read from a device word must give exactly the result of the same
+    neighbour passed in the descriptor (forward and every gradient), for all 8 neighbours."""
+    from vision_longformer_amd.ops import vil_full_attention
+    g = torch.Generator().manual_seed(11)
+    B, G, C = 2, 1, H * M
+    N = G + nx * nx
+    q0 = torch.randn(B, N, C, generator=g).to(dev, torch.bfloat16)
+    kv0 = torch.randn(B, N, 2 * C, generator=g).to(dev, torch.bfloat16)
+    tab0 = (torch.randn((4 * W - 1) ** 2, H, generator=g) * 0.3).to(dev)
+    g2l0 = (torch.randn(2, H, G, generator=g) * 0.3).to(dev)
+    g2g0 = (torch.randn(H, G, G, generator=g) * 0.3).to(dev)
+    dout = torch.randn(B, N, C, generator=g).to(dev, torch.bfloat16)
+    word = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def run(mode, mode_dev):
+        leaves = [t.clone().requires_grad_(True) for t in (q0, kv0, tab0, g2l0, g2g0)]
+        out = vil_full_attention(*leaves, nx=nx, ny=nx, w=W, nglo=G, num_heads=H, mode=mode, mode_dev=mode_dev)
+        out.backward(dout)
+        torch.cuda.synchronize()
+        return [out.detach()] + [t.grad for t in leaves]
+
+    for m in range(1, 9):
+        ref = run(m, None)
+        word.fill_(m)
+        got = run(1 if m != 1 else 2, word)              # the descriptor's static mode must be ignored
+        for name, a, b in zip(("out", "dq", "dkv", "dtable", "dg2l", "dg2g"), got, ref):
+            if name in ("dg2l", "dg2g"):                  # float atomics: order-dependent in the last bits
+                torch.testing.assert_close(a, b, atol=1e-4, rtol=1e-4, msg=f"mode {m} {name}")
+            else:
+                assert torch.equal(a, b), f"mode {m}: {name} differs"

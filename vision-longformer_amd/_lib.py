@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libvilattn.so")
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
 BACKEND_AUTO, BACKEND_SCALAR, BACKEND_MFMA = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_attn_workspace_bytes",
            "vil_attn_fwd", "vil_attn_bwd", "vil_geom_mask", "vil_geom_bias_index",
@@ -33,7 +33,8 @@ class VilAttnDesc(ctypes.Structure):
                  ("B", "H", "M", "nx", "ny", "W", "G", "mode", "exact", "dtype", "only_glo", "backend")] +
                 [("scale", ctypes.c_float), ("bias_side", ctypes.c_int32)] +
                 [(t + s, ctypes.c_int64) for t in ("q", "k", "v", "o", "do", "dq", "dk", "dv")
-                 for s in ("_sb", "_st", "_sh")])
+                 for s in ("_sb", "_st", "_sh")] +
+                [("mode_dev", ctypes.c_void_p)])
 
 
 VIL_E_BACKEND = -10

@@ -35,6 +35,7 @@ static int check_common(const VilAttnDesc* d) {
   if (d->exact < -1 || d->exact > 1) return VIL_E_EXACT;
   if (d->exact == 1 && d->mode != 0 && !d->only_glo) return VIL_E_EXACT;
   if (d->dtype != VIL_DTYPE_F32 && d->dtype != VIL_DTYPE_BF16) return VIL_E_DTYPE;
+  if (d->mode_dev && (d->mode < 1 || d->mode > 8)) return VIL_E_MODE;
   if (d->bias_side < 0 || (d->bias_side > 0 && (d->bias_side % 2 == 0 || d->bias_side > 4 * d->W - 1))) return VIL_E_SHAPE;
   return VIL_OK;
 }

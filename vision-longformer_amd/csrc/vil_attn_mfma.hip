@@ -115,13 +115,15 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
       vtr_off[hf][dt] = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
   }
   const int lgo = lg * 16;
+  int adr1, adc1;
+  shift_neighbour(p, adr1, adc1);
 
   for (int gi = 0; gi < c.gpw; ++gi) {
     const int unit = (wgi * c.gpw + gi) * c.wpw + wave;
     if (unit >= c.units_bh) break;
     const int wp = unit % c.NWP, ch = unit / c.NWP;
     const int cn = ch % g.my, cm = ch / g.my;
-    const int nslots = build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey);
+    const int nslots = build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey, adr1, adc1);
 
     // ---- query slots of this lane: column j of q-tile qt is query (x, y = 4*hq + qt)
     const int jj = wp * 16 + lj;

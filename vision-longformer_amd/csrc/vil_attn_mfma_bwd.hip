@@ -125,13 +125,15 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
       krow_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ (SWZ * (((row2 >> 2) & 1) << 5)));
   }
   const int lgo = lg * 16;
+  int adr1, adc1;
+  shift_neighbour(p, adr1, adc1);
 
   for (int gi = 0; gi < bc.dq_gpw; ++gi) {
     const int unit = (wgi * bc.dq_gpw + gi) * bc.dq_wpw + wave;
     if (unit < bc.dq_units_bh) {
       const int wp = unit % bc.dq_NWP, ch = unit / bc.dq_NWP;
       const int cn = ch % g.my, cm = ch / g.my;
-      const int nslots = build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey);
+      const int nslots = build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey, adr1, adc1);
       const int jj = wp * 16 + lj;
       const int qx = jj / bc.dq_HQ, qhq = jj % bc.dq_HQ;
       const int aq0b = (min(qx, W - 1) * c.P + QT * qhq) * 4;
@@ -401,6 +403,8 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
       row_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ (SWZ * (((row2 >> 2) & 1) << 5)));
   }
 
+  int adr1, adc1;
+  shift_neighbour(p, adr1, adc1);
   for (int gi = 0; gi < bc.kv_gpw; ++gi) {
     const int unit = (wgi * bc.kv_gpw + gi) * bc.kv_wpw + wave;
     if (unit >= bc.units_kv_bh) break;
@@ -429,7 +433,8 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
     } else {
       nchunks = 0;
       for (int a = 0; a < g.nact; ++a) {
-        const int m_ = km - g.adr[a], n_ = kn - g.adc[a];
+        const int ar = g.nact == 2 ? (a == 0 ? 0 : adr1) : g.adr[a], ac = g.nact == 2 ? (a == 0 ? 0 : adc1) : g.adc[a];
+        const int m_ = km - ar, n_ = kn - ac;
         nchunks += (m_ >= 0 && m_ < g.mx && n_ >= 0 && n_ < g.my);
       }
     }
@@ -443,8 +448,8 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
         int cnt = 0;
         for (int a = 0; a < g.nact; ++a) {
           const int a3 = (a * 11) >> 5;
-          const int ar = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : g.adr[1]);
-          const int ac = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : g.adc[1]);
+          const int ar = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : adr1);
+          const int ac = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : adc1);
           const int m_ = km - ar, n_ = kn - ac;
           const bool ok = m_ >= 0 && m_ < g.mx && n_ >= 0 && n_ < g.my;
           if (ok && cnt == ci) { qm = m_; qn = n_; dr = ar; dc = ac; }

@@ -430,6 +430,7 @@ int vil_scalar_supported(const VilAttnDesc* d) {
   switch (d->M) { case 8: case 16: case 32: case 48: case 64: break; default: return VIL_E_HEAD_DIM; }
   if (d->W < 1 || d->W > 32) return VIL_E_WINDOW;
   if (d->dtype != VIL_DTYPE_F32 && d->dtype != VIL_DTYPE_BF16) return VIL_E_DTYPE;
+  if (d->mode_dev) return VIL_E_BACKEND;                                           // device-side mode: MFMA family only
   if (d->bias_side != 0 && d->bias_side != 4 * d->W - 1) return VIL_E_BACKEND;   // non-default table side: MFMA family only
   return VIL_OK;
 }

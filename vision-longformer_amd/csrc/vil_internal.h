@@ -32,12 +32,14 @@ struct VilParams {
   const float* g2l0;         // (H,G) bias global query -> local keys, or null
   const float* g2g;          // (H,G,G) or null
   float* dg2l0; float* dg2g;
+  const int* mode_dev;       // device-side random-shift neighbour (1..8) or null
 };
 
 static inline void vil_fill_params(VilParams& p, const VilAttnDesc* d) {
   vil_geom_init(p.g, d->nx, d->ny, d->W, d->exact, d->mode);
   p.B = d->B; p.H = d->H; p.M = d->M; p.G = d->G; p.only_glo = d->only_glo;
   p.scale = d->scale;
+  p.mode_dev = d->mode_dev;
   p.bias_S = d->bias_side > 0 ? d->bias_side : 4 * d->W - 1;
   p.bias_off = (p.bias_S - 1) / 2;
   p.q_sb = d->q_sb; p.q_st = d->q_st; p.q_sh = d->q_sh;

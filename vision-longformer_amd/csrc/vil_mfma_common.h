@@ -67,6 +67,17 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Offset (dr, dc) of the one extra neighbour in random-shift mode: from the descriptor, or (hipGraph replay with a
+// fresh draw per step) from the device word the descriptor points at (reference slidingchunk_2d.py:15-24)
+__device__ __forceinline__ void shift_neighbour(const VilParams& p, int& adr1, int& adc1) {
+  adr1 = p.g.adr[1]; adc1 = p.g.adc[1];
+  if (p.mode_dev) {
+    const int m = __builtin_amdgcn_readfirstlane(*p.mode_dev);
+    const int s = m > 4 ? m : m - 1;
+    adr1 = s / 3 - 1; adc1 = s - 3 * (s / 3) - 1;
+  }
+}
+
 // Key-slot table of query chunk (cm,cn) in the wave's private LDS:
 //   s_koff[s] = byte offset (token * row stride) of key slot s inside the (image, head) K/V slice
 //   s_akey[s] = 4 * (Ak - aconst)   (padding slots: -4*guard0; global slot g: -4*(glo0 + g*gsz))
@@ -76,7 +87,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // grid see 4-6 of 9 neighbours).  Rows of the neighbourhood are distributed over lanes (one validity
 // test per row); a wave prefix sum places each row's keys.  Returns the padded slot count.
 __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg& c, int cm, int cn, int lane,
-                                               int row_stride_b, int* s_koff, int* s_akey) {
+                                               int row_stride_b, int* s_koff, int* s_akey, int adr1, int adc1) {
   const VilGeom& g = p.g;
   const int W = g.W;
   for (int s = lane; s < p.G; s += 64) {
@@ -90,8 +101,8 @@ __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg
     if (rid < nrows) {
       const int a = fdiv(rid, c.magicW), xt = rid - a * W;
       const int a3 = (a * 11) >> 5;                           // a / 3 for a in [0, 9)
-      const int dr = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : g.adr[1]);
-      const int dc = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : g.adc[1]);
+      const int dr = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : adr1);
+      const int dc = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : adc1);
       const int rm = cm + dr, rn = cn + dc, kr = rm * W + xt;
       if (rm >= 0 && rm < g.mx && rn >= 0 && rn < g.my && kr < g.nx) {
         const int kc0 = rn * W;

@@ -193,8 +193,8 @@ class GraphedTrainStep:
         all-reduce (mean) the flat buffers in one RCCL call each over xGMI (bf16 gradients of the working
         weights: ~50 MB for ViL-Small), replay B.  This gives up comm/compute overlap (~0.5 ms of ring
         time per step) for no host launch cost.
-    Not usable when a layer draws a new random-shift neighbour every step (mode > 0): kernel arguments
-    must be static, the caller falls back to the eager DDP step."""
+    Random-shift training (mode > 0) stays graphable: the neighbour of each layer is a device word read by the
+    kernels (VilAttnDesc.mode_dev), refreshed from the host before every replay."""
 
     def __init__(self, model, optimizer, images, targets, world=1, amp_dtype=torch.bfloat16, warmup=3):
         self.model, self.opt, self.world, self.amp = model, optimizer, world, amp_dtype
@@ -216,6 +216,16 @@ class GraphedTrainStep:
                     self.views[p] = flat[off:off + p.numel()].view_as(p)
                     off += n
                 self.flats.append(flat)
+        # random-shift layers: the neighbour of every layer is a device word the kernels read at launch time;
+        # it is drawn on the host before each replay with the reference's RNG call (one random.randrange(1, 9)
+        # per layer forward, in layer order: longformer2d.py:114-123) and uploaded with one small copy
+        from .longformer2d import Long2DSCSelfAttention
+        self.rs_layers = [m for m in model.modules() if isinstance(m, Long2DSCSelfAttention) and m.mode > 0]
+        if self.rs_layers:
+            self.modes_dev = torch.ones(len(self.rs_layers), dtype=torch.int32, device=dev)
+            self.modes_host = torch.ones(len(self.rs_layers), dtype=torch.int32).pin_memory()
+            for i, m in enumerate(self.rs_layers):
+                m.mode_dev = self.modes_dev[i:i + 1]
         self.loss = None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -235,6 +245,13 @@ class GraphedTrainStep:
             self.opt_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.opt_graph):
                 self.opt.step()
+
+    def _draw_modes(self):
+        if self.rs_layers and self.model.training:
+            import random
+            for i in range(len(self.rs_layers)):
+                self.modes_host[i] = random.randrange(1, 9)
+            self.modes_dev.copy_(self.modes_host, non_blocking=True)
 
     def _fwd_bwd(self):
         # p.grad = None: autograd then WRITES each gradient (into the graph's private pool: static addresses)
@@ -258,6 +275,7 @@ class GraphedTrainStep:
 
     def _body(self, eager):
         """the same step launched op by op (warm-up, and the per-kernel profile of bench.py)"""
+        self._draw_modes()
         self._fwd_bwd()
         if self.world > 1:
             self._allreduce()
@@ -266,6 +284,7 @@ class GraphedTrainStep:
     def __call__(self, images, targets):
         self.x.copy_(images, non_blocking=True)
         self.t.copy_(targets, non_blocking=True)
+        self._draw_modes()
         self.graph.replay()
         if self.opt_graph is not None:
             self._allreduce()

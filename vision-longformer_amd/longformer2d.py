@@ -64,6 +64,9 @@ class Long2DSCSelfAttention(nn.Module):
         self.rpe = rpe
         self.mode = mode                  # 0: 3x3 chunks; -1: own chunk; >0: random-shift training
         self.backend = None               # kernel family override ("scalar" / "mfma"); None = library default
+        self.mode_dev = None              # (1,) int32 device tensor: the random-shift neighbour is read by the
+                                          # kernels at launch time (set by engine.GraphedTrainStep, which draws
+                                          # the neighbour on the host before every hipGraph replay)
 
         self.query = VilLinear(dim, dim, bias=qkv_bias)
         self.kv = VilLinear(dim, dim * 2, bias=qkv_bias)
@@ -91,6 +94,8 @@ class Long2DSCSelfAttention(nn.Module):
     def _resolve_mode(self):
         """longformer2d.py:114-123: one draw from Python's global `random` per
         training forward when mode > 0; evaluation always uses the full 3x3."""
+        if self.mode > 0 and self.training and self.mode_dev is not None:
+            return self.mode             # the neighbour comes from self.mode_dev (drawn by the graphed step)
         if self.mode > 0:
             return random.randrange(1, 9) if self.training else 0
         return self.mode
@@ -108,12 +113,14 @@ class Long2DSCSelfAttention(nn.Module):
             # shared weights (every published ViL): ONE query / kv / proj GEMM over all N tokens and one
             # fused op for local + global rows -- no token slicing, no concatenation, and the two
             # gradient contributions to kv are summed inside the kernels
+            dev_mode = self.mode_dev if (self.mode_dev is not None and self.mode > 0 and self.training) else None
             out = vil_full_attention(self.query(x), self.kv(x),
                                      self.local_relative_position_bias_table if self.rpe else None,
                                      self.g2l_relative_position_bias if self.rpe else None,
                                      self.g2g_relative_position_bias if self.rpe else None,
-                                     nx=nx, ny=ny, w=self.attention_window, nglo=G, num_heads=H, mode=mode,
-                                     exact=self.exact, scale=self.scale, backend=self.backend)
+                                     nx=nx, ny=ny, w=self.attention_window, nglo=G, num_heads=H,
+                                     mode=(1 if dev_mode is not None else mode),
+                                     exact=self.exact, scale=self.scale, backend=self.backend, mode_dev=dev_mode)
             return self.proj_drop(self.proj(out))
 
         q = self.query(x[:, G:])                  # (B, Nloc, C), unscaled: the kernel applies `scale`

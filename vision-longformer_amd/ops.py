@@ -50,6 +50,7 @@ def _make_desc(q, k, v, out, cfg, backend):
     d.backend = _BACKENDS[backend]
     d.scale = float(cfg["scale"])
     d.bias_side = int(cfg.get("bias_side", 0))
+    d.mode_dev = cfg.get("mode_dev") or None      # device int32 holding the random-shift neighbour (graph replay)
     d.q_sb, d.q_st, d.q_sh = _strides(q, M)
     d.k_sb, d.k_st, d.k_sh = _strides(k, M)
     d.v_sb, d.v_st, d.v_sh = _strides(v, M)
@@ -297,13 +298,16 @@ def _cfg(q_last_dim, nx, ny, w, nglo, num_heads, mode, exact, scale, bias_side=0
 
 
 def vil_full_attention(q_all, kv, bias_table, g2l_bias, g2g_bias, *, nx, ny, w, nglo, num_heads, mode=0, exact=0,
-                       scale=None, backend=None):
+                       scale=None, backend=None, mode_dev=None):
     """All rows of one layer: q_all (B, nglo+nx*ny, C) from ONE query projection, kv (B, N, 2C);
     g2l_bias (2, H, nglo) and g2g_bias (H, nglo, nglo) or None.  Returns (B, N, C)."""
     if exact not in (0, 1, -1) or (exact == 1 and mode != 0):
         raise ValueError("longsc exact should be in [0,1,-1]!")
     assert 1 <= nglo <= FULL_MAX_G
     cfg = _cfg(q_all.shape[-1], nx, ny, w, nglo, num_heads, mode, exact, scale)
+    if mode_dev is not None:            # (1,) int32 device tensor, kept alive by the caller (the module's buffer)
+        assert mode > 0 and mode_dev.dtype == torch.int32 and mode_dev.is_cuda
+        cfg["mode_dev"] = mode_dev.data_ptr()
     return _VilFullAttention.apply(q_all, kv, bias_table, g2l_bias, g2g_bias, cfg, backend or DEFAULT_BACKEND)
 
 
