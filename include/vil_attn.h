@@ -214,6 +214,15 @@ int vil_resln_bwd(const void* dy, int dy_dtype, const float* gres, const float* 
                   float* dx, void* gbranch, int gb_dtype, float* dgamma, float* dbeta, void* workspace,
                   int64_t rows, int C, void* stream);
 
+/* ---- the plain library GEMMs of the projections (hipBLASLt, algorithm selected by measurement per problem on first
+ * use outside stream capture; reference call sites: every nn.Linear of msvit.py / longformer2d.py).
+ *   op 0: out[T][N] = in[T][K] * w[N][K]^T (+ bias[N])      (forward;  w = nn.Linear.weight)
+ *   op 1: out[T][N] = in[T][K] * w[K][N]                    (input gradient: in = dY, w = nn.Linear.weight)
+ * bf16 operands, fp32 accumulate; row strides in elements (multiples of 8); workspace of vil_gemm_workspace_bytes(). */
+size_t vil_gemm_workspace_bytes(void);
+int vil_gemm_bf16(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
+                  int64_t in_row_stride, int64_t out_row_stride, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_glo_attn_fwd", "vil_glo_attn_bwd", "vil_attn_bwd_full",
            "vil_colsum_workspace_bytes", "vil_colsum_bf16", "vil_colsum_f32",
            "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad",
-           "vil_resln_fwd", "vil_resln_bwd")
+           "vil_resln_fwd", "vil_resln_bwd", "vil_gemm_workspace_bytes", "vil_gemm_bf16")
 
 
 class VilAttnDesc(ctypes.Structure):
@@ -104,6 +104,11 @@ def lib():
         L.vil_resln_bwd.restype = ctypes.c_int
         L.vil_resln_bwd.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_int64, vp, vp, ctypes.c_int, vp, vp, vp,
                                     ctypes.c_int64, ctypes.c_int, vp]
+        L.vil_gemm_workspace_bytes.restype = ctypes.c_size_t
+        L.vil_gemm_workspace_bytes.argtypes = []
+        L.vil_gemm_bf16.restype = ctypes.c_int
+        L.vil_gemm_bf16.argtypes = [ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                    ctypes.c_int64, vp, ctypes.c_size_t, vp]
         L.vil_layernorm_workspace_bytes.restype = ctypes.c_size_t
         L.vil_layernorm_workspace_bytes.argtypes = [i64, ctypes.c_int]
         L.vil_layernorm_fwd.restype = ctypes.c_int

@@ -1,0 +1,122 @@
+// vil_gemm.hip -- the plain library GEMMs of the projections (forward Y = X W^T + b, input gradient dX = dY W)
+// through hipBLASLt with the algorithm SELECTED BY MEASUREMENT per problem.  ("plain library GEMMs
+// stay on hipBLASLt"; reference call sites: every nn.Linear of msvit.py / longformer2d.py.)
+// hipblasLtMatmulAlgoGetHeuristic returns a ranked list; its first entry (what a framework call gets) loses
+// 5-25 % against the best of the top 16 on this model's skinny shapes (tools/ubench/hipblaslt_algos.cpp), and the
+// framework's own dispatch was another 10-50 % behind on several of them.  First use of a problem (outside stream
+// capture): time the candidates on the caller's operands with hipEvents, cache the winner; later calls (and calls
+// that arrive during capture before a problem was tuned) just launch.
+#include "vil_internal.h"
+#include <hipblaslt/hipblaslt.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+namespace {
+
+struct Plan {
+  hipblasLtMatmulDesc_t md = nullptr;
+  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  size_t ws = 0;
+  bool tuned = false, valid = false;
+  std::vector<hipblasLtMatmulHeuristicResult_t> cand;
+};
+
+typedef std::tuple<int, int64_t, int, int, int64_t, int64_t, int> Key;   // op, T, K, N, in stride, out stride, bias
+std::map<Key, Plan> g_plans;
+std::mutex g_mu;
+hipblasLtHandle_t g_handle = nullptr;
+
+int make_plan(Plan& pl, int op, int64_t T, int K, int N, int64_t in_rs, int64_t out_rs, bool bias, size_t wsz) {
+  // row-major problem restated column-major: C (N x T, ld out_rs) = op(A) (N x K) * B (K x T, ld in_rs)
+  //   forward: A = W (N,K) row-major = (K x N) column-major, ld K, transposed;  dgrad: A = W (K,N) row-major =
+  //   (N x K) column-major, ld N, not transposed.   (K = contraction length, N = output features)
+  if (hipblasLtMatmulDescCreate(&pl.md, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return 1;
+  hipblasOperation_t ta = op == 0 ? HIPBLAS_OP_T : HIPBLAS_OP_N, tb = HIPBLAS_OP_N;
+  hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta));
+  hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
+  if (bias) {
+    hipblasLtEpilogue_t ep = HIPBLASLT_EPILOGUE_BIAS;
+    int32_t bt = HIP_R_16BF;
+    hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep));
+    hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
+  }
+  hipblasStatus_t st;
+  if (op == 0) st = hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, K, N, K);
+  else st = hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, N, K, N);
+  if (st != HIPBLAS_STATUS_SUCCESS) return 1;
+  if (hipblasLtMatrixLayoutCreate(&pl.lb, HIP_R_16BF, K, T, in_rs) != HIPBLAS_STATUS_SUCCESS) return 1;
+  if (hipblasLtMatrixLayoutCreate(&pl.lc, HIP_R_16BF, N, T, out_rs) != HIPBLAS_STATUS_SUCCESS) return 1;
+  hipblasLtMatmulPreference_t pref;
+  if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return 1;
+  hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz));
+  const int REQ = 16;
+  hipblasLtMatmulHeuristicResult_t res[REQ];
+  int got = 0;
+  if (bias) {                     // the heuristic wants a non-null bias pointer to rank epilogue kernels
+    const void* dummy = (const void*)16;
+    hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &dummy, sizeof(dummy));
+  }
+  st = hipblasLtMatmulAlgoGetHeuristic(g_handle, pl.md, pl.la, pl.lb, pl.lc, pl.lc, pref, REQ, res, &got);
+  hipblasLtMatmulPreferenceDestroy(pref);
+  if (st != HIPBLAS_STATUS_SUCCESS || got == 0) return 1;
+  for (int i = 0; i < got; ++i)
+    if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= wsz) pl.cand.push_back(res[i]);
+  if (pl.cand.empty()) return 1;
+  pl.algo = pl.cand[0].algo; pl.ws = pl.cand[0].workspaceSize;
+  pl.valid = true;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t vil_gemm_workspace_bytes(void) { return (size_t)32 << 20; }
+
+// op 0: out[T][N] = in[T][K] * w[N][K]^T (+ bias[N]);   op 1: out[T][N] = in[T][K] * w[K][N]   (w row-major)
+// bf16 everywhere, fp32 accumulate; row strides in elements (multiples of 8), 16-byte aligned bases.
+extern "C" int vil_gemm_bf16(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
+                             int64_t in_row_stride, int64_t out_row_stride, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  if (!in || !w || !out || !workspace) return VIL_E_NULL;
+  if (T <= 0 || K <= 0 || N <= 0 || (op != 0 && op != 1) || (op == 1 && bias)) return VIL_E_SHAPE;
+  if ((K & 7) || (N & 7) || (in_row_stride & 7) || (out_row_stride & 7) ||
+      (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out | (uintptr_t)workspace) & 15)) return VIL_E_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (!g_handle && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return VIL_E_BACKEND;
+  const Key key(op, T, K, N, in_row_stride, out_row_stride, bias ? 1 : 0);
+  Plan& pl = g_plans[key];
+  if (!pl.valid && make_plan(pl, op, T, K, N, in_row_stride, out_row_stride, bias != nullptr, workspace_bytes))
+    return VIL_E_BACKEND;
+  if (bias) hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+  const float alpha = 1.f, beta = 0.f;
+  auto run = [&](const hipblasLtMatmulAlgo_t& a) {
+    return hipblasLtMatmul(g_handle, pl.md, &alpha, w, pl.la, in, pl.lb, &beta, out, pl.lc, out, pl.lc, &a, workspace,
+                           workspace_bytes, s);
+  };
+  if (!pl.tuned) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing(s, &cs);
+    if (cs == hipStreamCaptureStatusNone && pl.cand.size() > 1) {
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0); hipEventCreate(&e1);
+      float best = 1e30f;
+      for (const auto& c : pl.cand) {
+        if (run(c.algo) != HIPBLAS_STATUS_SUCCESS) continue;                      // warm-up / validity
+        hipEventRecord(e0, s);
+        bool ok = true;
+        for (int r = 0; r < 4 && ok; ++r) ok = run(c.algo) == HIPBLAS_STATUS_SUCCESS;
+        hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) { best = ms; pl.algo = c.algo; pl.ws = c.workspaceSize; }
+      }
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      pl.tuned = true;
+    }
+  }
+  return run(pl.algo) == HIPBLAS_STATUS_SUCCESS ? VIL_OK : VIL_E_BACKEND;
+}

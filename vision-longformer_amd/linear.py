@@ -75,13 +75,47 @@ def _wgrad(dy2, x2, want_db):
     return dw, db
 
 
+_GEMM_WS = {}
+
+
+def _gemm(op, inp2, w, bias):
+    """op 0: inp2 @ w.T (+ bias);  op 1: inp2 @ w -- hipBLASLt through libvilattn with the algorithm chosen by
+    measurement per problem (vil_gemm_bf16).  None when the operands do not fit the contract."""
+    T, K = inp2.shape
+    N = w.shape[0] if op == 0 else w.shape[1]
+    if not (inp2.is_cuda and inp2.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.is_contiguous()
+            and (w.shape[1] if op == 0 else w.shape[0]) == K and K % 8 == 0 and N % 8 == 0 and T >= 1
+            and inp2.stride(1) == 1 and inp2.stride(0) % 8 == 0 and inp2.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous()))):
+        return None
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    ws = _GEMM_WS.get(inp2.device)
+    if ws is None:
+        ws = _GEMM_WS[inp2.device] = torch.empty(L.vil_gemm_workspace_bytes(), dtype=torch.uint8, device=inp2.device)
+    out = torch.empty(T, N, dtype=torch.bfloat16, device=inp2.device)
+    vp = ctypes.c_void_p
+    rc = L.vil_gemm_bf16(op, vp(inp2.data_ptr()), vp(w.data_ptr()), vp(bias.data_ptr()) if bias is not None else None,
+                         vp(out.data_ptr()), T, K, N, inp2.stride(0), N, vp(ws.data_ptr()), ws.numel(),
+                         vp(torch.cuda.current_stream(inp2.device).cuda_stream))
+    if rc == _lib.VIL_E_BACKEND:
+        return None
+    _lib.check(rc)
+    return out
+
+
 class _SplitKLinearFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        x2 = x.reshape(-1, x.shape[-1])
+        y = _gemm(0, x2, weight, bias) if x.is_cuda else None
+        if y is None:
+            return F.linear(x, weight, bias)
+        return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -93,7 +127,8 @@ class _SplitKLinearFn(torch.autograd.Function):
         T = x2.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ weight).view(x.shape)
+            dx = _gemm(1, dy2, weight, None) if dy2.is_cuda else None
+            dx = (dx if dx is not None else dy2 @ weight).view(x.shape)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             fused = _wgrad(dy2, x2, want_db)
