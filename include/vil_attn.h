@@ -218,6 +218,8 @@ int vil_resln_bwd(const void* dy, int dy_dtype, const float* gres, const float* 
  * use outside stream capture; reference call sites: every nn.Linear of msvit.py / longformer2d.py).
  *   op 0: out[T][N] = in[T][K] * w[N][K]^T (+ bias[N])      (forward;  w = nn.Linear.weight)
  *   op 1: out[T][N] = in[T][K] * w[K][N]                    (input gradient: in = dY, w = nn.Linear.weight)
+ *   op 2: out[N][K] = w[T][N]^T * in[T][K], bias[N] = colsum(w)  (weight / bias gradient: in = x, w = dY,
+ *         out_row_stride = row stride of dY; bias (output) may be NULL)
  * bf16 operands, fp32 accumulate; row strides in elements (multiples of 8); workspace of vil_gemm_workspace_bytes(). */
 size_t vil_gemm_workspace_bytes(void);
 int vil_gemm_bf16(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,

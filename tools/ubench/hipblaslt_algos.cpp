@@ -26,6 +26,9 @@ int main() {
     {"s3 proj fwd", 25216, 384, 384, 0}, {"s3 fc1 dgrad", 25216, 1536, 384, 1}, {"s3 fc2 dgrad", 25216, 384, 1536, 1},
     {"s3 qkv dgrad", 25216, 1152, 384, 1}, {"s2 fc1 fwd", 100480, 192, 768, 0}, {"s2 fc2 fwd", 100480, 768, 192, 0},
     {"s1 fc1 fwd", 401536, 96, 384, 0}, {"s1 fc2 fwd", 401536, 384, 96, 0}, {"s1 fc1 dgrad", 401536, 384, 96, 1},
+    // kind 2: weight gradient dW[N][K] = dY[T][N]^T X[T][K]  (contraction over T)
+    {"s3 fc1 wgrad", 25216, 384, 1536, 2}, {"s3 fc2 wgrad", 25216, 1536, 384, 2}, {"s3 proj wgrad", 25216, 384, 384, 2},
+    {"s2 fc1 wgrad", 100480, 192, 768, 2}, {"s1 fc1 wgrad", 401536, 96, 384, 2},
   };
   size_t wsz = 64u << 20; void* ws; CK(hipMalloc(&ws, wsz));
   hipStream_t s; CK(hipStreamCreate(&s));
@@ -35,20 +38,24 @@ int main() {
     // fwd:   A = W row-major (N,K) = col-major (K x N) ld K, op T
     // dgrad: dX[T][K'] = dY[T][N'] W[N'][K'];  here sh.K = N' (contraction), sh.N = K' (output cols)
     //        col-major: C(K' x T) = A(K' x N') * B(N' x T), A = W row-major (N',K') = col-major (K' x N') ld K', op N
-    const int64_t M_ = sh.N, N_ = sh.T, K_ = sh.K;
+    int64_t M_ = sh.N, N_ = sh.T, K_ = sh.K;
+    if (sh.kind == 2) { M_ = sh.K; N_ = sh.N; K_ = sh.T; }     // C (K x N col-major = dW (N,K) row-major) = X^T-view (K x T) * dY (T x N)
     void *A, *B, *C;
-    CK(hipMalloc(&A, (size_t)sh.N * sh.K * 2)); CK(hipMalloc(&B, (size_t)sh.T * sh.K * 2)); CK(hipMalloc(&C, (size_t)sh.T * sh.N * 2));
-    { size_t na = (size_t)sh.N * sh.K, nb = (size_t)sh.T * sh.K;
+    // generous allocations (every kind touches at most T*max(K,N) elements per operand)
+    const size_t big = (size_t)sh.T * (sh.K > sh.N ? sh.K : sh.N) * 2;
+    CK(hipMalloc(&A, big)); CK(hipMalloc(&B, big)); CK(hipMalloc(&C, big));
+    { size_t na = big / 2, nb = big / 2;
       k_fill<<<(unsigned)((na + 255) / 256), 256>>>((unsigned short*)A, na, 1u);
       k_fill<<<(unsigned)((nb + 255) / 256), 256>>>((unsigned short*)B, nb, 7u); CK(hipDeviceSynchronize()); }
     hipblasLtMatmulDesc_t md; CK(hipblasLtMatmulDescCreate(&md, HIPBLAS_COMPUTE_32F, HIP_R_32F));
-    hipblasOperation_t ta = sh.kind == 0 ? HIPBLAS_OP_T : HIPBLAS_OP_N, tb = HIPBLAS_OP_N;
+    hipblasOperation_t ta = sh.kind == 0 ? HIPBLAS_OP_T : HIPBLAS_OP_N, tb = sh.kind == 2 ? HIPBLAS_OP_T : HIPBLAS_OP_N;
     CK(hipblasLtMatmulDescSetAttribute(md, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)));
     CK(hipblasLtMatmulDescSetAttribute(md, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)));
     hipblasLtMatrixLayout_t la, lb, lc;
     if (sh.kind == 0) CK(hipblasLtMatrixLayoutCreate(&la, HIP_R_16BF, K_, M_, K_));
     else CK(hipblasLtMatrixLayoutCreate(&la, HIP_R_16BF, M_, K_, M_));
-    CK(hipblasLtMatrixLayoutCreate(&lb, HIP_R_16BF, K_, N_, K_));
+    if (sh.kind == 2) CK(hipblasLtMatrixLayoutCreate(&lb, HIP_R_16BF, N_, K_, N_));
+    else CK(hipblasLtMatrixLayoutCreate(&lb, HIP_R_16BF, K_, N_, K_));
     CK(hipblasLtMatrixLayoutCreate(&lc, HIP_R_16BF, M_, N_, M_));
     hipblasLtMatmulPreference_t pref; CK(hipblasLtMatmulPreferenceCreate(&pref));
     CK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz)));

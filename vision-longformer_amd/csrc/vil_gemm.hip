@@ -33,22 +33,31 @@ int make_plan(Plan& pl, int op, int64_t T, int K, int N, int64_t in_rs, int64_t 
   // row-major problem restated column-major: C (N x T, ld out_rs) = op(A) (N x K) * B (K x T, ld in_rs)
   //   forward: A = W (N,K) row-major = (K x N) column-major, ld K, transposed;  dgrad: A = W (K,N) row-major =
   //   (N x K) column-major, ld N, not transposed.   (K = contraction length, N = output features)
+  //   weight gradient (op 2): C (K x N column-major = dW (N,K) row-major, ld K) = A (K x T: x row-major, ld in_rs)
+  //   * B^T (B = dY row-major (T,N) = (N x T) column-major, ld out_rs... passed as `w`); bias = db via BGRADB
   if (hipblasLtMatmulDescCreate(&pl.md, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return 1;
-  hipblasOperation_t ta = op == 0 ? HIPBLAS_OP_T : HIPBLAS_OP_N, tb = HIPBLAS_OP_N;
+  hipblasOperation_t ta = op == 0 ? HIPBLAS_OP_T : HIPBLAS_OP_N, tb = op == 2 ? HIPBLAS_OP_T : HIPBLAS_OP_N;
   hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta));
   hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
   if (bias) {
-    hipblasLtEpilogue_t ep = HIPBLASLT_EPILOGUE_BIAS;
+    hipblasLtEpilogue_t ep = op == 2 ? HIPBLASLT_EPILOGUE_BGRADB : HIPBLASLT_EPILOGUE_BIAS;
     int32_t bt = HIP_R_16BF;
     hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep));
     hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
   }
   hipblasStatus_t st;
-  if (op == 0) st = hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, K, N, K);
-  else st = hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, N, K, N);
-  if (st != HIPBLAS_STATUS_SUCCESS) return 1;
-  if (hipblasLtMatrixLayoutCreate(&pl.lb, HIP_R_16BF, K, T, in_rs) != HIPBLAS_STATUS_SUCCESS) return 1;
-  if (hipblasLtMatrixLayoutCreate(&pl.lc, HIP_R_16BF, N, T, out_rs) != HIPBLAS_STATUS_SUCCESS) return 1;
+  if (op == 2) {
+    // here T = contraction length, K = C_in, N = C_out; in_rs = row stride of x, out_rs = row stride of dY
+    if (hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, K, T, in_rs) != HIPBLAS_STATUS_SUCCESS) return 1;
+    if (hipblasLtMatrixLayoutCreate(&pl.lb, HIP_R_16BF, N, T, out_rs) != HIPBLAS_STATUS_SUCCESS) return 1;
+    if (hipblasLtMatrixLayoutCreate(&pl.lc, HIP_R_16BF, K, N, K) != HIPBLAS_STATUS_SUCCESS) return 1;
+  } else {
+    if (op == 0) st = hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, K, N, K);
+    else st = hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, N, K, N);
+    if (st != HIPBLAS_STATUS_SUCCESS) return 1;
+    if (hipblasLtMatrixLayoutCreate(&pl.lb, HIP_R_16BF, K, T, in_rs) != HIPBLAS_STATUS_SUCCESS) return 1;
+    if (hipblasLtMatrixLayoutCreate(&pl.lc, HIP_R_16BF, N, T, out_rs) != HIPBLAS_STATUS_SUCCESS) return 1;
+  }
   hipblasLtMatmulPreference_t pref;
   if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return 1;
   hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz));
@@ -75,12 +84,14 @@ int make_plan(Plan& pl, int op, int64_t T, int K, int N, int64_t in_rs, int64_t 
 extern "C" size_t vil_gemm_workspace_bytes(void) { return (size_t)32 << 20; }
 
 // op 0: out[T][N] = in[T][K] * w[N][K]^T (+ bias[N]);   op 1: out[T][N] = in[T][K] * w[K][N]   (w row-major)
+// op 2: out[N][K] = w[T][N]^T * in[T][K]  (weight gradient: in = x, w = dY, `out_row_stride` = row stride of dY),
+//       bias != NULL: bias[N] = column sums of dY (bias gradient, written by the GEMM's epilogue)
 // bf16 everywhere, fp32 accumulate; row strides in elements (multiples of 8), 16-byte aligned bases.
 extern "C" int vil_gemm_bf16(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
                              int64_t in_row_stride, int64_t out_row_stride, void* workspace, size_t workspace_bytes,
                              void* stream) {
   if (!in || !w || !out || !workspace) return VIL_E_NULL;
-  if (T <= 0 || K <= 0 || N <= 0 || (op != 0 && op != 1) || (op == 1 && bias)) return VIL_E_SHAPE;
+  if (T <= 0 || K <= 0 || N <= 0 || op < 0 || op > 2 || (op == 1 && bias)) return VIL_E_SHAPE;
   if ((K & 7) || (N & 7) || (in_row_stride & 7) || (out_row_stride & 7) ||
       (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out | (uintptr_t)workspace) & 15)) return VIL_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
@@ -93,6 +104,9 @@ extern "C" int vil_gemm_bf16(int op, const void* in, const void* w, const void* 
   if (bias) hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
   const float alpha = 1.f, beta = 0.f;
   auto run = [&](const hipblasLtMatmulAlgo_t& a) {
+    if (op == 2)      // A = x (`in`), B = dY (`w`)
+      return hipblasLtMatmul(g_handle, pl.md, &alpha, in, pl.la, w, pl.lb, &beta, out, pl.lc, out, pl.lc, &a, workspace,
+                             workspace_bytes, s);
     return hipblasLtMatmul(g_handle, pl.md, &alpha, w, pl.la, in, pl.lb, &beta, out, pl.lc, out, pl.lc, &a, workspace,
                            workspace_bytes, s);
   };
