@@ -60,6 +60,36 @@ def test_argument_validation():
     assert L.vil_attn_workspace_bytes(ctypes.byref(d), 1) > 0
 
 
+def test_glue_entry_points_validate_before_launching():
+    """The glue kernels' entry points (LayerNorm, column sum, weight gradient, library GEMM) reject NULL / bad
+    shapes / misalignment with VIL_E_* codes before touching the device (so this runs without a GPU)."""
+    L = _lib.lib()
+    vp = ctypes.c_void_p
+    a16 = vp(4096)                       # a 16-byte aligned fake address: never dereferenced on these paths
+    assert L.vil_colsum_bf16(None, 8, 8, 8, a16, 1, a16, None) == -1
+    assert L.vil_colsum_bf16(a16, 8, 12, 16, a16, 1, a16, None) == -8          # C % 8: VIL_E_ALIGN
+    assert L.vil_colsum_f32(a16, 0, 8, 8, a16, 0, a16, None) == -2
+    assert L.vil_colsum_workspace_bytes(384) == 512 * 384 * 4
+    assert L.vil_linear_wgrad(None, a16, 64, 8, 8, 8, 8, a16, None, 1, a16, None) == -1
+    assert L.vil_linear_wgrad(a16, a16, 64, 8, 12, 8, 16, a16, None, 1, a16, None) == -8
+    assert L.vil_linear_wgrad(a16, vp(4100), 64, 8, 8, 8, 8, a16, None, 1, a16, None) == -8
+    assert L.vil_linear_wgrad_workspace_bytes(25216, 1536, 384) > 1536 * 384 * 4
+    assert L.vil_gemm_bf16(0, None, a16, None, a16, 8, 8, 8, 8, 8, a16, 1 << 20, None) == -1
+    assert L.vil_gemm_bf16(3, a16, a16, None, a16, 8, 8, 8, 8, 8, a16, 1 << 20, None) == -2
+    assert L.vil_gemm_bf16(1, a16, a16, a16, a16, 8, 8, 8, 8, 8, a16, 1 << 20, None) == -2   # no bias on the input gradient
+    assert L.vil_gemm_bf16(0, a16, a16, None, a16, 8, 12, 8, 16, 8, a16, 1 << 20, None) == -8
+    assert L.vil_gemm_workspace_bytes() >= 1 << 20
+    assert L.vil_resln_fwd(None, a16, 1, None, 1, a16, a16, a16, a16, 1, a16, a16, 8, 8, 1e-6, None) == -1
+    assert L.vil_resln_fwd(a16, a16, 1, None, 0, a16, a16, a16, a16, 1, a16, a16, 8, 8, 1e-6, None) == -2
+    assert L.vil_resln_bwd(a16, 1, None, a16, a16, a16, a16, None, 1, a16, None, 1, a16, a16, a16, 8, 8, None) == -1
+    d = _desc(mode=3, dtype=_lib.DTYPE_BF16)
+    d.mode_dev = 4096
+    assert L.vil_attn_check(ctypes.byref(d)) in (0, -10)        # accepted (MFMA) or backend-declined, never a crash
+    d = _desc(mode=0, dtype=_lib.DTYPE_BF16)
+    d.mode_dev = 4096
+    assert L.vil_attn_check(ctypes.byref(d)) == -5              # a device-side neighbour needs a random-shift mode
+
+
 @pytest.mark.parametrize("grid", GC.MASK_GRIDS, ids=lambda g: "g%dx%dp%dx%dw%d" % g)
 def test_geometry_masks_bit_exact(golden_dir, grid):
     L = _lib.lib()
