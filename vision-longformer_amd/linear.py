@@ -1,12 +1,16 @@
-"""`VilLinear`: an `nn.Linear` whose weight-gradient GEMM is split along the token axis.
+"""`VilLinear` / `vil_linear`: the projections around the hot path (every nn.Linear of msvit.py / longformer2d.py,
+and the patch embedding restated as a Linear), same parameters / state-dict keys as nn.Linear.
 
-The projections around the hot path are plain library GEMMs (hipBLASLt through PyTorch).  Their
-weight gradients dW = dY^T X contract over B*N tokens (25 k ... 400 k) into a tiny (C_out x C_in)
-output; the library's heuristic launches one workgroup per output tile with no split-K, i.e. 9-144
-workgroups on a 256-CU part (measured on MI355X, tools/gemm_probe.py: 0.72-0.87 ms per stage-1
-weight gradient = 20-35 TFLOP/s).  Splitting the contraction into S batched chunks
-(`torch.bmm` -> S x (C_out x C_in) partials, summed in fp32) fills the machine: 3-4x faster.
-Forward and input-gradient GEMMs are unchanged.  Parameters / state-dict keys are nn.Linear's."""
+On device tensors each of the three GEMMs of a projection goes through libvilattn.so:
+  forward  Y = X W^T + b  and  input gradient dX = dY W :  hipBLASLt with the algorithm selected by measurement
+                                                          per problem (`vil_gemm_bf16`);
+  weight + bias gradient  dW = dY^T X, db = colsum(dY)  :  one fused MFMA kernel (`vil_linear_wgrad`: the contraction
+           runs over 6 k ... 400 k tokens into a tiny output, which a library GEMM handles with 9-144 workgroups
+           on a 256-CU part; measured 20-35 TFLOP/s on the stage-1 shapes, tools/gemm_probe.py), or for small
+           token counts a library GEMM + the column-sum kernel.
+No bias / cls-token gradient is left to PyTorch's multi-block reductions (they replay wrongly under hipGraph on this
+stack, see `_colsum`).  Operands that do not fit a kernel's contract (fp32, odd sizes, CPU) take the PyTorch path;
+the `torch.bmm` split-K fallback is what the fused kernel replaced (3-4x faster than the unsplit library call)."""
 import torch
 from torch import nn
 import torch.nn.functional as F
