@@ -1,5 +1,7 @@
-"""Host model: multi-scale Vision Longformer (MsViT) assembled from stock
-PyTorch-ROCm blocks (GEMMs -> hipBLASLt) around the HIP hot path.
+"""Host model: multi-scale Vision Longformer (MsViT) around the HIP hot path.  On device tensors every layer
+type runs on libvilattn.so: sliding-chunk and dense attention (ops.py), the projections and the patch embedding
+(linear.py: hipBLASLt GEMMs with measured algorithm choice, fused weight/bias gradient), LayerNorm fused with the
+preceding residual add (layernorm.py; `MsViT._run_stage`).  GELU and the loss are stock PyTorch kernels.
 
 Only what the `longformerhand` path needs to be exercised end to end is here:
 the arch-string parser, PatchEmbed, the dense `Attention` of the `s0` stages,

@@ -1,12 +1,13 @@
 """Fused local attention of Vision Longformer as a torch.autograd.Function over
 the C ABI of libvilattn.so (include/vil_attn.h).
 
-Replaces, for the local-query rows, everything between the q/kv projections and
-the output projection of the reference module
-(src/models/layers/longformer2d.py:134-204 and the SlidingChunk2D autograd
-function, src/models/layers/slidingchunk_2d.py:202-246): no chunk/pad/roll
-copies, no score tensor; the backward recomputes probabilities from the saved
-log-sum-exp.
+Replaces everything between the q/kv projections and the output projection of
+the reference module: the local-query rows (src/models/layers/longformer2d.py:134-204
+and the SlidingChunk2D autograd function, src/models/layers/slidingchunk_2d.py:202-246),
+the global-token query rows (longformer2d.py:210-227; `vil_full_attention`) and, as the
+one-chunk case, the dense `Attention` of the s0 stages (msvit.py:91-120;
+`vil_dense_attention`): no chunk/pad/roll copies, no score or (H,N,N) bias tensor;
+the backward recomputes probabilities from the saved log-sum-exp.
 
 PyTorch is plumbing here (device memory, the current HIP stream); the compute
 is the HIP kernels.  There is no eager fallback: CPU tensors or a missing
