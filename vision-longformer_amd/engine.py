@@ -3,11 +3,13 @@
 Counterpart of the reference's loop (src/engine.py:60-195 driven by
 src/run_experiment.py:142-262) reduced to what the throughput metric needs, and
 MI355X-first: one process per GPU, `torch.distributed` backend "nccl" (= RCCL
-over xGMI on ROCm), DistributedDataParallel with `broadcast_buffers=False` (the
-reference re-broadcasts the constant int64 relative_position_index buffers every
-step: 3-66 MB of pure waste) and `gradient_as_bucket_view=True`,
-bf16 autocast with fp32 master weights (no GradScaler needed), and no per-step
-host synchronisation (the reference's meters call .item() every step).
+over xGMI on ROCm); the step is captured as hipGraphs (`GraphedTrainStep`: forward +
+backward, one all-reduce per flat gradient buffer, AdamW) because the eager step is
+host-bound; the eager fallback is DistributedDataParallel with `broadcast_buffers=False`
+(the reference re-broadcasts the constant int64 relative_position_index buffers every
+step: 3-66 MB of pure waste) and `gradient_as_bucket_view=True`.
+bf16 compute with fp32 master weights (`MasterWeightAdamW`; no GradScaler needed), and no
+per-step host synchronisation (the reference's meters call .item() every step).
 The hot path has no collective of its own: (image, head, chunk) units are
 independent, so the batch is simply sharded across ranks."""
 import os
