@@ -343,6 +343,21 @@ def test_model_vil_tiny_vs_reference_logits(dev, golden_dir):
     errb = (lb.double().cpu() - ref).abs().max().item()
     _report(f"     model ViL-Tiny bf16 autocast: max|logit err| = {errb:.3e} (logit range {ref.abs().max():.2f})")
     assert errb < 0.1
+    # bf16 autocast TRAINING step: every fused backward (MFMA dQ / dK/dV with the global rows, dense one-chunk
+    # attention, fused weight/bias gradients, tuned GEMMs, residual-LayerNorm) against the reference's gradient norms
+    model.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lossb = torch.nn.functional.cross_entropy(model(img).float(), tgt)
+    lossb.backward()
+    torch.cuda.synchronize()
+    assert abs(lossb.item() - float(gold["loss"])) < 3e-2
+    worst = 0.0
+    for n, p_ in model.named_parameters():
+        if n in gn:
+            rel = abs(p_.grad.float().norm().item() - gn[n]) / max(gn[n], 1e-3)
+            worst = max(worst, rel)
+            assert rel < 8e-2, (n, p_.grad.float().norm().item(), gn[n])
+    _report(f"     model ViL-Tiny bf16 autocast backward: loss {lossb.item():.5f}, worst gradient-norm rel. err {worst:.3e}")
 
 
 # ---------------------------------------------------------------- block glue: fused LayerNorm
