@@ -16,7 +16,7 @@ def _wgrad_lt(dy2, x2, want_db):
             and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0):
         return None
     import ctypes
-    from . import _lib
+    from vision_longformer_amd import _lib
     L = _lib.lib()
     ws = _GEMM_WS.get(dy2.device)
     if ws is None:

@@ -112,20 +112,20 @@ extern "C" int vil_gemm_bf16(int op, const void* in, const void* w, const void* 
   };
   if (!pl.tuned) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    hipStreamIsCapturing(s, &cs);
+    (void)hipStreamIsCapturing(s, &cs);
     if (cs == hipStreamCaptureStatusNone && pl.cand.size() > 1) {
       hipEvent_t e0, e1;
-      hipEventCreate(&e0); hipEventCreate(&e1);
+      (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
       float best = 1e30f;
       for (const auto& c : pl.cand) {
         if (run(c.algo) != HIPBLAS_STATUS_SUCCESS) continue;                      // warm-up / validity
-        hipEventRecord(e0, s);
+        (void)hipEventRecord(e0, s);
         bool ok = true;
         for (int r = 0; r < 4 && ok; ++r) ok = run(c.algo) == HIPBLAS_STATUS_SUCCESS;
-        hipEventRecord(e1, s);
+        (void)hipEventRecord(e1, s);
         if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
         float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) { best = ms; pl.algo = c.algo; pl.ws = c.workspaceSize; }
       }
       (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
