@@ -727,3 +727,90 @@ def test_library_gemm_selected_algorithm(dev, T, K, N):
     y = _gemm(0, wide.to(dev)[:, K:], w.to(dev), None)
     want = wide[rows, K:].double() @ w.double().t()
     assert (y[rows].float().cpu().double() - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
+
+
+# ---------------------------------------------------------------- seeded fuzz over the op's configuration space
+def _fuzz_cases(n=48, seed=20250926):
+    import random as _r
+    rng = _r.Random(seed)
+    cases = []
+    while len(cases) < n:
+        W = rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 12])
+        M = rng.choice([16, 32, 48, 64])
+        H = rng.choice([1, 2, 3])
+        nx = rng.randint(max(1, W - 1), int(3.5 * W))
+        ny = rng.randint(max(1, W - 1), int(3.5 * W))
+        G = rng.choice([0, 1, 1, 2, 3, 4])
+        mode = rng.choice([0, 0, 0, -1, 1, 2, 3, 4, 5, 6, 7, 8])
+        exact = rng.choice([0, 0, 1]) if mode == 0 else 0
+        cases.append(_case(H, M, W, nx, ny, G, mode=mode, exact=exact, rpe=rng.random() < 0.8, B=rng.choice([1, 2, 3])))
+    return cases
+
+
+@pytest.mark.parametrize("c", _fuzz_cases(), ids=_cid)
+def test_mfma_bf16_fuzz_vs_oracle(c, dev):
+    """Seeded random walk over (heads, head_dim, window, ragged grids, global tokens, modes, exact window, batch):
+    MFMA forward and backward against the oracle."""
+    inp = make_inputs(c, torch.bfloat16, seed=GC.SEED + 1)
+    ref = run_oracle(c, *inp)
+    got = run_hip(c, *inp, torch.bfloat16, "mfma", dev)
+    compare("fuzz mfma/bf16 " + _cid(c), got, ref, BF16_TOL)
+
+
+def _fuzz_full_cases(n=24, seed=777):
+    import random as _r
+    rng = _r.Random(seed)
+    cases = []
+    while len(cases) < n:
+        W = rng.choice([2, 3, 4, 5, 6, 7, 8])
+        M = rng.choice([16, 32, 48, 64])
+        H = rng.choice([1, 2, 3])
+        nx = rng.randint(max(1, W - 1), 3 * W)
+        ny = rng.randint(max(1, W - 1), 3 * W)
+        G = rng.choice([1, 1, 2, 3, 4])
+        mode = rng.choice([0, 0, -1, 1, 3, 6, 8])
+        cases.append(_case(H, M, W, nx, ny, G, mode=mode, exact=0, rpe=rng.random() < 0.8, B=rng.choice([1, 2])))
+    return cases
+
+
+@pytest.mark.parametrize("c", _fuzz_full_cases(), ids=_cid)
+def test_full_attention_fuzz_vs_oracle(c, dev):
+    """vil_full_attention (local rows + global-token query rows, backward through vil_attn_bwd_full) against the
+    oracle's local rows plus a direct fp64 statement of the global rows (reference longformer2d.py:210-227)."""
+    from vision_longformer_amd.ops import vil_full_attention
+    B, H, M, G, W, nx, ny = c["B"], c["H"], c["M"], c["G"], c["W"], c["nx"], c["ny"]
+    C, Nloc = H * M, nx * ny
+    N = G + Nloc
+    g = torch.Generator().manual_seed(GC.SEED + 2)
+    rt = lambda t: t.bfloat16().float()
+    q, kv, dout = rt(torch.randn(B, N, C, generator=g)), rt(torch.randn(B, N, 2 * C, generator=g)), rt(torch.randn(B, N, C, generator=g))
+    table = torch.randn((4 * W - 1) ** 2, H, generator=g) * 0.5 if c["rpe"] else None
+    g2l = torch.randn(2, H, G, generator=g) * 0.5 if c["rpe"] else None
+    g2g = torch.randn(H, G, G, generator=g) * 0.5 if c["rpe"] else None
+    scale = M ** -0.5
+    # ---- fp64 reference
+    L = [t.double().requires_grad_(True) if t is not None else None for t in (q, kv, table, g2l, g2g)]
+    qh = L[0].view(B, N, H, M).transpose(1, 2)                          # (B,H,N,M)
+    kvh = L[1].view(B, N, 2, H, M).permute(2, 0, 3, 1, 4)
+    loc = O.local_attention(qh[:, :, G:], kvh[0], kvh[1], nx, ny, W, G, mode=c["mode"], exact=0,
+                            bias_table=L[2], g2l_bias=L[3][1] if L[3] is not None else None)
+    sg = scale * (qh[:, :, :G] @ kvh[0].transpose(-1, -2))              # (B,H,G,N)
+    if L[3] is not None:
+        sg = sg + torch.cat([L[4], L[3][0].unsqueeze(-1).expand(-1, -1, Nloc)], dim=-1).unsqueeze(0)
+    glo = sg.softmax(-1) @ kvh[1]
+    ref_out = torch.cat([glo, loc], dim=2).transpose(1, 2).reshape(B, N, C)
+    (ref_out * dout.double()).sum().backward()
+    ref = dict(out=ref_out.detach(), dq=L[0].grad, dkv=L[1].grad, dtable=L[2].grad if L[2] is not None else None,
+               dg2l=L[3].grad if L[3] is not None else None, dg2g=L[4].grad if L[4] is not None else None)
+    # ---- HIP
+    D = [t.to(dev, torch.bfloat16 if i < 2 else torch.float32).requires_grad_(True) if t is not None else None
+         for i, t in enumerate((q, kv, table, g2l, g2g))]
+    out = vil_full_attention(D[0], D[1], D[2], D[3], D[4], nx=nx, ny=ny, w=W, nglo=G, num_heads=H, mode=c["mode"],
+                             backend="mfma")
+    out.backward(dout.to(dev, torch.bfloat16))
+    torch.cuda.synchronize()
+    f = lambda t: t.detach().double().cpu() if t is not None else None
+    got = dict(out=f(out), dq=f(D[0].grad), dkv=f(D[1].grad), dtable=f(D[2].grad if D[2] is not None else None),
+               dg2l=f(D[3].grad if D[3] is not None else None), dg2g=f(D[4].grad if D[4] is not None else None))
+    tol = dict(BF16_TOL, dg2g=(2.5e-1, 1e-1))
+    compare("fuzz full mfma/bf16 " + _cid(c), got, ref, tol)
