@@ -251,7 +251,7 @@ static int ln_check(int64_t rows, int C, int64_t s0, int64_t s1) {
 }
 static int ln_blocks(int64_t rows, int rpw) {
   int64_t need = (rows + 4 * rpw - 1) / (4 * rpw);
-  return (int)(need < 512 ? need : 512);
+  return (int)(need < 1024 ? need : 1024);
 }
 
 extern "C" size_t vil_layernorm_workspace_bytes(int64_t rows, int C) {
