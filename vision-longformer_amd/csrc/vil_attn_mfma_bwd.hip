@@ -877,7 +877,7 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   while (bc.dq_wpw > 1 && (size_t)c.tabsize * 8 + (size_t)bc.dq_wpw * bc.dq_wave_lds > 160 * 1024) bc.dq_wpw >>= 1;
   {
     const int dgroups = (bc.dq_units_bh + bc.dq_wpw - 1) / bc.dq_wpw;
-    int dgpw = (int)(((int64_t)d->B * d->H * dgroups) / 2048);
+    int dgpw = (int)(((int64_t)d->B * d->H * dgroups) / 4096);
     if (dgpw < 1) dgpw = 1;
     if (dgpw > dgroups) dgpw = dgroups;
     bc.dq_gpw = dgpw;
