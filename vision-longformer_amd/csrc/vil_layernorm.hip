@@ -64,6 +64,7 @@ struct LNParams {
   // backward dx = gres + LNbwd(dy) and gbranch = rscale[row / rps] * dx in the branch's dtype
   const void* res; int res_bf16; int64_t res_rs;
   const float* rscale; int64_t rps;
+  unsigned rps_magic;        // ceil(2^32 / rps) when row / rps == umulhi(row, magic) for every row of the call, else 0
   float* xout; int64_t xout_rs;
   const float* gres; int64_t gres_rs;
   void* gbranch; int gb_bf16; int64_t gb_rs;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(LNParams p) {
         float r[8];
         if (p.res_bf16) LNIO<vil_bf16>::ld8((const vil_bf16*)p.res + row * p.res_rs + e0, r);
         else LNIO<float>::ld8((const float*)p.res + row * p.res_rs + e0, r);
-        const float sc = p.rscale ? p.rscale[row / p.rps] : 1.0f;
+        const float sc = p.rscale ? p.rscale[p.rps_magic ? (int64_t)__umulhi((unsigned)row, p.rps_magic) : row / p.rps] : 1.0f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[it][i] = fmaf(sc, r[i], v[it][i]);
         LNIO<float>::st8(p.xout + row * p.xout_rs + e0, v[it]);
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(LNParams p) {
           }
           LNIO<TO>::st8((TO*)p.dx + row * p.dx_rs + e0, o);
           if (p.gbranch) {             // gradient of the branch that was added in the forward
-            const float sc = p.rscale ? p.rscale[row / p.rps] : 1.0f;
+            const float sc = p.rscale ? p.rscale[p.rps_magic ? (int64_t)__umulhi((unsigned)row, p.rps_magic) : row / p.rps] : 1.0f;
             float b[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) b[i] = o[i] * sc;
@@ -332,6 +333,16 @@ static int ln_bwd_launch(LNParams& p, int x_dtype, int dy_dtype, hipStream_t s) 
   return (int)hipGetLastError();
 }
 
+// 64-bit division per row and lane is ~50 VALU instructions; one multiply-high when exact for the call's row range
+static unsigned ln_rps_magic(int64_t rows, int64_t rps) {
+  if (rps <= 0 || rps >= (1ll << 31) || rows >= (1ll << 32)) return 0;
+  const uint64_t magic = ((1ull << 32) + (uint64_t)rps - 1) / (uint64_t)rps;     // ceil(2^32 / rps)
+  if (magic >= (1ull << 32)) return 0;
+  // floor(n * magic / 2^32) == floor(n / rps) for all n < rows  <=  rows * (magic * rps - 2^32) < 2^32
+  const uint64_t e = magic * (uint64_t)rps - (1ull << 32);
+  return (e * (uint64_t)rows < (1ull << 32)) ? (unsigned)magic : 0u;
+}
+
 // ---- fused residual + LayerNorm on the fp32 residual stream (contiguous rows)
 extern "C" int vil_resln_fwd(const float* x, const void* res, int res_dtype, const float* rscale, int64_t rows_per_sample,
                              const float* gamma, const float* beta, float* x_out, void* y, int y_dtype,
@@ -346,6 +357,7 @@ extern "C" int vil_resln_fwd(const float* x, const void* res, int res_dtype, con
   p.rows = rows; p.C = C; p.x_rs = C; p.y_rs = C; p.eps = eps;
   p.res = res; p.res_bf16 = res_dtype == VIL_DTYPE_BF16; p.res_rs = C; p.rscale = rscale; p.rps = rows_per_sample;
   p.xout = x_out; p.xout_rs = C;
+  p.rps_magic = ln_rps_magic(rows, rows_per_sample);
   return ln_fwd_launch(p, VIL_DTYPE_F32, y_dtype, (hipStream_t)stream);
 }
 
@@ -364,5 +376,6 @@ extern "C" int vil_resln_bwd(const void* dy, int dy_dtype, const float* gres, co
   p.rows = rows; p.C = C; p.dy_rs = C; p.x_rs = C; p.dx_rs = C;
   p.gres = gres; p.gres_rs = C; p.gbranch = gbranch; p.gb_bf16 = gb_dtype == VIL_DTYPE_BF16; p.gb_rs = C;
   p.rscale = rscale; p.rps = rows_per_sample;
+  p.rps_magic = ln_rps_magic(rows, rows_per_sample);
   return ln_bwd_launch(p, VIL_DTYPE_F32, dy_dtype, (hipStream_t)stream);
 }
