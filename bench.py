@@ -127,6 +127,12 @@ def main():
     opt = MasterWeightAdamW(model, capturable=use_graph) if use_master else make_optimizer(model, capturable=use_graph)
     data = SyntheticBatches(B, img, device, rank)
     if use_graph:
+        def agree(ok):                   # every rank takes the same branch (a lone eager rank would dead-lock the others)
+            if world > 1:
+                flag = torch.tensor([ok], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            return ok
         ok = 1
         try:
             if world > 1:      # same initial weights on every rank (what DDP's constructor would do)
@@ -136,19 +142,19 @@ def main():
                     for m_ in opt.master:
                         dist.broadcast(m_, 0)
             gstep = GraphedTrainStep(model, opt, *data.next(), world=world)
-            # pre-flight: a replayed step must behave like a training step (finite, sane loss) -- on this
-            # stack hipGraph replay mis-orders hipMemsetAsync nodes, which broke PyTorch's multi-block
-            # reductions before every such reduction was moved onto the library's kernels
-            pre = [float(gstep(*data.next())) for _ in range(4)]
-            if not all(v == v and 0.0 < v < 30.0 for v in pre):
-                raise RuntimeError(f"graph replay pre-flight losses {pre}")
         except Exception as exc:          # capture refused: every rank falls back to the eager DDP step together
             print(f"[rank {rank}] hipGraph capture failed ({exc!r}); falling back to the eager step", file=sys.stderr)
             ok = 0
-        if world > 1:
-            flag = torch.tensor([ok], device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
+        ok = agree(ok)
+        if ok:
+            # pre-flight: a replayed step must behave like a training step (finite, sane loss) -- on this stack
+            # hipGraph replay mis-orders hipMemsetAsync nodes, which broke PyTorch's multi-block reductions
+            # before every such reduction was moved onto the library's kernels
+            pre = [float(gstep(*data.next())) for _ in range(4)]
+            good = all(v == v and 0.0 < v < 30.0 for v in pre)
+            if not good:
+                print(f"[rank {rank}] graph replay pre-flight losses {pre}; falling back to the eager step", file=sys.stderr)
+            ok = agree(int(good))
         if not ok:
             use_graph = False
             torch.cuda.synchronize()
