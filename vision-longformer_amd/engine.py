@@ -36,13 +36,15 @@ def init_distributed():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
-    device = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
+    # VIL_SHARE_DEVICE=1 (tests on a 1-GPU box): every rank uses cuda:0 and the collectives go over gloo
+    share = use_cuda and os.environ.get("VIL_SHARE_DEVICE") == "1"
+    device = torch.device("cuda", 0 if share else local_rank) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if use_cuda:
+        if use_cuda and not share:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -272,8 +274,13 @@ class GraphedTrainStep:
                     p.grad = self.views[p]
 
     def _allreduce(self):
+        avg = dist.get_backend() == "nccl"               # gloo (single-device tests) has no AVG
         for f in self.flats:
-            dist.all_reduce(f, op=dist.ReduceOp.AVG)
+            if avg:
+                dist.all_reduce(f, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(f)
+                f.div_(self.world)
 
     def _body(self, eager):
         """the same step launched op by op (warm-up, and the per-kernel profile of bench.py)"""
