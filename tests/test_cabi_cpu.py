@@ -162,3 +162,29 @@ def test_product_path_has_no_cpu_fallback():
         m(torch.randn(1, 65, 32), 8, 8)
     with pytest.raises(AssertionError):
         m(torch.randn(1, 64, 32), 8, 8)   # "Global dimension does not match!"
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py measures the HIP path only: on a box without a GPU it must stop with a clear message instead of
+    timing a CPU fallback (and `--help` must work anywhere)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under the product package may import it."""
+    pkg = os.path.join(ROOT, "vision-longformer_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+    for fn in ("__init__.py",):
+        src = open(os.path.join(ROOT, "vision_longformer_amd", fn)).read()
+        assert "oracle" not in src
