@@ -119,3 +119,10 @@ def sample_big(t):
     flat = t.reshape(-1).to(torch.float64)
     step = max(1, flat.numel() // 4096)
     return flat[::step].clone(), torch.stack([flat.sum(), flat.abs().sum(), (flat * flat).sum()])
+
+
+def model_grad_sample(g, n=512):
+    """Deterministic strided sample (<= n elements) of a model-level gradient tensor."""
+    flat = g.detach().reshape(-1).to(torch.float64).cpu()
+    step = max(1, flat.numel() // n)
+    return flat[::step][:n].clone()

@@ -1,0 +1,467 @@
+"""GPU (-m gpu), collected FIRST: the HIP path, called through the C ABI (ctypes -> libvilattn.so), against the CPU
+oracle on the same seeded inputs, against the golden fixtures frozen from the reference, and -- at BASELINE's full
+sizes -- through size-independent properties.  Nothing in this file depends on the training engine: an engine or
+glue regression (tests/test_gpu_2_glue.py, test_gpu_3_engine.py) cannot hide oracle parity under `-x`.
+Tolerances: tests/gpu_common.py."""
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as GC
+from gpu_common import (ROOT, report, case, cid, make_inputs, run_oracle, run_hip, compare, rms,
+                        F32_TOL, BF16_TOL, LOW_TOL, SMALL)
+from oracle import vil_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def test_layout_probe(dev):
+    """Hardware check of the MFMA fragment / ds_read_b64_tr_b16 layouts the kernels assume."""
+    exe = os.path.join(ROOT, "vision-longformer_amd", "probe_layout")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    report("probe_layout:\n" + r.stdout + r.stderr)
+    assert r.returncode == 0 and "FAIL" not in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("c", SMALL, ids=cid)
+def test_scalar_f32_vs_oracle(c, dev):
+    inp = make_inputs(c, torch.float32)
+    ref = run_oracle(c, *inp)
+    got = run_hip(c, *inp, torch.float32, "scalar", dev)
+    compare("scalar/f32 " + cid(c), got, ref, F32_TOL)
+
+
+@pytest.mark.parametrize("c", SMALL, ids=cid)
+def test_scalar_bf16_vs_oracle(c, dev):
+    inp = make_inputs(c, torch.bfloat16)
+    ref = run_oracle(c, *inp)
+    got = run_hip(c, *inp, torch.bfloat16, "scalar", dev)
+    compare("scalar/bf16 " + cid(c), got, ref, BF16_TOL)
+
+
+MFMA_CASES = [c for c in SMALL if c["exact"] != -1 and not c["only_glo"] and c["M"] in (16, 32, 48, 64)]
+
+
+@pytest.mark.parametrize("c", MFMA_CASES, ids=cid)
+def test_mfma_bf16_vs_oracle(c, dev):
+    """MFMA forward AND backward (backend forced: unsupported shapes would raise) on bf16 I/O."""
+    inp = make_inputs(c, torch.bfloat16)
+    ref = run_oracle(c, *inp)
+    got = run_hip(c, *inp, torch.bfloat16, "mfma", dev)
+    compare("mfma/bf16 " + cid(c), got, ref, BF16_TOL)
+
+
+def test_mfma_forced_rescale_branch(dev):
+    """The deferred-max rescale is rare on random data: force it with a spiked key
+    (cdna guide 5.4 rule 26) late in the key order and check against the oracle."""
+    c = case(2, 32, 7, 14, 14, 1)
+    q, kv, table, g2l, dout = make_inputs(c, torch.bfloat16)
+    C = c["H"] * c["M"]
+    # token (13,13) is visited last by chunk (1,1); align its key with query (8,8)
+    qi = 8 * 14 + 8
+    ki = 1 + 13 * 14 + 13
+    kv[:, ki, :C] = (q[:, qi] * 6).bfloat16().float()
+    ref = run_oracle(c, q, kv, table, g2l, dout)
+    got = run_hip(c, q, kv, table, g2l, dout, torch.bfloat16, "mfma", dev)
+    compare("mfma spike " + cid(c), got, ref, BF16_TOL)
+
+
+def _fuzz_cases(n=48, seed=20250926):
+    import random as _r
+    rng = _r.Random(seed)
+    cases = []
+    while len(cases) < n:
+        W = rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 12])
+        M = rng.choice([16, 32, 48, 64])
+        H = rng.choice([1, 2, 3])
+        nx = rng.randint(max(1, W - 1), int(3.5 * W))
+        ny = rng.randint(max(1, W - 1), int(3.5 * W))
+        G = rng.choice([0, 1, 1, 2, 3, 4])
+        mode = rng.choice([0, 0, 0, -1, 1, 2, 3, 4, 5, 6, 7, 8])
+        exact = rng.choice([0, 0, 1]) if mode == 0 else 0
+        cases.append(case(H, M, W, nx, ny, G, mode=mode, exact=exact, rpe=rng.random() < 0.8, B=rng.choice([1, 2, 3])))
+    return cases
+
+
+@pytest.mark.parametrize("c", _fuzz_cases(), ids=cid)
+def test_mfma_bf16_fuzz_vs_oracle(c, dev):
+    """Seeded random walk over (heads, head_dim, window, ragged grids, global tokens, modes, exact window, batch):
+    MFMA forward and backward against the oracle."""
+    inp = make_inputs(c, torch.bfloat16, seed=GC.SEED + 1)
+    ref = run_oracle(c, *inp)
+    got = run_hip(c, *inp, torch.bfloat16, "mfma", dev)
+    compare("fuzz mfma/bf16 " + cid(c), got, ref, BF16_TOL)
+
+
+def _fuzz_full_cases(n=24, seed=777):
+    import random as _r
+    rng = _r.Random(seed)
+    cases = []
+    while len(cases) < n:
+        W = rng.choice([2, 3, 4, 5, 6, 7, 8])
+        M = rng.choice([16, 32, 48, 64])
+        H = rng.choice([1, 2, 3])
+        nx = rng.randint(max(1, W - 1), 3 * W)
+        ny = rng.randint(max(1, W - 1), 3 * W)
+        G = rng.choice([1, 1, 2, 3, 4])
+        mode = rng.choice([0, 0, -1, 1, 3, 6, 8])
+        cases.append(case(H, M, W, nx, ny, G, mode=mode, exact=0, rpe=rng.random() < 0.8, B=rng.choice([1, 2])))
+    return cases
+
+
+@pytest.mark.parametrize("c", _fuzz_full_cases(), ids=cid)
+def test_full_attention_fuzz_vs_oracle(c, dev):
+    """vil_full_attention (local rows + global-token query rows, backward through vil_attn_bwd_full) against the
+    oracle's local rows plus a direct fp64 statement of the global rows (reference longformer2d.py:210-227)."""
+    from vision_longformer_amd.ops import vil_full_attention
+    B, H, M, G, W, nx, ny = c["B"], c["H"], c["M"], c["G"], c["W"], c["nx"], c["ny"]
+    C, Nloc = H * M, nx * ny
+    N = G + Nloc
+    g = torch.Generator().manual_seed(GC.SEED + 2)
+    rt = lambda t: t.bfloat16().float()
+    q, kv, dout = rt(torch.randn(B, N, C, generator=g)), rt(torch.randn(B, N, 2 * C, generator=g)), rt(torch.randn(B, N, C, generator=g))
+    table = torch.randn((4 * W - 1) ** 2, H, generator=g) * 0.5 if c["rpe"] else None
+    g2l = torch.randn(2, H, G, generator=g) * 0.5 if c["rpe"] else None
+    g2g = torch.randn(H, G, G, generator=g) * 0.5 if c["rpe"] else None
+    scale = M ** -0.5
+    # ---- fp64 reference
+    L = [t.double().requires_grad_(True) if t is not None else None for t in (q, kv, table, g2l, g2g)]
+    qh = L[0].view(B, N, H, M).transpose(1, 2)                          # (B,H,N,M)
+    kvh = L[1].view(B, N, 2, H, M).permute(2, 0, 3, 1, 4)
+    loc = O.local_attention(qh[:, :, G:], kvh[0], kvh[1], nx, ny, W, G, mode=c["mode"], exact=0,
+                            bias_table=L[2], g2l_bias=L[3][1] if L[3] is not None else None)
+    sg = scale * (qh[:, :, :G] @ kvh[0].transpose(-1, -2))              # (B,H,G,N)
+    if L[3] is not None:
+        sg = sg + torch.cat([L[4], L[3][0].unsqueeze(-1).expand(-1, -1, Nloc)], dim=-1).unsqueeze(0)
+    glo = sg.softmax(-1) @ kvh[1]
+    ref_out = torch.cat([glo, loc], dim=2).transpose(1, 2).reshape(B, N, C)
+    (ref_out * dout.double()).sum().backward()
+    ref = dict(out=ref_out.detach(), dq=L[0].grad, dkv=L[1].grad, dtable=L[2].grad if L[2] is not None else None,
+               dg2l=L[3].grad if L[3] is not None else None, dg2g=L[4].grad if L[4] is not None else None)
+    # ---- HIP
+    D = [t.to(dev, torch.bfloat16 if i < 2 else torch.float32).requires_grad_(True) if t is not None else None
+         for i, t in enumerate((q, kv, table, g2l, g2g))]
+    out = vil_full_attention(D[0], D[1], D[2], D[3], D[4], nx=nx, ny=ny, w=W, nglo=G, num_heads=H, mode=c["mode"],
+                             backend="mfma")
+    out.backward(dout.to(dev, torch.bfloat16))
+    torch.cuda.synchronize()
+    f = lambda t: t.detach().double().cpu() if t is not None else None
+    got = dict(out=f(out), dq=f(D[0].grad), dkv=f(D[1].grad), dtable=f(D[2].grad if D[2] is not None else None),
+               dg2l=f(D[3].grad if D[3] is not None else None), dg2g=f(D[4].grad if D[4] is not None else None))
+    tol = BF16_TOL
+    compare("fuzz full mfma/bf16 " + cid(c), got, ref, tol)
+
+
+# ---------------------------------------------------------------- module level vs golden
+def _load_module(c, dev, dtype):
+    from vision_longformer_amd.longformer2d import Long2DSCSelfAttention
+    params, x, dout = GC.module_inputs(c, dtype=torch.float64)
+    mod = Long2DSCSelfAttention(c["dim"], num_heads=c["H"], qkv_bias=True, w=c["W"], sharew=c["sharew"],
+                                nglo=c["G"], only_glo=c["only_glo"], exact=c["exact"], rpe=c["rpe"],
+                                mode=(1 if c["mode"] > 0 else c["mode"]))
+    sd = mod.state_dict()
+    for k in sd:
+        if k in params:
+            sd[k] = params[k].to(sd[k].dtype)
+    mod.load_state_dict(sd)
+    return mod.to(dev), x, dout
+
+
+@pytest.mark.parametrize("c", GC.MODULE_CASES, ids=lambda c: c["name"])
+def test_module_fp32_vs_golden(c, dev, golden_dir):
+    import random
+    gold = np.load(os.path.join(golden_dir, "module_cases.npz"))
+    mod, x, dout = _load_module(c, dev, torch.float32)
+    mod.backend = "scalar"
+    mod.train()
+    orig = random.randrange
+    random.randrange = (lambda a, b=None, _m=c["mode"]: _m)
+    try:
+        xd = x.float().to(dev).requires_grad_(True)
+        out = mod(xd, c["nx"], c["ny"])
+        out.backward(dout.float().to(dev))
+    finally:
+        random.randrange = orig
+    torch.cuda.synchronize()
+    pre = c["name"] + "/"
+
+    def check(nm, t, atol, rtol):
+        t = t.detach().double().cpu()
+        if pre + nm in gold.files:
+            ref = torch.from_numpy(gold[pre + nm])
+            torch.testing.assert_close(t, ref, atol=atol, rtol=rtol, msg=lambda m: f"{pre}{nm}: {m}")
+        else:
+            s, _ = GC.sample_big(t)
+            ref = torch.from_numpy(gold[pre + nm + "@sample"])
+            torch.testing.assert_close(s, ref, atol=atol, rtol=rtol, msg=lambda m: f"{pre}{nm}: {m}")
+
+    check("out", out, 1e-4, 1e-4)
+    check("dx", xd.grad, 3e-4, 1e-3)
+    for n, p_ in mod.named_parameters():
+        if p_.grad is not None and ((pre + "d_" + n) in gold.files or (pre + "d_" + n + "@sample") in gold.files):
+            scale = max(1.0, float(p_.grad.abs().max()))
+            check("d_" + n, p_.grad, 2e-3 * scale, 2e-3)
+    report("ok   module/f32 " + c["name"])
+
+
+@pytest.mark.parametrize("c", GC.MODULE_CASES, ids=lambda c: c["name"])
+def test_module_bf16_autocast_vs_golden(c, dev, golden_dir):
+    """bf16 autocast through the module (MFMA family wherever it applies) against the REFERENCE's fp64 fixtures:
+    the forward output AND, element-wise, dx and every parameter gradient (not just norms: a permutation or sign
+    error inside a gradient tensor would keep its norm)."""
+    import random
+    gold = np.load(os.path.join(golden_dir, "module_cases.npz"))
+    mod, x, dout = _load_module(c, dev, torch.float32)
+    mod.train()
+    orig = random.randrange
+    random.randrange = (lambda a, b=None, _m=c["mode"]: _m)
+    try:
+        xd = x.float().to(dev).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = mod(xd, c["nx"], c["ny"])
+        out.backward(dout.to(dev, out.dtype))
+    finally:
+        random.randrange = orig
+    torch.cuda.synchronize()
+    pre = c["name"] + "/"
+
+    def ref_of(nm, t):
+        t = t.detach().double().cpu()
+        if pre + nm in gold.files:
+            return t, torch.from_numpy(gold[pre + nm])
+        if pre + nm + "@sample" in gold.files:
+            return GC.sample_big(t)[0], torch.from_numpy(gold[pre + nm + "@sample"])
+        return None, None
+
+    t, ref = ref_of("out", out)
+    err = (t - ref).abs().max().item()
+    report(f"     module/bf16-autocast {c['name']} max|err|={err:.3e} (ref max {ref.abs().max().item():.2f})")
+    assert err < 0.06 * max(1.0, ref.abs().max().item())
+    # backward: bf16 GEMMs + bf16 attention I/O against fp64; bounds relative to each tensor's rms
+    worst = []
+    got, want, tols = {}, {}, {}
+    t, ref = ref_of("dx", xd.grad)
+    got["dx"], want["dx"], tols["dx"] = t, ref, ("rms", 0.2, 5e-2)
+    for n, p_ in mod.named_parameters():
+        if p_.grad is None:
+            continue
+        t, ref = ref_of("d_" + n, p_.grad)
+        if ref is not None:
+            got["d_" + n], want["d_" + n] = t, ref
+            tols["d_" + n] = ("rms", 0.1, 5e-2)
+    assert len(tols) >= 4, "golden gradients missing"
+    compare("module/bf16-autocast backward " + c["name"], got, want, tols)
+
+
+# ---------------------------------------------------------------- full-size properties
+FULL = [
+    ("small_s1", case(3, 32, 7, 56, 56, 1, B=8)),
+    ("small_s2", case(3, 64, 7, 28, 28, 1, B=8)),
+    ("meddeep_s1_f7", case(3, 32, 7, 96, 96, 1, B=2)),
+    ("meddeep_s2_f12", case(3, 64, 12, 48, 48, 1, B=2)),
+    ("basedeep_s1_f6_rs", case(3, 32, 6, 96, 96, 1, B=2, mode=4)),
+    ("basedeep_s2_f8_rs", case(3, 64, 8, 48, 48, 1, B=2, mode=6)),
+]
+
+
+@pytest.mark.parametrize("name,c", FULL, ids=[n for n, _ in FULL])
+def test_full_size_properties(name, c, dev):
+    """BASELINE shapes: (1) softmax rows sum to one: v == const -> out == const;
+    (2) linearity in v; (3) MFMA forward agrees with the scalar fp32-math family;
+    (4) one sampled image against the oracle."""
+    from vision_longformer_amd.ops import vil_local_attention
+    q, kv, table, g2l, dout = make_inputs(c, torch.bfloat16, seed=11)
+    C = c["H"] * c["M"]
+    kw = dict(nx=c["nx"], ny=c["ny"], w=c["W"], nglo=c["G"], num_heads=c["H"], mode=c["mode"], exact=c["exact"])
+    qd, kvd = q.to(dev, torch.bfloat16), kv.to(dev, torch.bfloat16)
+    tab, g2 = table.to(dev), g2l.to(dev)
+    with torch.no_grad():
+        kv1 = kvd.clone(); kv1[..., C:] = 0.75
+        o1 = vil_local_attention(qd, kv1, tab, g2, **kw)
+        assert (o1.float() - 0.75).abs().max().item() < 8e-3
+        kv2 = kvd.clone(); kv2[..., C:] = kv2[..., C:] * 2
+        oa = vil_local_attention(qd, kvd, tab, g2, **kw).float()
+        ob = vil_local_attention(qd, kv2, tab, g2, **kw).float()
+        assert (ob - 2 * oa).abs().max().item() < 4e-2
+        os_ = vil_local_attention(qd, kvd, tab, g2, backend="scalar", **kw).float()
+        d = (oa - os_).abs().max().item()
+        report(f"     full {name}: |mfma - scalar| = {d:.3e}")
+        assert d < 3e-2
+    c1 = dict(c, B=1)
+    ref = run_oracle(c1, q[:1], kv[:1], table, g2l, dout[:1])
+    got = run_hip(c1, q[:1], kv[:1], table, g2l, dout[:1], torch.bfloat16, "mfma", dev)
+    compare("full " + name, got, ref, BF16_TOL)
+
+
+# ---------------------------------------------------------------- dense attention (s0 stages)
+def _dense_reference(qkv, table, g2l, g2g, nx, ny, G, H, scale):
+    """fp64 restatement of the reference's dense Attention.forward (src/models/msvit.py:91-120)."""
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    M = C // H
+    q, k, v = qkv.view(B, N, 3, H, M).permute(2, 0, 3, 1, 4)
+    attn = (q @ k.transpose(-2, -1)) * scale
+    if table is not None:
+        L = nx * ny
+        ix, iy = torch.meshgrid(torch.arange(nx), torch.arange(ny), indexing="ij")
+        ix, iy = ix.reshape(-1), iy.reshape(-1)
+        rel = (ix[:, None] - ix[None, :] + nx - 1) * (2 * ny - 1) + (iy[:, None] - iy[None, :] + ny - 1)
+        loc = table[rel.reshape(-1)].view(L, L, H).permute(2, 0, 1)
+        if G > 0:
+            top = torch.cat([g2g, g2l[0].unsqueeze(-1).expand(-1, -1, L)], dim=-1)
+            bot = torch.cat([g2l[1].unsqueeze(1).expand(-1, L, -1), loc], dim=-1)
+            bias = torch.cat([top, bot], dim=1)
+        else:
+            bias = loc
+        attn = attn + bias.unsqueeze(0)
+    attn = attn.softmax(dim=-1)
+    return (attn @ v).transpose(1, 2).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("nx,G,H,M,B,rpe", [(14, 1, 6, 64, 2, True), (7, 0, 12, 64, 2, True), (24, 1, 6, 64, 1, True),
+                                             (12, 0, 12, 64, 1, True), (5, 2, 2, 16, 2, True), (14, 1, 3, 32, 2, False),
+                                             (9, 1, 2, 48, 2, True)])
+def test_dense_attention_one_chunk_vs_reference(dev, nx, G, H, M, B, rpe):
+    from vision_longformer_amd.ops import vil_dense_attention
+    g = torch.Generator().manual_seed(17)
+    N, C = G + nx * nx, H * M
+    qkv = torch.randn(B, N, 3 * C, generator=g).bfloat16().float()
+    dout = torch.randn(B, N, C, generator=g).bfloat16().float()
+    table = torch.randn((2 * nx - 1) ** 2, H, generator=g) * 0.5 if rpe else None
+    g2l = torch.randn(2, H, G, generator=g) * 0.5 if (rpe and G) else None
+    g2g = torch.randn(H, G, G, generator=g) * 0.5 if (rpe and G) else None
+    scale = M ** -0.5
+    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (qkv, table, g2l, g2g)]
+    ref = _dense_reference(leaves[0], leaves[1], leaves[2], leaves[3], nx, nx, G, H, scale)
+    (ref * dout.double()).sum().backward()
+    dl = [t.to(dev, torch.bfloat16 if i == 0 else torch.float32).requires_grad_(True) if t is not None else None
+          for i, t in enumerate((qkv, table, g2l, g2g))]
+    out = vil_dense_attention(dl[0], dl[1], dl[2], dl[3], nx=nx, ny=nx, nglo=G, num_heads=H, scale=scale, backend="mfma")
+    out.backward(dout.to(dev, torch.bfloat16))
+    torch.cuda.synchronize()
+    got = dict(out=out.detach().double().cpu(), dqkv=dl[0].grad.double().cpu())
+    want = dict(out=ref.detach(), dqkv=leaves[0].grad)
+    for nm, i in (("dtable", 1), ("dg2l", 2), ("dg2g", 3)):
+        if leaves[i] is not None:
+            got[nm] = dl[i].grad.double().cpu(); want[nm] = leaves[i].grad
+    tol = {k: BF16_TOL[k] for k in ("out", "dqkv", "dtable", "dg2l", "dg2g")}
+    compare(f"dense one-chunk nx{nx} G{G} H{H} M{M}", got, want, tol)
+
+
+@pytest.mark.parametrize("nx,W,M,H", [(16, 4, 32, 2), (20, 7, 64, 3), (21, 6, 32, 2)])
+def test_device_side_random_shift_mode(dev, nx, W, M, H):
+    """VilAttnDesc.mode_dev: the neighbour read from a device word must give exactly the result of the same
+    neighbour passed in the descriptor (forward and every gradient), for all 8 neighbours."""
+    from vision_longformer_amd.ops import vil_full_attention
+    g = torch.Generator().manual_seed(11)
+    B, G, C = 2, 1, H * M
+    N = G + nx * nx
+    q0 = torch.randn(B, N, C, generator=g).to(dev, torch.bfloat16)
+    kv0 = torch.randn(B, N, 2 * C, generator=g).to(dev, torch.bfloat16)
+    tab0 = (torch.randn((4 * W - 1) ** 2, H, generator=g) * 0.3).to(dev)
+    g2l0 = (torch.randn(2, H, G, generator=g) * 0.3).to(dev)
+    g2g0 = (torch.randn(H, G, G, generator=g) * 0.3).to(dev)
+    dout = torch.randn(B, N, C, generator=g).to(dev, torch.bfloat16)
+    word = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def run(mode, mode_dev):
+        leaves = [t.clone().requires_grad_(True) for t in (q0, kv0, tab0, g2l0, g2g0)]
+        out = vil_full_attention(*leaves, nx=nx, ny=nx, w=W, nglo=G, num_heads=H, mode=mode, mode_dev=mode_dev)
+        out.backward(dout)
+        torch.cuda.synchronize()
+        return [out.detach()] + [t.grad for t in leaves]
+
+    for m in range(1, 9):
+        ref = run(m, None)
+        word.fill_(m)
+        got = run(1 if m != 1 else 2, word)              # the descriptor's static mode must be ignored
+        for name, a, b in zip(("out", "dq", "dkv", "dtable", "dg2l", "dg2g"), got, ref):
+            if name in ("dg2l", "dg2g"):                  # float atomics: order-dependent in the last bits
+                torch.testing.assert_close(a, b, atol=1e-4, rtol=1e-4, msg=f"mode {m} {name}")
+            else:
+                assert torch.equal(a, b), f"mode {m}: {name} differs"
+
+
+# ---------------------------------------------------------------- model level (BASELINE config 1)
+def test_model_vil_tiny_vs_reference_logits(dev, golden_dir):
+    """ViL-Tiny 224, B=2: the build's MsViT (HIP hot path, fp32) against logits / loss /
+    gradient norms produced by the REFERENCE MsViT loaded with the same state dict."""
+    from vision_longformer_amd.engine import build_vil
+    gold = np.load(os.path.join(golden_dir, "model_tiny.npz"))
+    torch.manual_seed(0)
+    model = build_vil("vil_tiny_224", drop_path_rate=0.0).double()
+    with torch.no_grad():
+        for n, p_ in model.named_parameters():
+            if "relative_position" in n:
+                p_.normal_(0, 0.3)
+    model = model.float().to(dev).train()
+    for m in model.modules():
+        if hasattr(m, "backend"):
+            m.backend = "scalar"
+    g = torch.Generator().manual_seed(GC.SEED)
+    img = torch.randn(2, 3, 224, 224, generator=g, dtype=torch.float64).float().to(dev)
+    tgt = torch.tensor([3, 977], device=dev)
+    logits = model(img)
+    loss = torch.nn.functional.cross_entropy(logits, tgt)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(gold["logits"])
+    err = (logits.detach().double().cpu() - ref).abs().max().item()
+    report(f"     model ViL-Tiny fp32: max|logit err| = {err:.3e}, loss {loss.item():.6f} vs {float(gold['loss']):.6f}")
+    assert err < 2e-3
+    assert abs(loss.item() - float(gold["loss"])) < 1e-4
+    gn = dict(zip([str(s) for s in gold["grad_names"]], gold["grad_norms"]))
+    def sampled(tag, k, rtol, cos_min):
+        """sampled gradient ELEMENTS against the reference's (norms are blind to permutation / sign errors)"""
+        worst_r, worst_c = 0.0, 1.0
+        for n, p_ in model.named_parameters():
+            if n in gn:
+                ref_s = torch.from_numpy(gold["gsample/" + n])
+                got_s = GC.model_grad_sample(p_.grad)
+                err = (got_s - ref_s).abs()
+                lim = k * max(rms(ref_s), 1e-12) + rtol * ref_s.abs()
+                cos = float((got_s * ref_s).sum() / (got_s.norm() * ref_s.norm()).clamp_min(1e-30))
+                worst_r, worst_c = max(worst_r, float((err / lim).max())), min(worst_c, cos)
+                assert bool((err <= lim).all()), (tag, n, float(err.max()), rms(ref_s))
+                assert cos > cos_min, (tag, n, cos)
+        report(f"     model ViL-Tiny {tag}: sampled gradient elements worst err/lim {worst_r:.2f}, worst cosine {worst_c:.6f}")
+
+    for n, p_ in model.named_parameters():
+        if n in gn:
+            assert abs(p_.grad.norm().item() - gn[n]) < 2e-3 * max(1.0, gn[n]), n
+    sampled("fp32", 2e-3, 2e-3, 0.999999)
+    # bf16 autocast, MFMA forward
+    for m in model.modules():
+        if hasattr(m, "backend"):
+            m.backend = None
+    with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+        lb = model(img)
+    errb = (lb.double().cpu() - ref).abs().max().item()
+    report(f"     model ViL-Tiny bf16 autocast: max|logit err| = {errb:.3e} (logit range {ref.abs().max():.2f})")
+    assert errb < 0.1
+    # bf16 autocast TRAINING step: every fused backward (MFMA dQ / dK/dV with the global rows, dense one-chunk
+    # attention, fused weight/bias gradients, tuned GEMMs, residual-LayerNorm) against the reference's gradient norms
+    model.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lossb = torch.nn.functional.cross_entropy(model(img).float(), tgt)
+    lossb.backward()
+    torch.cuda.synchronize()
+    assert abs(lossb.item() - float(gold["loss"])) < 3e-2
+    worst = 0.0
+    for n, p_ in model.named_parameters():
+        if n in gn:
+            rel = abs(p_.grad.float().norm().item() - gn[n]) / max(gn[n], 1e-3)
+            worst = max(worst, rel)
+            assert rel < 8e-2, (n, p_.grad.float().norm().item(), gn[n])
+    report(f"     model ViL-Tiny bf16 autocast backward: loss {lossb.item():.5f}, worst gradient-norm rel. err {worst:.3e}")
+    sampled("bf16 autocast", 0.3, 0.1, 0.995)

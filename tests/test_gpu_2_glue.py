@@ -1,0 +1,168 @@
+"""GPU (-m gpu): the block-glue kernels around the hot path against fp64 references: fused
+LayerNorm / residual-LayerNorm, bias-gradient column sums, fused weight+bias gradient, library GEMM wrapper."""
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as GC
+from gpu_common import (ROOT, report, case, cid, make_inputs, run_oracle, run_hip, compare, rms,
+                        F32_TOL, BF16_TOL, LOW_TOL, SMALL)
+from oracle import vil_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    return torch.device("cuda:0")
+
+
+# ---------------------------------------------------------------- block glue: fused LayerNorm
+@pytest.mark.parametrize("C,rows", [(96, 1000), (48, 333), (192, 4097), (384, 777), (768, 130), (16, 70)])
+@pytest.mark.parametrize("mode", ["fp32", "fp32_to_bf16", "bf16"])
+def test_fused_layernorm_vs_torch(dev, C, rows, mode):
+    from vision_longformer_amd.layernorm import VilLayerNorm
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5)
+    dy = torch.randn(rows, C, generator=g)
+    ln = VilLayerNorm(C, eps=1e-6).to(dev)
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.3); ln.bias.normal_(0, 0.3)
+    ref = torch.nn.LayerNorm(C, eps=1e-6).double()
+    ref.weight.data.copy_(ln.weight.detach().double().cpu()); ref.bias.data.copy_(ln.bias.detach().double().cpu())
+    xin_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+    xd = x.to(xin_dtype).to(dev).requires_grad_(True)
+    xr = x.to(xin_dtype).double().requires_grad_(True)
+    if mode == "fp32_to_bf16":
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = ln(xd)
+        assert y.dtype == torch.bfloat16
+    else:
+        y = ln(xd)
+        assert y.dtype == xin_dtype
+    dyd = dy.to(y.dtype).to(dev)
+    y.backward(dyd)
+    yr = ref(xr)
+    yr.backward(dyd.double().cpu())
+    torch.cuda.synchronize()
+    lo = mode != "fp32"
+    torch.testing.assert_close(y.double().cpu(), yr.detach(), atol=3e-2 if lo else 2e-5, rtol=2e-2 if lo else 1e-5)
+    torch.testing.assert_close(xd.grad.double().cpu(), xr.grad, atol=3e-2 if mode == "bf16" else 2e-4, rtol=2e-2 if mode == "bf16" else 1e-4)
+    gs = max(1.0, float(ref.weight.grad.abs().max()))
+    torch.testing.assert_close(ln.weight.grad.double().cpu(), ref.weight.grad, atol=2e-3 * gs, rtol=2e-3)
+    torch.testing.assert_close(ln.bias.grad.double().cpu(), ref.bias.grad, atol=2e-3 * gs, rtol=2e-3)
+
+
+@pytest.mark.parametrize("rows,C", [(25216, 384), (1000, 96), (6400, 3072), (777, 1152), (5, 8)])
+def test_colsum_bias_gradient(dev, rows, C):
+    """db of the projections (vil_colsum_bf16) against an fp64 column sum."""
+    from vision_longformer_amd.linear import _colsum
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(rows, C, generator=g).bfloat16()
+    got = _colsum(x.to(dev)).float().cpu().double()
+    want = x.double().sum(0)
+    err = (got - want).abs().max().item()
+    tol = 4e-3 * max(1.0, want.abs().max().item())          # bf16 output rounding
+    assert err <= tol, (err, tol)
+    # strided view (a column slice of a wider matrix), as dY of a fused qkv projection would be
+    wide = torch.randn(rows, 2 * C, generator=g).bfloat16()
+    got = _colsum(wide.to(dev)[:, C:]).float().cpu().double()
+    want = wide[:, C:].double().sum(0)
+    assert (got - want).abs().max().item() <= 4e-3 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("T,CO,CI", [(25216, 1536, 384), (25216, 384, 1536), (6272, 3072, 768), (100480, 192, 576),
+                                      (40000, 96, 288), (1031, 40, 72), (4096, 1000, 768)])
+def test_linear_wgrad_fused(dev, T, CO, CI):
+    """dW = dY^T X and db = colsum(dY) (vil_linear_wgrad) against fp64 on the same bf16 inputs."""
+    from vision_longformer_amd.linear import _wgrad
+    g = torch.Generator().manual_seed(9)
+    dy = (torch.randn(T, CO, generator=g) * 0.1).bfloat16()
+    x = torch.randn(T, CI, generator=g).bfloat16()
+    res = _wgrad(dy.to(dev), x.to(dev), True)
+    assert res is not None
+    dw, db = res
+    torch.cuda.synchronize()
+    sub = slice(0, min(CO, 256))                               # fp64 reference on a slab of output rows (CPU time)
+    want = dy[:, sub].double().t() @ x.double()
+    got = dw[sub].float().cpu().double()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 6e-3 * scale, ((got - want).abs().max().item(), scale)
+    wdb = dy.double().sum(0)
+    assert (db.float().cpu().double() - wdb).abs().max().item() <= 6e-3 * max(1.0, wdb.abs().max().item())
+    # strided operands: column slices of wider matrices (dY of a packed projection)
+    wide = (torch.randn(T, 2 * CO, generator=g) * 0.1).bfloat16()
+    res = _wgrad(wide.to(dev)[:, CO:], x.to(dev), False)
+    want = wide[:, CO:][:, sub].double().t() @ x.double()
+    got = res[0][sub].float().cpu().double()
+    assert (got - want).abs().max().item() <= 6e-3 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("B,N,C,bdt", [(4, 197, 384, torch.bfloat16), (2, 50, 768, torch.bfloat16), (3, 785, 192, torch.float32),
+                                        (2, 3137, 96, torch.bfloat16)])
+def test_residual_layernorm_fused(dev, B, N, C, bdt):
+    """vil_resln_fwd/_bwd: (x + s*branch, LN(x + s*branch)) and all gradients against fp64."""
+    from vision_longformer_amd.layernorm import VilLayerNorm, res_layernorm
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, N, C, generator=g)
+    br = torch.randn(B, N, C, generator=g).to(bdt).float()
+    sc = torch.tensor([0.0, 1.25, 1.25, 0.0][:B])
+    ln = VilLayerNorm(C, eps=1e-6).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * torch.randn(C, generator=g)); ln.bias.copy_(0.1 * torch.randn(C, generator=g))
+    gx = torch.randn(B, N, C, generator=g)
+    gy = torch.randn(B, N, C, generator=g).bfloat16().float()
+    # fp64 reference
+    xr, brr = x.double().requires_grad_(True), br.double().requires_grad_(True)
+    wr, b_r = ln.weight.detach().double().cpu().requires_grad_(True), ln.bias.detach().double().cpu().requires_grad_(True)
+    xn_r = xr + sc.double().view(B, 1, 1) * brr
+    y_r = torch.nn.functional.layer_norm(xn_r, (C,), wr, b_r, 1e-6)
+    ((xn_r * gx.double()).sum() + (y_r * gy.double()).sum()).backward()
+    # fused
+    xd, brd = x.to(dev).requires_grad_(True), br.to(dev, bdt).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        xn, y = res_layernorm(xd, brd, sc.to(dev), ln)
+    assert y.dtype == torch.bfloat16 and xn.dtype == torch.float32
+    ((xn * gx.to(dev)).sum() + (y.float() * gy.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(xn.detach().double().cpu(), xn_r.detach(), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(y.detach().double().cpu(), y_r.detach(), atol=3e-2, rtol=1e-2)
+    torch.testing.assert_close(xd.grad.double().cpu(), xr.grad, atol=1e-4, rtol=1e-4)
+    tolb = dict(atol=2e-2, rtol=1e-2) if bdt == torch.bfloat16 else dict(atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(brd.grad.double().cpu(), brr.grad, **tolb)
+    gs = float(wr.grad.abs().max())
+    torch.testing.assert_close(ln.weight.grad.double().cpu(), wr.grad, atol=2e-3 * gs, rtol=2e-3)
+    torch.testing.assert_close(ln.bias.grad.double().cpu(), b_r.grad, atol=2e-3 * float(b_r.grad.abs().max()), rtol=2e-3)
+
+
+@pytest.mark.parametrize("T,K,N", [(25216, 384, 1536), (25216, 1536, 384), (6400, 768, 3072), (100480, 192, 576),
+                                    (4000, 96, 288), (197, 768, 1000), (8, 48, 96)])
+def test_library_gemm_selected_algorithm(dev, T, K, N):
+    """vil_gemm_bf16 (hipBLASLt, measured algorithm choice): forward with bias and input gradient vs fp64."""
+    from vision_longformer_amd.linear import _gemm
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(T, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    dy = torch.randn(T, N, generator=g).bfloat16()
+    rows = slice(0, min(T, 512))
+    for rep in range(2):                                       # first call tunes, second uses the cached plan
+        y = _gemm(0, x.to(dev), w.to(dev), b.to(dev))
+        assert y is not None and y.shape == (T, N)
+        want = x[rows].double() @ w.double().t() + b.double()
+        err = (y[rows].float().cpu().double() - want).abs().max().item()
+        assert err <= 2e-2 * max(1.0, want.abs().max().item()), err
+        dx = _gemm(1, dy.to(dev), w.to(dev), None)
+        want = dy[rows].double() @ w.double()
+        err = (dx[rows].float().cpu().double() - want).abs().max().item()
+        assert err <= 2e-2 * max(1.0, want.abs().max().item()), err
+    # strided input rows (a column slice of a wider matrix)
+    wide = torch.randn(T, 2 * K, generator=g).bfloat16()
+    y = _gemm(0, wide.to(dev)[:, K:], w.to(dev), None)
+    want = wide[rows, K:].double() @ w.double().t()
+    assert (y[rows].float().cpu().double() - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())

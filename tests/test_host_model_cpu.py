@@ -67,9 +67,13 @@ def test_no_weight_decay_groups():
     m = MsViT(SMALL_ARCH, img_size=32, num_classes=10)
     groups = param_groups(m, 0.05)
     nd = {id(p) for p in groups[1]["params"]}
+    skip = m.no_weight_decay()
+    assert {"pos_embed", "cls_token", "norm.weight", "norm.bias", "norm_embed", "head.bias", "relative_position"} == set(skip)
     for n, p in m.named_parameters():
-        if "relative_position" in n or "cls_token" in n or n.endswith(".bias") or ".norm" in n:
-            assert id(p) in nd, n
+        # the reference's rule (optim/__init__.py:24-37): NAME contains one of the no_weight_decay() substrings;
+        # plain Linear biases (qkv / proj / fc) are decayed
+        assert (id(p) in nd) == any(s in n for s in skip), n
+    assert any(n.endswith("proj.bias") and id(p) not in nd for n, p in m.named_parameters())
     assert sum(len(g["params"]) for g in groups) == len(list(m.parameters()))
 
 
@@ -157,3 +161,43 @@ def test_master_weight_adamw_matches_plain_adamw_in_fp32():
     fa = torch.cat([p.detach().reshape(-1) for p in a.parameters()])
     fb = torch.cat([p.detach().reshape(-1) for p in b.parameters()])
     torch.testing.assert_close(fa, fb, rtol=0, atol=0)
+
+
+def test_master_weight_adamw_state_dict_roundtrip_and_fp32_export():
+    """The fp32 masters and Adam moments checkpoint through MasterWeightAdamW.state_dict(); the exported model state
+    dict is fp32 (the reference checkpoint format, utils/checkpoint.py:170-180), shared aliases included."""
+    from vision_longformer_amd.engine import MasterWeightAdamW, set_lr
+    torch.manual_seed(0)
+    m = MsViT(SMALL_ARCH, img_size=32, num_classes=10, sharew=True)
+    opt = MasterWeightAdamW(m, lr=1e-2)
+    for p in opt.low:
+        p.grad = torch.randn_like(p)
+    for p in opt.direct:
+        p.grad = torch.randn_like(p)
+    opt.step()
+    sd = opt.state_dict()
+    fp32 = opt.export_fp32_state_dict(m)
+    assert all(v.dtype != torch.bfloat16 for v in fp32.values())
+    assert set(fp32.keys()) == set(m.state_dict().keys())
+    n0 = opt._low_names[0]
+    assert torch.equal(fp32[n0], sd["master"][n0])
+    # resume into a fresh model / optimizer
+    torch.manual_seed(1)
+    m2 = MsViT(SMALL_ARCH, img_size=32, num_classes=10, sharew=True)
+    opt2 = MasterWeightAdamW(m2, lr=1e-2)
+    opt2.load_state_dict(sd)
+    for a, b in zip(opt.master, opt2.master):
+        assert torch.equal(a, b)
+    for a, b in zip(opt.low, opt2.low):
+        assert torch.equal(a, b) and b.dtype == torch.bfloat16
+    s1, s2 = opt.opt.state_dict()["state"], opt2.opt.state_dict()["state"]
+    assert s1.keys() == s2.keys() and all(torch.equal(s1[k]["exp_avg"], s2[k]["exp_avg"]) for k in s1)
+    set_lr(opt2, 5e-4)
+    assert all(float(g["lr"]) == 5e-4 for g in opt2.param_groups)
+
+
+def test_attn_drop_in_training_is_refused_not_ignored():
+    a = Long2DSCSelfAttention(32, num_heads=2, w=4, nglo=1, sharew=True, attn_drop=0.1)
+    a.train()
+    with pytest.raises(NotImplementedError):
+        a(torch.zeros(1, 1 + 16, 32), 4, 4)

@@ -67,6 +67,11 @@ def import_reference():
     return ref_sc, ref_l2d
 
 
+def model_grad_sample(g):
+    from golden_cases import model_grad_sample as f
+    return f(g)
+
+
 def main():
     from oracle import vil_oracle as O
     import golden_cases as GC
@@ -224,10 +229,13 @@ def main():
     pick = ["layer1.1.attn.query.weight", "layer1.1.attn.kv.weight", "layer1.1.attn.local_relative_position_bias_table",
             "layer1.1.attn.g2l_relative_position_bias", "layer2.1.attn.proj.weight", "layer1.0.proj.weight",
             "layer3.1.attn.qkv.weight", "head.weight"]
+    # strided element samples of the same gradients (<= 512 each): norms alone are blind to permutation / sign errors
+    grads = dict(refm.named_parameters())
+    samples = {"gsample/" + n: model_grad_sample(grads[n].grad).numpy() for n in pick}
     np.savez_compressed(os.path.join(outdir, "model_tiny.npz"), logits=logits.detach().numpy(),
                         loss=np.float64(loss.item()), grad_names=np.array(pick),
                         grad_norms=np.array([gn[n] for n in pick]),
-                        state_keys=np.array(sorted(refm.state_dict().keys())))
+                        state_keys=np.array(sorted(refm.state_dict().keys())), **samples)
     print("model-level ViL-Tiny ok: loss", loss.item(), "n_state_keys", len(refm.state_dict()))
 
     # exact=1 with mode != 0 raises ValueError in the reference

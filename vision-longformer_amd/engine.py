@@ -60,21 +60,45 @@ def build_vil(config, drop_path_rate=0.1, num_classes=1000, **overrides):
 
 
 def param_groups(model, weight_decay):
-    """No weight decay on the substrings MsViT.no_weight_decay() lists
-    (reference optim/__init__.py:14-64 behaviour)."""
+    """No weight decay exactly on the parameters whose NAME contains one of the substrings
+    MsViT.no_weight_decay() lists -- the reference's rule (optim/__init__.py:24-37): plain Linear
+    biases (qkv / proj / fc) ARE decayed there, so they are here."""
     skip = model.no_weight_decay()
     decay, no_decay = [], []
     for n, p in model.named_parameters():
         if not p.requires_grad:
             continue
-        (no_decay if (p.ndim <= 1 or any(s in n for s in skip)) else decay).append(p)
+        (no_decay if _no_decay(n, skip) else decay).append(p)
     return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
 
 
+def _no_decay(name, skip):
+    return any(s in name for s in skip)
+
+
+def _lr_value(lr, device, capturable):
+    """A captured optimizer step bakes a Python-float lr into the graph as a kernel scalar; a
+    per-iteration schedule (reference engine.py: warm-up + cosine every iteration) would then be
+    silently ignored on replay.  With capturable=True the lr is therefore a DEVICE tensor that the
+    schedule updates in place (`set_lr`)."""
+    return torch.tensor(float(lr), dtype=torch.float32, device=device) if capturable else float(lr)
+
+
+def set_lr(optimizer, lr):
+    """In-place learning-rate update that a captured (hipGraph) optimizer step observes."""
+    for g in optimizer.param_groups:
+        if torch.is_tensor(g["lr"]):
+            g["lr"].fill_(float(lr))
+        else:
+            g["lr"] = float(lr)
+
+
 def make_optimizer(model, lr=1e-3, weight_decay=0.05, capturable=False):
-    fused = next(model.parameters()).is_cuda
-    return torch.optim.AdamW(param_groups(model, weight_decay), lr=lr, betas=(0.9, 0.999), fused=fused,
-                             capturable=bool(capturable and fused))
+    p0 = next(model.parameters())
+    fused = p0.is_cuda
+    cap = bool(capturable and fused)
+    return torch.optim.AdamW(param_groups(model, weight_decay), lr=_lr_value(lr, p0.device, cap), betas=(0.9, 0.999),
+                             fused=fused, capturable=cap)
 
 
 class MasterWeightAdamW:
@@ -110,12 +134,43 @@ class MasterWeightAdamW:
             else:
                 self.direct.append(p)
                 tgt = p
-            (no_decay if (p.ndim <= 1 or any(s in n for s in skip)) else decay).append(tgt)
-        fused = next(model.parameters()).is_cuda
+            (no_decay if _no_decay(n, skip) else decay).append(tgt)
+        p0 = next(model.parameters())
+        fused = p0.is_cuda
+        cap = bool(capturable and fused)
         self.opt = torch.optim.AdamW([{"params": decay, "weight_decay": weight_decay},
-                                      {"params": no_decay, "weight_decay": 0.0}], lr=lr, betas=betas, fused=fused,
-                                     capturable=bool(capturable and fused))
+                                      {"params": no_decay, "weight_decay": 0.0}], lr=_lr_value(lr, p0.device, cap),
+                                     betas=betas, fused=fused, capturable=cap)
         self.param_groups = self.opt.param_groups
+        self._low_names = [names[id(p)] for p in self.low]
+
+    # ---- checkpointing: the module's state_dict holds bf16-rounded working copies of the GEMM weights, so the
+    # fp32 masters and the Adam moments live here (reference checkpoints: utils/checkpoint.py:170-180 saves
+    # {net, optimizer}; `export_fp32_state_dict` gives the `net` entry in the reference's fp32 format)
+    def state_dict(self):
+        return {"master": {n: m.detach().clone() for n, m in zip(self._low_names, self.master)},
+                "opt": self.opt.state_dict()}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        for n, m, p in zip(self._low_names, self.master, self.low):
+            m.copy_(sd["master"][n])
+            p.copy_(m)                              # refresh the bf16 working copy from the master
+        lrs = [g["lr"] for g in self.opt.param_groups]
+        self.opt.load_state_dict(sd["opt"])
+        for g, lr in zip(self.opt.param_groups, lrs):   # keep the (device-tensor) lr object the graph captured
+            if torch.is_tensor(lr):
+                lr.fill_(float(g["lr"]))
+                g["lr"] = lr
+
+    def export_fp32_state_dict(self, model):
+        """model.state_dict() with every bf16 working weight replaced by its fp32 master."""
+        out = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        master_of = {id(p): m for p, m in zip(self.low, self.master)}
+        for n, p in model.named_parameters(remove_duplicate=False):   # shared (sharew) weights appear under every alias
+            if id(p) in master_of:
+                out[n] = master_of[id(p)].detach().clone()
+        return out
 
     def zero_grad(self, set_to_none=True):
         for p in self.low:
@@ -227,8 +282,15 @@ class GraphedTrainStep:
         self.rs_layers = [m for m in model.modules() if isinstance(m, Long2DSCSelfAttention) and m.mode > 0]
         if self.rs_layers:
             self.modes_dev = torch.ones(len(self.rs_layers), dtype=torch.int32, device=dev)
-            self.modes_host = torch.ones(len(self.rs_layers), dtype=torch.int32).pin_memory()
+            # the host runs ahead of the device: a ring of pinned staging buffers, each guarded by an event recorded
+            # after its copy, so a later step's draws never overwrite words an earlier (pending) copy still reads
+            self.modes_ring = [torch.ones(len(self.rs_layers), dtype=torch.int32).pin_memory() for _ in range(4)]
+            self.modes_evt = [None] * len(self.modes_ring)
+            self.modes_i = 0
             for i, m in enumerate(self.rs_layers):
+                if not m.fused_path_ok():
+                    raise RuntimeError("random-shift layer outside the fused path cannot read a device-side neighbour "
+                                       "word (mode_dev); run it with the eager step")
                 m.mode_dev = self.modes_dev[i:i + 1]
         self.loss = None
         side = torch.cuda.Stream(device=dev)
@@ -253,9 +315,17 @@ class GraphedTrainStep:
     def _draw_modes(self):
         if self.rs_layers and self.model.training:
             import random
+            k = self.modes_i
+            self.modes_i = (k + 1) % len(self.modes_ring)
+            if self.modes_evt[k] is not None:
+                self.modes_evt[k].synchronize()          # the copy that last read this staging buffer has finished
+            host = self.modes_ring[k]
             for i in range(len(self.rs_layers)):
-                self.modes_host[i] = random.randrange(1, 9)
-            self.modes_dev.copy_(self.modes_host, non_blocking=True)
+                host[i] = random.randrange(1, 9)
+            self.modes_dev.copy_(host, non_blocking=True)
+            if self.modes_evt[k] is None:
+                self.modes_evt[k] = torch.cuda.Event()
+            self.modes_evt[k].record()
 
     def _fwd_bwd(self):
         # p.grad = None: autograd then WRITES each gradient (into the graph's private pool: static addresses)
@@ -274,7 +344,9 @@ class GraphedTrainStep:
                     p.grad = self.views[p]
 
     def _allreduce(self):
-        avg = dist.get_backend() == "nccl"               # gloo (single-device tests) has no AVG
+        # gloo (single-device tests) has no AVG; without a process group (unit test with the collective
+        # stubbed) there is no backend to ask
+        avg = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
         for f in self.flats:
             if avg:
                 dist.all_reduce(f, op=dist.ReduceOp.AVG)

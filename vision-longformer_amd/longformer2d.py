@@ -18,7 +18,7 @@ import random
 import torch
 from torch import nn
 
-from .ops import vil_local_attention, vil_full_attention, FULL_MAX_G
+from .ops import vil_local_attention, vil_full_attention, vil_global_attention, FULL_MAX_G
 from .linear import VilLinear
 
 
@@ -100,52 +100,67 @@ class Long2DSCSelfAttention(nn.Module):
             return random.randrange(1, 9) if self.training else 0
         return self.mode
 
+    def fused_path_ok(self):
+        """One query / kv / proj GEMM over all tokens + one fused op for local and global rows: the shared-weight
+        layers of every published ViL."""
+        G, H, M = self.Nglo, self.num_heads, self.head_dim
+        return (1 <= G <= FULL_MAX_G and self.query_global is self.query and self.kv_global is self.kv
+                and self.proj_global is self.proj and not self.only_glo and M in (8, 16, 32, 48, 64))
+
     def forward(self, x, nx, ny):
         B, N, C = x.shape
         G, H, M = self.Nglo, self.num_heads, self.head_dim
         Nloc = nx * ny
         assert G + Nloc == N, "Global dimension does not match!"
+        if self.training and self.attn_drop.p > 0.0:
+            # the reference drops attention probabilities of local AND global rows (longformer2d.py:186,224); the
+            # fused kernels never materialise them.  Every published config has ATTN_DROP = 0: refuse loudly
+            # instead of silently training with different semantics.
+            raise NotImplementedError("attn_drop > 0 in training is not supported by the fused attention kernels")
         mode = self._resolve_mode()
+        rs_dev = self.mode_dev is not None and self.mode > 0 and self.training
+        table = self.local_relative_position_bias_table if self.rpe else None
+        g2l = self.g2l_relative_position_bias if (self.rpe and G >= 1) else None
+        g2g = self.g2g_relative_position_bias if (self.rpe and G >= 1) else None
 
-        if (1 <= G <= FULL_MAX_G and self.query_global is self.query and self.kv_global is self.kv
-                and self.proj_global is self.proj and not self.only_glo and H * M == C
-                and M in (8, 16, 32, 48, 64) and self.attn_drop.p == 0.0):
+        if self.fused_path_ok():
             # shared weights (every published ViL): ONE query / kv / proj GEMM over all N tokens and one
             # fused op for local + global rows -- no token slicing, no concatenation, and the two
             # gradient contributions to kv are summed inside the kernels (SURVEY 8f row 1)
-            dev_mode = self.mode_dev if (self.mode_dev is not None and self.mode > 0 and self.training) else None
-            out = vil_full_attention(self.query(x), self.kv(x),
-                                     self.local_relative_position_bias_table if self.rpe else None,
-                                     self.g2l_relative_position_bias if self.rpe else None,
-                                     self.g2g_relative_position_bias if self.rpe else None,
+            out = vil_full_attention(self.query(x), self.kv(x), table, g2l, g2g,
                                      nx=nx, ny=ny, w=self.attention_window, nglo=G, num_heads=H,
-                                     mode=(1 if dev_mode is not None else mode),
-                                     exact=self.exact, scale=self.scale, backend=self.backend, mode_dev=dev_mode)
+                                     mode=(1 if rs_dev else mode), exact=self.exact, scale=self.scale,
+                                     backend=self.backend, mode_dev=self.mode_dev if rs_dev else None)
             return self.proj_drop(self.proj(out))
 
+        if rs_dev:
+            raise RuntimeError("mode_dev (device-side random-shift neighbour) is only read by the fused path; this "
+                               "layer (sharew=False / only_glo / nglo outside 1..4) must draw its neighbour on the host")
         q = self.query(x[:, G:])                  # (B, Nloc, C), unscaled: the kernel applies `scale`
         kv = self.kv(x)                           # (B, N, 2C): [..., :C] keys, [..., C:] values
-        table = self.local_relative_position_bias_table if self.rpe else None
-        g2l_loc = self.g2l_relative_position_bias[1] if (self.rpe and G >= 1) else None
-        x1 = vil_local_attention(q, kv, table, g2l_loc, nx=nx, ny=ny, w=self.attention_window, nglo=G,
-                                 num_heads=H, mode=mode, exact=self.exact, scale=self.scale,
-                                 only_glo=self.only_glo, backend=self.backend)
+        x1 = vil_local_attention(q, kv, table, g2l[1] if g2l is not None else None, nx=nx, ny=ny,
+                                 w=self.attention_window, nglo=G, num_heads=H, mode=mode, exact=self.exact,
+                                 scale=self.scale, only_glo=self.only_glo, backend=self.backend)
         x1 = self.proj(x1)
         if G == 0:
             return self.proj_drop(x1)
 
-        # global-token rows: full attention over all N keys (longformer2d.py:210-227)
-        qg = (self.scale * self.query_global(x[:, :G])).view(B, G, H, M)
+        # global-token rows: full attention over all N keys (longformer2d.py:210-227) with the global projections
+        qg = self.query_global(x[:, :G])          # unscaled
         kvg = kv if self.kv_global is self.kv else self.kv_global(x)
-        kvg = kvg.view(B, N, 2, H, M)
-        a0 = torch.einsum('bghm,bnhm->bhgn', qg, kvg[:, :, 0])
-        if self.rpe:
-            gbias = torch.cat([self.g2g_relative_position_bias,
-                               self.g2l_relative_position_bias[0].unsqueeze(-1).expand(-1, -1, Nloc)], dim=-1)
-            a0 = a0 + gbias.unsqueeze(0)
-        a0 = torch.softmax(a0.float(), dim=-1).to(kvg.dtype)
-        a0 = self.attn_drop(a0)
-        x0 = torch.einsum('bhgn,bnhm->bghm', a0, kvg[:, :, 1]).reshape(B, G, C)
+        if G <= FULL_MAX_G and M in (8, 16, 32, 48, 64):
+            x0 = vil_global_attention(qg, kvg, g2g, g2l[0] if g2l is not None else None,
+                                      nx=nx, ny=ny, nglo=G, num_heads=H, scale=self.scale)
+        else:
+            # nglo > 4 (no published model): the global-row kernels keep their bias-gradient partials for at most
+            # four global tokens; this one case stays on library ops
+            qg = (self.scale * qg).view(B, G, H, M)
+            kvh = kvg.view(B, N, 2, H, M)
+            a0 = torch.einsum('bghm,bnhm->bhgn', qg, kvh[:, :, 0])
+            if self.rpe:
+                a0 = a0 + torch.cat([g2g, g2l[0].unsqueeze(-1).expand(-1, -1, Nloc)], dim=-1).unsqueeze(0)
+            a0 = torch.softmax(a0.float(), dim=-1).to(kvh.dtype)
+            x0 = torch.einsum('bhgn,bnhm->bghm', a0, kvh[:, :, 1]).reshape(B, G, C)
         x0 = self.proj_global(x0)
         return self.proj_drop(torch.cat((x0, x1.to(x0.dtype)), dim=1))
 

@@ -292,6 +292,72 @@ class _VilQKVAttention(torch.autograd.Function):
 FULL_MAX_G = 4      # vil_glo_attn_* bookkeeping limit
 
 
+class _VilGlobalRows(torch.autograd.Function):
+    """The G global-token QUERY rows alone (reference longformer2d.py:210-227) for layers whose global rows do
+    not share the local rows' projections (`sharew=False`), `only_glo` layers, or any layer outside the fused
+    whole-layer op: q_g (B, G, C) from `query_global`, kv (B, N, 2C) from `kv_global` -> (B, G, C).
+    vil_glo_attn_fwd / vil_glo_attn_bwd; the backward accumulates into a zero-initialised dkv."""
+
+    @staticmethod
+    def forward(ctx, q_g, kv, g2g, g2l0, cfg):
+        _check_dev(q_g, "vil_global_attention")
+        q_g, kv = _last_contig(q_g), _last_contig(kv)
+        L = _lib.lib()
+        B, G, C = q_g.shape
+        H = cfg["H"]
+        M = C // H
+        assert kv.dtype == q_g.dtype and kv.shape[0] == B and kv.shape[2] == 2 * C and G == cfg["G"]
+        k, v = kv[..., :C], kv[..., C:]
+        out = torch.empty_like(q_g)
+        lse = torch.empty(B, H, G, dtype=torch.float32, device=q_g.device)
+        g2g_f, g2l_f = _f32c(g2g), _f32c(g2l0)
+        d = _make_desc(q_g, k, v, out, cfg, "auto")
+        stream = ctypes.c_void_p(torch.cuda.current_stream(q_g.device).cuda_stream)
+        with torch.cuda.device(q_g.device):
+            _lib.check(L.vil_glo_attn_fwd(ctypes.byref(d), _ptr(q_g), _ptr(k), _ptr(v), _ptr(g2g_f), _ptr(g2l_f),
+                                          _ptr(out), _ptr(lse), stream))
+        ctx.save_for_backward(q_g, kv, out, lse, g2g_f, g2l_f)
+        ctx.cfg = cfg
+        ctx.dts = tuple(t.dtype if t is not None else None for t in (g2g, g2l0))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q_g, kv, out, lse, g2g_f, g2l_f = ctx.saved_tensors
+        cfg = ctx.cfg
+        L = _lib.lib()
+        B, G, C = q_g.shape
+        M = C // cfg["H"]
+        dout = _last_contig(dout).to(q_g.dtype)
+        dq = torch.empty_like(q_g)
+        dkv = torch.zeros_like(kv)
+        k, v, dk, dv = kv[..., :C], kv[..., C:], dkv[..., :C], dkv[..., C:]
+        dg2g = torch.zeros_like(g2g_f) if g2g_f is not None else None
+        dg2l = torch.zeros_like(g2l_f) if g2l_f is not None else None
+        d = _make_desc(q_g, k, v, out, cfg, "auto")
+        d.do_sb, d.do_st, d.do_sh = _strides(dout, M)
+        d.dq_sb, d.dq_st, d.dq_sh = _strides(dq, M)
+        d.dk_sb, d.dk_st, d.dk_sh = _strides(dk, M)
+        d.dv_sb, d.dv_st, d.dv_sh = _strides(dv, M)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(q_g.device).cuda_stream)
+        with torch.cuda.device(q_g.device):
+            _lib.check(L.vil_glo_attn_bwd(ctypes.byref(d), _ptr(q_g), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse),
+                                          _ptr(g2g_f), _ptr(g2l_f), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dg2g), _ptr(dg2l),
+                                          stream))
+        gdt, ldt = ctx.dts
+        return (dq, dkv, dg2g.to(gdt) if dg2g is not None else None, dg2l.to(ldt) if dg2l is not None else None, None)
+
+
+def vil_global_attention(q_g, kv, g2g_bias, g2l0_bias, *, nx, ny, nglo, num_heads, scale=None):
+    """Global-token query rows only: q_g (B, nglo, C) UNSCALED output of `query_global`, kv (B, nglo+nx*ny, 2C)
+    output of `kv_global`; g2g_bias (H, nglo, nglo), g2l0_bias (H, nglo) = g2l_relative_position_bias[0], or None.
+    Returns (B, nglo, C)."""
+    assert 1 <= nglo <= FULL_MAX_G
+    cfg = _cfg(q_g.shape[-1], nx, ny, 1, nglo, num_heads, 0, 0, scale)
+    return _VilGlobalRows.apply(q_g, kv, g2g_bias, g2l0_bias, cfg)
+
+
+
 def _cfg(q_last_dim, nx, ny, w, nglo, num_heads, mode, exact, scale, bias_side=0):
     return dict(nx=int(nx), ny=int(ny), W=int(w), G=int(nglo), H=int(num_heads), mode=int(mode), exact=int(exact),
                 only_glo=False, scale=float(scale) if scale is not None else (q_last_dim // num_heads) ** -0.5,
