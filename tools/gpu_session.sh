@@ -1,0 +1,41 @@
+#!/bin/bash
+# One gpurun call of the build/measure loop:  tools/gpu_session.sh <tag> [steps...]
+#   steps: test  ab  bench  pmc_<shape>  meddeep
+# Everything lands under gpurun_out/<tag>/.
+set -u
+TAG=$1; shift
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+rm -f gpurun_out/parity_report.txt
+for STEP in "$@"; do
+  case $STEP in
+    test)
+      timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1
+      echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"; tail -5 "$OUT/pytest_gpu.log"
+      cp gpurun_out/parity_report.txt "$OUT/parity_report.txt" 2>/dev/null ;;
+    testall)      # no -x: every failure listed
+      timeout 900 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1
+      echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"; tail -15 "$OUT/pytest_gpu.log"
+      cp gpurun_out/parity_report.txt "$OUT/parity_report.txt" 2>/dev/null ;;
+    ab)
+      for SH in small_s1 small_s2 meddeep_s1_f7 meddeep_s2_f7 small_s3_dense basedeep_s1_f6_rs; do
+        for LIB in tools/ab/libvilattn_r01.so ""; do
+          echo "== $SH lib=${LIB:-HEAD}" >> "$OUT/ab.txt"
+          VIL_ATTN_LIB=${LIB:+$PWD/$LIB} timeout 200 python tools/kernel_bench.py $SH --reps 10 >> "$OUT/ab.txt" 2>&1
+        done
+      done
+      cat "$OUT/ab.txt" ;;
+    bench)
+      timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 3000 "$OUT/bench.json" ;;
+    meddeep)
+      timeout 600 python bench.py --config vil_medium_deep_384 --no-cpu-baseline > "$OUT/bench_meddeep.json" 2> "$OUT/bench_meddeep.err"
+      tail -c 1500 "$OUT/bench_meddeep.json" ;;
+    pmc_*)
+      SH=${STEP#pmc_}
+      bash tools/pmc.sh $SH "$OUT/pmc_$SH" > "$OUT/pmc_$SH.txt" 2>&1; grep -A40 "k_mfma_fwd\|k_mfma_bwd" "$OUT/pmc_$SH.txt" | grep -- "--\|^k_" ;;
+    smoke)
+      python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" ;;
+    *) echo "unknown step $STEP" ;;
+  esac
+done

@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvilattn.so")
+# VIL_ATTN_LIB: A/B benchmarking hook (tools/kernel_bench.py against a library built from another revision)
+LIB_PATH = os.environ.get("VIL_ATTN_LIB") or os.path.join(_HERE, "libvilattn.so")
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
 BACKEND_AUTO, BACKEND_SCALAR, BACKEND_MFMA = 0, 1, 2

@@ -27,6 +27,7 @@
 //
 // Reference semantics: src/models/layers/longformer2d.py:134-204 (see include/vil_attn.h).
 #include "vil_mfma_common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------ table prologue
 __global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out) {
@@ -61,15 +62,20 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
   constexpr int MK = (MD + 1) / 2;            // 32-wide K steps over the head dim
   constexpr int VCH = 2 * MD;                 // 16-byte chunks per V row
   constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;  // V tile XOR swizzle needs rows that are multiples of 64 B
+  constexpr int PF = MD <= 2 ? 2 : 1;         // depth of the K / V prefetch ring (register budget: M = 64 runs at 244)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VilGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, lg = lane >> 4;
 
+  // logical order (image, workgroup-of-chunks, head): the H workgroups that walk the same chunks of one image run
+  // back to back on one XCD, so both 64-byte halves (two heads) of every K / V cache line are consumed while the
+  // line is L2-resident, and the in-flight K/V footprint of an XCD is H times smaller than with (image, head, ...)
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = logical / c.wg_per_bh, wgi = logical % c.wg_per_bh;
-  const int b = bh / p.H, h = bh % p.H;
+  const int b = logical / (c.wg_per_bh * p.H), rem_ = logical - b * (c.wg_per_bh * p.H);
+  const int wgi = rem_ / p.H, h = rem_ - wgi * p.H;
+  const int bh = b * p.H + h;
 
   float* tab = (float*)smem;
   {
@@ -77,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
     for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
   }
   __syncthreads();
+  const unsigned tab_lds = lds_addr(smem);
 
   char* wbase = smem + (size_t)c.tabsize * 4 + (size_t)wave * c.wave_lds;
   int* s_koff = (int*)wbase;                       // [NSP] byte offset of each key slot's K/V row
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
     // ---- query slots of this lane: column j of q-tile qt is query (x, y = 4*hq + qt)
     const int jj = wp * 16 + lj;
     const int qx = jj / c.HQ, qhq = jj % c.HQ;
-    const int aq0b = (min(qx, W - 1) * c.P + 4 * qhq) * 4;   // bytes; + 4*qt per q-tile
+    const unsigned aq0b = tab_lds + (min(qx, W - 1) * c.P + 4 * qhq) * 4;   // LDS byte address; + 4*qt per q-tile
     int qtok[4];
     bool qreal[4];
 #pragma unroll
@@ -159,47 +166,50 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
     }
 
     const int nsteps = nslots >> 5;
-    bf16x8 kf[2][MK];
-    u32x4 vr[MD];
-    auto load_step = [&](int st) {
+    // global -> register prefetch ring, PF steps deep (2 where the registers allow it: one step of compute is
+    // shorter than an L2 / HBM round trip under load, so a 1-deep ring left the wave parked at vmcnt(0))
+    bf16x8 kf[PF][2][MK];
+    u32x4 vr[PF][MD];
+    auto load_step = [&](auto slot_, int st) {
+      constexpr int sl = decltype(slot_)::value;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int off = s_koff[st * 32 + hf * 16 + lj] + lgo;
 #pragma unroll
         for (int ks = 0; ks < MK; ++ks) {
           bf16x8 z = {};
-          kf[hf][ks] = (ks * 32 + lg * 8) < M ? buf_load8(krs, off + ks * 64) : z;
+          kf[sl][hf][ks] = (ks * 32 + lg * 8) < M ? buf_load8(krs, off + ks * 64) : z;
         }
       }
 #pragma unroll
       for (int it = 0; it < MD; ++it) {
         const int row = (it * 64 + lane) / VCH;
-        vr[it] = __builtin_amdgcn_raw_buffer_load_b128(vrs, s_koff[st * 32 + row] + vld_off[it], 0, 0);
+        vr[sl][it] = __builtin_amdgcn_raw_buffer_load_b128(vrs, s_koff[st * 32 + row] + vld_off[it], 0, 0);
       }
     };
-    load_step(0);
 
-    for (int st = 0; st < nsteps; ++st) {
+    auto step = [&](auto slot_, int st) {
+      constexpr int sl = decltype(slot_)::value;
       // ---- this step's operands: K fragments (registers), V tile (LDS), bias addresses
       bf16x8 kc_[2][MK];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-        for (int ks = 0; ks < MK; ++ks) kc_[hf][ks] = kf[hf][ks];
+        for (int ks = 0; ks < MK; ++ks) kc_[hf][ks] = kf[sl][hf][ks];
 #pragma unroll
-      for (int it = 0; it < MD; ++it) *(u32x4*)(s_v + vst_off[it]) = vr[it];
+      for (int it = 0; it < MD; ++it) *(u32x4*)(s_v + vst_off[it]) = vr[sl][it];
       i32x4 ak[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) ak[hf] = *(const i32x4*)(s_akey + st * 32 + hf * 16 + lg * 4);
-      if (st + 1 < nsteps) load_step(st + 1);
+      if (st + PF < nsteps) load_step(slot_, st + PF);
 
       // ---- S^T = K Q^T + bias   (accumulator initialised with the gathered bias)
       f32x4 sc[2][4];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const float* tb[4];
+        lds_cvf tb[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tb[r] = (const float*)((const char*)tab + (aq0b - ak[hf][r]));
+        for (int r = 0; r < 4; ++r) tb[r] = lds_f32(aq0b - (unsigned)ak[hf][r]);
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
           f32x4 acc = {tb[0][qt], tb[1][qt], tb[2][qt], tb[3][qt]};
@@ -214,12 +224,12 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
       bf16x8 pb[4];
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt) {
-        float pm = fmaxf(fmaxf(fmaxf(sc[0][qt][0], sc[0][qt][1]), fmaxf(sc[0][qt][2], sc[0][qt][3])),
-                         fmaxf(fmaxf(sc[1][qt][0], sc[1][qt][1]), fmaxf(sc[1][qt][2], sc[1][qt][3])));
+        float pm = max3f(max3f(max3f(sc[0][qt][0], sc[0][qt][1], sc[0][qt][2]), sc[0][qt][3], sc[1][qt][0]),
+                         max3f(sc[1][qt][1], sc[1][qt][2], sc[1][qt][3]), mrow[qt]);   // >= mrow: max3 is free
         if (__any(pm > mrow[qt] + thr)) {
           pm = fmaxf(pm, __shfl_xor(pm, 16, 64));
           pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
-          const float mn = fmaxf(mrow[qt], pm);
+          const float mn = pm;
           const float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mn) * c1);
           mrow[qt] = mn;
           lacc[qt] *= alpha;
@@ -255,6 +265,15 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
       for (int qt = 0; qt < 4; ++qt)
         lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qt], lacc[qt], 0, 0, 0);
       wave_lds_fence();
+    };
+
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, PF - 1> S1;
+    load_step(S0{}, 0);
+    if constexpr (PF == 2) { if (nsteps > 1) load_step(S1{}, 1); }
+    for (int st = 0; st < nsteps; st += PF) {
+      step(S0{}, st);
+      if constexpr (PF == 2) { if (st + 1 < nsteps) step(S1{}, st + 1); }
     }
 
     // ---- epilogue: normalise, store O (4 dims x 8 bytes per d-tile) and LSE

@@ -19,6 +19,7 @@
 // Reference semantics: SlidingChunk2D.backward (src/models/layers/slidingchunk_2d.py:234-246)
 // plus the autograd of bias gather / mask / softmax in longformer2d.py:152-200.
 #include "vil_mfma_common.h"
+#include <type_traits>
 
 #define LSE_PAD 1.0e30f
 
@@ -51,18 +52,23 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
   constexpr int MK = (MD + 1) / 2;
   constexpr int VCH = 2 * MD;
   constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;
+  constexpr int PF = MD <= 2 ? 2 : 1;         // depth of the K / V prefetch ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VilGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, lg = lane >> 4;
 
+  // (image, workgroup-of-chunks, head) order: see k_mfma_fwd
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = logical / bc.dq_wg_per_bh, wgi = logical % bc.dq_wg_per_bh;
-  const int b = bh / p.H, h = bh % p.H;
+  const int b = logical / (bc.dq_wg_per_bh * p.H), rem_ = logical - b * (bc.dq_wg_per_bh * p.H);
+  const int wgi = rem_ / p.H, h = rem_ - wgi * p.H;
+  const int bh = b * p.H + h;
 
   float* tab = (float*)smem;
   int* hist = (int*)(tab + c.tabsize);
+  const unsigned tab_lds = lds_addr(smem);
+  const unsigned hist_off = (unsigned)c.tabsize * 4u;        // histogram bin = table entry + hist_off (bytes)
   {
     const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
     for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
       const int nslots = build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey, adr1, adc1);
       const int jj = wp * 16 + lj;
       const int qx = jj / bc.dq_HQ, qhq = jj % bc.dq_HQ;
-      const int aq0b = (min(qx, W - 1) * c.P + QT * qhq) * 4;
+      const unsigned aq0b = tab_lds + (min(qx, W - 1) * c.P + QT * qhq) * 4;
       int qtok[QT];
       bool qreal[QT];
       float lse2[QT], dlt[QT];
@@ -167,38 +173,39 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
         for (int dt = 0; dt < MD; ++dt) dq[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
       const int nsteps = nslots >> 5;
-      bf16x8 vf[2][MK];
-      u32x4 kr_[MD];
-      auto load_step = [&](int st) {
+      bf16x8 vf[PF][2][MK];
+      u32x4 kr_[PF][MD];
+      auto load_step = [&](auto slot_, int st) {
+        constexpr int sl = decltype(slot_)::value;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const int off = s_koff[st * 32 + hf * 16 + lj] + lgo;
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) {
             bf16x8 z = {};
-            vf[hf][ks] = (ks * 32 + lg * 8) < M ? buf_load8(vrs, off + ks * 64) : z;
+            vf[sl][hf][ks] = (ks * 32 + lg * 8) < M ? buf_load8(vrs, off + ks * 64) : z;
           }
         }
 #pragma unroll
         for (int it = 0; it < MD; ++it) {
           const int row = (it * 64 + lane) / VCH;
-          kr_[it] = __builtin_amdgcn_raw_buffer_load_b128(krs, s_koff[st * 32 + row] + kld_off[it], 0, 0);
+          kr_[sl][it] = __builtin_amdgcn_raw_buffer_load_b128(krs, s_koff[st * 32 + row] + kld_off[it], 0, 0);
         }
       };
-      load_step(0);
 
-      for (int st = 0; st < nsteps; ++st) {
+      auto step = [&](auto slot_, int st) {
+        constexpr int sl = decltype(slot_)::value;
         bf16x8 vc[2][MK];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-          for (int ks = 0; ks < MK; ++ks) vc[hf][ks] = vf[hf][ks];
+          for (int ks = 0; ks < MK; ++ks) vc[hf][ks] = vf[sl][hf][ks];
 #pragma unroll
-        for (int it = 0; it < MD; ++it) *(u32x4*)(s_k + kst_off[it]) = kr_[it];
+        for (int it = 0; it < MD; ++it) *(u32x4*)(s_k + kst_off[it]) = kr_[sl][it];
         i32x4 ak[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) ak[hf] = *(const i32x4*)(s_akey + st * 32 + hf * 16 + lg * 4);
-        if (st + 1 < nsteps) load_step(st + 1);
+        if (st + PF < nsteps) load_step(slot_, st + PF);
         wave_lds_fence();
 
         bf16x8 dsb[QT];
@@ -211,12 +218,12 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
             bf16x8 z = {};
             kc_[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(s_k + krow_off[hf][ks]) : z;
           }
-          int i0[4];
-          const float* tb[4];
+          unsigned i0[4];
+          lds_cvf tb[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            i0[r] = aq0b - ak[hf][r];
-            tb[r] = (const float*)((const char*)tab + i0[r]);
+            i0[r] = aq0b - (unsigned)ak[hf][r];
+            tb[r] = lds_f32(i0[r]);
           }
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) {
@@ -232,7 +239,9 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
               const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], c1, -lse2[qt]));
               const float ds = pr * (dp[r] - dlt[qt]);
               dsb[qt][hf * 4 + r] = (__bf16)ds;
-              if (bc.do_hist) atomicAdd((int*)((char*)hist + i0[r]) + qt, __float2int_rn(ds));
+              if (bc.do_hist)
+                __hip_atomic_fetch_add(lds_i32(i0[r] + hist_off) + qt, __float2int_rn(ds),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
         }
@@ -253,6 +262,15 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
             dq[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsb[qt], dq[dt][qt], 0, 0, 0);
         }
         wave_lds_fence();
+      };
+
+      typedef std::integral_constant<int, 0> S0;
+      typedef std::integral_constant<int, PF - 1> S1;
+      load_step(S0{}, 0);
+      if constexpr (PF == 2) { if (nsteps > 1) load_step(S1{}, 1); }
+      for (int st = 0; st < nsteps; st += PF) {
+        step(S0{}, st);
+        if constexpr (PF == 2) { if (st + 1 < nsteps) step(S1{}, st + 1); }
       }
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt)
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
   }
   if (bc.do_hist) {
     __syncthreads();
-    int* out = (int*)bc.hist_parts + (int64_t)logical * c.tabsize;
+    int* out = (int*)bc.hist_parts + ((int64_t)bh * bc.dq_wg_per_bh + wgi) * c.tabsize;   // layout k_mfma_reduce_hist reads
     for (int i = tid; i < c.tabsize; i += blockDim.x) out[i] = hist[i];
     if (logical == 0 && tid == 0) ((int*)bc.norm2)[2] = lfx;      // the reduce needs the scale
   }
@@ -349,9 +367,12 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, lg = lane >> 4;
 
+  // (image, workgroup-of-chunks, head) order: see k_mfma_fwd
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = logical / bc.kv_wg_per_bh, wgi = logical % bc.kv_wg_per_bh;
-  const int b = bh / p.H, h = bh % p.H;
+  const int b = logical / (bc.kv_wg_per_bh * p.H), rem_ = logical - b * (bc.kv_wg_per_bh * p.H);
+  const int wgi = rem_ / p.H, h = rem_ - wgi * p.H;
+  const int bh = b * p.H + h;
+  const unsigned tab_lds = lds_addr(smem);
 
   float* tab = (float*)smem;
   {
@@ -475,8 +496,8 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
     // ---- this lane's key slots: column j of key-tile kt is key (x, y = KT*hq + KT-1 - kt)
     const int jj = wp * 16 + lj;
     const int kx = jj / bc.kv_HQ, khq = jj % bc.kv_HQ;
-    const int akl = glo ? -(c.glo0 + min(lj, max(p.G - 1, 0)) * c.gsz) * 4
-                        : (min(kx, W - 1) * c.P + KT * khq + KT - 1) * 4;
+    const unsigned akl = (unsigned)(glo ? -(c.glo0 + min(lj, max(p.G - 1, 0)) * c.gsz) * 4
+                                        : (min(kx, W - 1) * c.P + KT * khq + KT - 1) * 4) - tab_lds;
     int ktok[KT];
     bool kreal[KT];
 #pragma unroll
@@ -546,9 +567,9 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
         const i32x4 aq4 = *(const i32x4*)(s_aq + sb);
         const f32x4 ls4 = *(const f32x4*)(s_lse + sb);
         const f32x4 dl4 = *(const f32x4*)(s_dlt + sb);
-        const float* tb[4];
+        lds_cvf tb[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tb[r] = (const float*)((const char*)tab + (aq4[r] - akl));
+        for (int r = 0; r < 4; ++r) tb[r] = lds_f32((unsigned)aq4[r] - akl);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
           f32x4 acc = {tb[0][kt], tb[1][kt], tb[2][kt], tb[3][kt]};

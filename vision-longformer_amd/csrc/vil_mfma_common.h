@@ -47,6 +47,24 @@ struct MfmaCfg {
 
 __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned magic) { return __umulhi(n, magic); }
 
+// LDS byte address of a __shared__ object as a plain integer, and a dword read at such an address.  The bias
+// gather of the MFMA kernels is `table[Aq - Ak + qt]` for 4 keys (r) x 4 queries (qt) per lane: written through
+// generic pointers the compiler pairs the qt-consecutive entries into ds_read2_b32 and then needs 14 v_mov per
+// 16 entries to transpose them into the accumulators' (r-major) registers, plus a `v_add 0` per key for the
+// relocatable LDS base.  Volatile dword reads at integer addresses land directly in the accumulator registers:
+// one v_sub per key, immediate offsets per query (ISA: 4 v_sub + 16 ds_read_b32 instead of 8 VALU + 8
+// ds_read2_b32 + 14 v_mov; the LDS array cycles are the same, a ds_read2_b32 counts as two reads).
+typedef __attribute__((address_space(3))) const volatile float* lds_cvf;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ lds_cvf lds_f32(unsigned a) { return (lds_cvf)(size_t)a; }
+__device__ __forceinline__ __attribute__((address_space(3))) int* lds_i32(unsigned a) {
+  return (__attribute__((address_space(3))) int*)(size_t)a;
+}
+// three-operand maximum (v_max3_f32)
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
 // XCD-aware bijective remap: consecutive logical workgroups (same image/head, neighbouring
 // chunks -> shared K/V) land on the same XCD's L2 (hardware places block b on XCD b % 8)
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
