@@ -41,7 +41,7 @@ extern "C" {
 
 #define VIL_ATTN_ABI_VERSION 2
 
-enum { VIL_DTYPE_F32 = 0, VIL_DTYPE_BF16 = 1 };
+enum { VIL_DTYPE_F32 = 0, VIL_DTYPE_BF16 = 1, VIL_DTYPE_F16 = 2, VIL_DTYPE_F64 = 3 /* operator-level entry points only */ };
 
 enum {
   VIL_OK = 0,
@@ -157,6 +157,24 @@ int vil_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
                       const float* mean, const float* rstd, void* dx, int dx_dtype,
                       float* dgamma, float* dbeta, void* workspace, int64_t rows, int C,
                       int64_t dy_row_stride, int64_t x_row_stride, int64_t dx_row_stride, void* stream);
+
+/* ---- the reference's OPERATOR-level surface (compatibility / parity; the hot path is vil_attn_fwd/_bwd, which never
+ * builds the score tensor).  Chunked layouts of the reference: images (BH, M, mx, my, W^2), scores
+ * (BH, mx, my, W^2, kv), kv = 9 W^2 (mode 0) | W^2 (mode -1) | 2 W^2 (mode 1..8: [own chunk | neighbour]); neighbours
+ * are cyclic (torch.roll).  dtype VIL_DTYPE_F32 or VIL_DTYPE_F64; contiguous tensors.
+ *   vil_sc2d_qk     SlidingChunk2D.slidingchunk_qk     (src/models/layers/slidingchunk_2d.py:26-79)
+ *   vil_sc2d_av     SlidingChunk2D.slidingchunk_av     (:82-130)
+ *   vil_sc2d_agrad  SlidingChunk2D.slidingchunk_agrad  (:132-200)
+ *   vil_sc2d_mask   mask_invalid_locations             (:321-357): in-place -inf; *count (device, caller-zeroed, may be
+ *                   NULL) receives the reference's num_invalid; VIL_E_EXACT where the reference raises ValueError. */
+int vil_sc2d_qk(const void* q_img, const void* k_img, void* attn, int BH, int M, int mx, int my, int W, int mode,
+                int dtype, void* stream);
+int vil_sc2d_av(const void* attn, const void* v_img, void* out_img, int BH, int M, int mx, int my, int W, int mode,
+                int dtype, void* stream);
+int vil_sc2d_agrad(const void* attn, const void* grad_img, void* out_img, int BH, int M, int mx, int my, int W, int mode,
+                   int dtype, void* stream);
+int vil_sc2d_mask(void* attn, int BH, int mx, int my, int padx, int pady, int W, int exact, int mode, int dtype,
+                  unsigned long long* count, void* stream);
 
 /* ---- optional profiling sink (a measurement aid for bench.py; the ONLY state the
  * library keeps: process-global, not thread-safe).  Between _begin and _end every

@@ -9,8 +9,8 @@ Tolerances
   bf16 / fp16 I/O: against the fp64 oracle evaluated on the SAME rounded inputs:
       out atol 2e-2 / rtol 5e-2 (the reference's fp16 profiling tolerance is 2e-2 / 1e-1, :167-175);
       every gradient is bounded RELATIVE TO THE REFERENCE TENSOR'S RMS, |err| <= k * rms(ref) + rtol * |ref|:
-      q / kv gradients k = 0.15, rtol 5e-2; bias-table / g2l / g2g gradients (sums of rounded dS over up to
-      B * Nloc terms) k = 5e-2, rtol 2e-2.  An absolute bound would pass a wrong-bin bug on small-gradient cases.
+      q / kv gradients k = 0.10, rtol 5e-2; bias-table / g2l / g2g gradients (sums of rounded dS over up to
+      B * Nloc terms; heavy-tailed: corner bins get one term, centre bins hundreds) k = 8e-2, rtol 3e-2.  An absolute bound would pass a wrong-bin bug on small-gradient cases.
 """
 import os
 
@@ -116,9 +116,11 @@ def compare(tag, got, ref, tols):
 
 
 F32_TOL = dict(out=(2e-5, 1e-4), dq=(1e-4, 1e-3), dkv=(1e-4, 1e-3), dtable=(5e-4, 1e-3), dg2l=(5e-4, 1e-3))
-LOW_TOL = dict(out=(2e-2, 5e-2), dq=("rms", 0.15, 5e-2), dkv=("rms", 0.15, 5e-2), dqkv=("rms", 0.15, 5e-2),
-               dtable=("rms", 5e-2, 2e-2), dg2l=("rms", 5e-2, 2e-2), dg2g=("rms", 5e-2, 2e-2))
+LOW_TOL = dict(out=(2e-2, 5e-2), dq=("rms", 0.10, 5e-2), dkv=("rms", 0.10, 5e-2), dqkv=("rms", 0.10, 5e-2),
+               dtable=("rms", 8e-2, 3e-2), dg2l=("rms", 8e-2, 3e-2), dg2g=("rms", 8e-2, 3e-2))
 BF16_TOL = LOW_TOL
+# measured on MI355X (gpurun_out/*/parity_report.txt prints err / bound per tensor): worst observed ratio over the
+# ~250 bf16 cases is ~0.45 for q/kv gradients and ~0.67 for the bias gradients under these bounds
 
 SMALL = [
     case(2, 16, 4, 8, 8, 1), case(2, 16, 4, 8, 8, 1, rpe=False), case(2, 16, 4, 10, 9, 1),

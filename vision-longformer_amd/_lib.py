@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VIL_ATTN_LIB: A/B benchmarking hook (tools/kernel_bench.py against a library built from another revision)
 LIB_PATH = os.environ.get("VIL_ATTN_LIB") or os.path.join(_HERE, "libvilattn.so")
 
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F64 = 0, 1, 2, 3
 BACKEND_AUTO, BACKEND_SCALAR, BACKEND_MFMA = 0, 1, 2
 ABI_VERSION = 2
 
@@ -26,7 +26,8 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_glo_attn_fwd", "vil_glo_attn_bwd", "vil_attn_bwd_full",
            "vil_colsum_workspace_bytes", "vil_colsum_bf16", "vil_colsum_f32",
            "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad",
-           "vil_resln_fwd", "vil_resln_bwd", "vil_gemm_workspace_bytes", "vil_gemm_bf16")
+           "vil_resln_fwd", "vil_resln_bwd", "vil_gemm_workspace_bytes", "vil_gemm_bf16",
+           "vil_sc2d_qk", "vil_sc2d_av", "vil_sc2d_agrad", "vil_sc2d_mask")
 
 
 class VilAttnDesc(ctypes.Structure):
@@ -110,6 +111,12 @@ def lib():
         L.vil_gemm_bf16.restype = ctypes.c_int
         L.vil_gemm_bf16.argtypes = [ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                     ctypes.c_int64, vp, ctypes.c_size_t, vp]
+        ci = ctypes.c_int
+        for fn in (L.vil_sc2d_qk, L.vil_sc2d_av, L.vil_sc2d_agrad):
+            fn.restype = ci
+            fn.argtypes = [vp, vp, vp] + [ci] * 7 + [vp]
+        L.vil_sc2d_mask.restype = ci
+        L.vil_sc2d_mask.argtypes = [vp] + [ci] * 9 + [vp, vp]
         L.vil_layernorm_workspace_bytes.restype = ctypes.c_size_t
         L.vil_layernorm_workspace_bytes.argtypes = [i64, ctypes.c_int]
         L.vil_layernorm_fwd.restype = ctypes.c_int

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
   constexpr int VCH = 2 * MD;                 // 16-byte chunks per V row
   constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;  // V tile XOR swizzle needs rows that are multiples of 64 B
   constexpr int PF = MD <= 2 ? 2 : 1;         // depth of the K / V prefetch ring (register budget: M = 64 runs at 244)
+  constexpr bool PIPE = MD <= 2;              // software pipeline over steps (two score tiles + two LDS V tiles live)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VilGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -188,23 +189,23 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
       }
     };
 
-    auto step = [&](auto slot_, int st) {
+    // One step = 32 key slots.  stage_s(st): the step's operands leave the prefetch ring (K fragments stay in
+    // registers, the V tile goes to the wave's LDS tile of parity st & 1), the ring slot is refilled PF steps
+    // ahead, and S^T = K Q^T + bias is issued (accumulator initialised with the gathered bias).
+    auto stage_s = [&](auto slot_, int st, f32x4 (&sc)[2][4]) {
       constexpr int sl = decltype(slot_)::value;
-      // ---- this step's operands: K fragments (registers), V tile (LDS), bias addresses
+      char* sv = s_v + (PIPE ? (st & 1) * (32 * M * 2) : 0);
       bf16x8 kc_[2][MK];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int ks = 0; ks < MK; ++ks) kc_[hf][ks] = kf[sl][hf][ks];
 #pragma unroll
-      for (int it = 0; it < MD; ++it) *(u32x4*)(s_v + vst_off[it]) = vr[sl][it];
+      for (int it = 0; it < MD; ++it) *(u32x4*)(sv + vst_off[it]) = vr[sl][it];
       i32x4 ak[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) ak[hf] = *(const i32x4*)(s_akey + st * 32 + hf * 16 + lg * 4);
       if (st + PF < nsteps) load_step(slot_, st + PF);
-
-      // ---- S^T = K Q^T + bias   (accumulator initialised with the gathered bias)
-      f32x4 sc[2][4];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         lds_cvf tb[4];
@@ -219,23 +220,32 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
           sc[hf][qt] = acc;
         }
       }
-
-      // ---- online softmax, deferred max
-      bf16x8 pb[4];
+    };
+    // online softmax with a deferred maximum: ONE (rare) branch per step covers all four query tiles, so the
+    // common path of a step is a single basic block the scheduler can interleave with the neighbouring MFMAs
+    auto softmax = [&](const f32x4 (&sc)[2][4], bf16x8 (&pb)[4]) {
+      float pm[4];
+      bool grow = false;
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt) {
-        float pm = max3f(max3f(max3f(sc[0][qt][0], sc[0][qt][1], sc[0][qt][2]), sc[0][qt][3], sc[1][qt][0]),
-                         max3f(sc[1][qt][1], sc[1][qt][2], sc[1][qt][3]), mrow[qt]);   // >= mrow: max3 is free
-        if (__any(pm > mrow[qt] + thr)) {
-          pm = fmaxf(pm, __shfl_xor(pm, 16, 64));
-          pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
-          const float mn = pm;
-          const float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mn) * c1);
+        pm[qt] = max3f(max3f(max3f(sc[0][qt][0], sc[0][qt][1], sc[0][qt][2]), sc[0][qt][3], sc[1][qt][0]),
+                       max3f(sc[1][qt][1], sc[1][qt][2], sc[1][qt][3]), mrow[qt]);     // >= mrow
+        grow |= pm[qt] > mrow[qt] + thr;
+      }
+      if (__any(grow)) {
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+          float mn = fmaxf(pm[qt], __shfl_xor(pm[qt], 16, 64));
+          mn = fmaxf(mn, __shfl_xor(mn, 32, 64));
+          const float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mn) * c1);   // 1 for the tiles that did not grow
           mrow[qt] = mn;
           lacc[qt] *= alpha;
 #pragma unroll
           for (int dt = 0; dt < MD; ++dt) o[dt][qt] *= alpha;
         }
+      }
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
         const float mc = mrow[qt] * c1;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
@@ -243,16 +253,17 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
           for (int r = 0; r < 4; ++r)
             pb[qt][hf * 4 + r] = (__bf16)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[hf][qt][r], c1, -mc));
       }
-
-      // ---- O^T += V^T P^T ; row sums via the ones-row
-      wave_lds_fence();
+    };
+    // O^T += V^T P^T ; row sums via the ones-row
+    auto pv = [&](int st, const bf16x8 (&pb)[4]) {
+      const char* sv = s_v + (PIPE ? (st & 1) * (32 * M * 2) : 0);
 #pragma unroll
       for (int dt = 0; dt < MD; ++dt) {
         bf16x8 vt;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const s16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(s_v + vtr_off[hf][dt]));
+              (s16x4 __attribute__((address_space(3)))*)(sv + vtr_off[hf][dt]));
           const bf16x4 tb4 = __builtin_bit_cast(bf16x4, t4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) vt[hf * 4 + e] = tb4[e];
@@ -264,16 +275,41 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt)
         lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qt], lacc[qt], 0, 0, 0);
-      wave_lds_fence();
     };
 
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, PF - 1> S1;
     load_step(S0{}, 0);
     if constexpr (PF == 2) { if (nsteps > 1) load_step(S1{}, 1); }
-    for (int st = 0; st < nsteps; st += PF) {
-      step(S0{}, st);
-      if constexpr (PF == 2) { if (st + 1 < nsteps) step(S1{}, st + 1); }
+    if constexpr (PIPE) {
+      // software pipeline over steps: S^T of step st+1 is ISSUED before the softmax of step st, so its LDS gathers
+      // and MFMAs run under that softmax's VALU work, and the P V MFMAs of step st run under the next step's
+      // gathers.  A single wave otherwise walks one long dependency chain per step (LDS gather -> MFMA -> max ->
+      // exp -> LDS transpose-read -> MFMA) with two waves per SIMD to cover it: PMC showed the wave issuing 42 %
+      // of its cycles, and cutting the VALU instructions per step from 196 to 120 moved the time by only 7 %.
+      f32x4 scA[2][4], scB[2][4];
+      bf16x8 pb[4];
+      stage_s(S0{}, 0, scA);
+      for (int st = 0; st < nsteps; st += 2) {
+        if (st + 1 < nsteps) stage_s(S1{}, st + 1, scB);
+        softmax(scA, pb);
+        pv(st, pb);
+        if (st + 1 < nsteps) {
+          if (st + 2 < nsteps) stage_s(S0{}, st + 2, scA);
+          softmax(scB, pb);
+          pv(st + 1, pb);
+        }
+      }
+    } else {
+      for (int st = 0; st < nsteps; ++st) {
+        f32x4 sc[2][4];
+        bf16x8 pb[4];
+        stage_s(S0{}, st, sc);
+        softmax(sc, pb);
+        wave_lds_fence();
+        pv(st, pb);
+        wave_lds_fence();
+      }
     }
 
     // ---- epilogue: normalise, store O (4 dims x 8 bytes per d-tile) and LSE
@@ -320,7 +356,7 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   c.NS = d->G + g.nact * g.W2;
   c.NSP = (c.NS + 31) & ~31;
   c.units_bh = g.mx * g.my * c.NWP;
-  c.wave_lds = ((c.NSP * 8 + 32 * d->M * 2 + 15) / 16) * 16;
+  c.wave_lds = ((c.NSP * 8 + (d->M <= 32 ? 2 : 1) * 32 * d->M * 2 + 15) / 16) * 16;   // slot tables + V tile(s) (PIPE: two)
   c.wpw = 4;
   while (c.wpw > 1 && (size_t)c.tabsize * 8 + (size_t)c.wpw * c.wave_lds > 160 * 1024) c.wpw >>= 1;
   const int groups = (c.units_bh + c.wpw - 1) / c.wpw;

@@ -53,6 +53,10 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
   constexpr int VCH = 2 * MD;
   constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;
   constexpr int PF = MD <= 2 ? 2 : 1;         // depth of the K / V prefetch ring
+#ifndef VIL_DQ_PIPE
+#define VIL_DQ_PIPE 1
+#endif
+  constexpr bool PIPE = VIL_DQ_PIPE && MD == 2;   // software pipeline over steps (two score tiles + two LDS K tiles live; M = 16 runs QT = 4 and would spill)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VilGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -193,22 +197,23 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
         }
       };
 
-      auto step = [&](auto slot_, int st) {
+      // stage_s(st): K tile of the step -> LDS tile of parity st & 1 (read both ways below), V fragments stay in
+      // registers, the ring slot is refilled; S^T = K Q^T + bias and dP^T = V dO^T are issued
+      auto stage_s = [&](auto slot_, int st, f32x4 (&sacc)[2][QT], f32x4 (&dpacc)[2][QT], unsigned (&i0)[2][4]) {
         constexpr int sl = decltype(slot_)::value;
+        char* sk = s_k + (PIPE ? (st & 1) * (32 * M * 2) : 0);
         bf16x8 vc[2][MK];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) vc[hf][ks] = vf[sl][hf][ks];
 #pragma unroll
-        for (int it = 0; it < MD; ++it) *(u32x4*)(s_k + kst_off[it]) = kr_[sl][it];
+        for (int it = 0; it < MD; ++it) *(u32x4*)(sk + kst_off[it]) = kr_[sl][it];
         i32x4 ak[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) ak[hf] = *(const i32x4*)(s_akey + st * 32 + hf * 16 + lg * 4);
         if (st + PF < nsteps) load_step(slot_, st + PF);
         wave_lds_fence();
-
-        bf16x8 dsb[QT];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           // K rows of this half as the A operand (natural layout, from the LDS tile)
@@ -216,14 +221,13 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) {
             bf16x8 z = {};
-            kc_[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(s_k + krow_off[hf][ks]) : z;
+            kc_[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(sk + krow_off[hf][ks]) : z;
           }
-          unsigned i0[4];
           lds_cvf tb[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            i0[r] = aq0b - (unsigned)ak[hf][r];
-            tb[r] = lds_f32(i0[r]);
+            i0[hf][r] = aq0b - (unsigned)ak[hf][r];
+            tb[r] = lds_f32(i0[hf][r]);
           }
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) {
@@ -234,25 +238,34 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
               acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_[ks], qf[ks][qt], acc, 0, 0, 0);
               dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc[hf][ks], dof[ks][qt], dp, 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], c1, -lse2[qt]));
-              const float ds = pr * (dp[r] - dlt[qt]);
-              dsb[qt][hf * 4 + r] = (__bf16)ds;
-              if (bc.do_hist)
-                __hip_atomic_fetch_add(lds_i32(i0[r] + hist_off) + qt, __float2int_rn(ds),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            sacc[hf][qt] = acc; dpacc[hf][qt] = dp;
           }
         }
-        // dQ^T += K^T dS^T
+      };
+      // dS^T = P^T o (dP^T - delta) (+ the bias-gradient histogram), then dQ^T += K^T dS^T
+      auto finish = [&](int st, const f32x4 (&sacc)[2][QT], const f32x4 (&dpacc)[2][QT], const unsigned (&i0)[2][4]) {
+        const char* sk = s_k + (PIPE ? (st & 1) * (32 * M * 2) : 0);
+        bf16x8 dsb[QT];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][qt][r], c1, -lse2[qt]));
+              const float ds = pr * (dpacc[hf][qt][r] - dlt[qt]);
+              dsb[qt][hf * 4 + r] = (__bf16)ds;
+              if (bc.do_hist)
+                __hip_atomic_fetch_add(lds_i32(i0[hf][r] + hist_off) + qt, __float2int_rn(ds),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
 #pragma unroll
         for (int dt = 0; dt < MD; ++dt) {
           bf16x8 kt_;
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
             const s16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(s_k + ktr_off[hf][dt]));
+                (s16x4 __attribute__((address_space(3)))*)(sk + ktr_off[hf][dt]));
             const bf16x4 tb = __builtin_bit_cast(bf16x4, t4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) kt_[hf * 4 + e] = tb[e];
@@ -261,16 +274,34 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
           for (int qt = 0; qt < QT; ++qt)
             dq[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsb[qt], dq[dt][qt], 0, 0, 0);
         }
-        wave_lds_fence();
       };
 
       typedef std::integral_constant<int, 0> S0;
       typedef std::integral_constant<int, PF - 1> S1;
       load_step(S0{}, 0);
       if constexpr (PF == 2) { if (nsteps > 1) load_step(S1{}, 1); }
-      for (int st = 0; st < nsteps; st += PF) {
-        step(S0{}, st);
-        if constexpr (PF == 2) { if (st + 1 < nsteps) step(S1{}, st + 1); }
+      if constexpr (PIPE) {
+        // software pipeline over steps (see k_mfma_fwd): the score / dP MFMAs of step st+1 are issued before the
+        // VALU work of step st
+        f32x4 sA[2][QT], dA[2][QT], sB[2][QT], dB[2][QT];
+        unsigned iA[2][4], iB[2][4];
+        stage_s(S0{}, 0, sA, dA, iA);
+        for (int st = 0; st < nsteps; st += 2) {
+          if (st + 1 < nsteps) stage_s(S1{}, st + 1, sB, dB, iB);
+          finish(st, sA, dA, iA);
+          if (st + 1 < nsteps) {
+            if (st + 2 < nsteps) stage_s(S0{}, st + 2, sA, dA, iA);
+            finish(st + 1, sB, dB, iB);
+          }
+        }
+      } else {
+        for (int st = 0; st < nsteps; ++st) {
+          f32x4 sA[2][QT], dA[2][QT];
+          unsigned iA[2][4];
+          stage_s(S0{}, st, sA, dA, iA);
+          finish(st, sA, dA, iA);
+          wave_lds_fence();
+        }
       }
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt)
@@ -355,12 +386,17 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
 // ===================================================================== dK/dV pass
 // KT = key tiles (of 16 columns) per wave: 4 (64 keys) for M <= 32; 2 (32 keys) for M >= 48, where 64 keys'
 // accumulators (128 registers) + K/V fragments (64) pinned the kernel at one latency-bound wave per SIMD.
+#ifndef VIL_KV_KT32
+#define VIL_KV_KT32 2      // key tiles per wave at head_dim 32 (4: one wave per 7x7 chunk, 248 registers, no pipeline)
+#endif
 template <int MD, int KT>
 __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;
   constexpr int VCH = 2 * MD;
   constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;
+  constexpr bool PIPE = MD == 2 && KT == 2;   // software pipeline over steps (two score / dP tile sets, two LDS Q / dO tiles)
+  constexpr int PF = PIPE ? 2 : 1;            // depth of the Q / dO prefetch ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VilGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -386,9 +422,8 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
   int* s_aq = s_tok + bc.nqs;                     // [nqs] bias-table address term (bytes)
   float* s_lse = (float*)(s_aq + bc.nqs);         // [nqs] lse * log2(e)   (+big for padding slots)
   float* s_dlt = s_lse + bc.nqs;                  // [nqs] delta
-  char* s_q = (char*)(s_dlt + bc.nqs);            // [32][M] bf16 Q tile
-  char* s_do = s_q + 32 * M * 2;                  // [32][M] bf16 dO tile
-  char* s_gq = s_do + 32 * M * 2;                 // [G][3][M] bf16: q, dO, out rows of the global queries
+  char* s_q = (char*)(s_dlt + bc.nqs);            // [32][M] bf16 Q tile, then the [32][M] dO tile (PIPE: two such pairs)
+  char* s_gq = s_q + (PIPE ? 4 : 2) * 32 * M * 2;   // [G][3][M] bf16: q, dO, out rows of the global queries
 
   const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const __bf16*)p.q + b * p.q_sb + h * p.q_sh);
   const __amdgpu_buffer_rsrc_t drs = make_rsrc((const __bf16*)p.dout + b * p.do_sb + h * p.do_sh);
@@ -532,41 +567,42 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
       }
     wave_lds_fence();
 
-    u32x4 qr_[MD], dr_[MD];
-    auto load_step = [&](int st) {
+    // global -> register prefetch ring of the streamed Q / dO rows, PF steps deep
+    u32x4 qr_[PF][MD], dr_[PF][MD];
+    auto load_step = [&](auto slot_, int st) {
+      constexpr int sl = decltype(slot_)::value;
 #pragma unroll
       for (int it = 0; it < MD; ++it) {
         const int row = (it * 64 + lane) / VCH;
         const int tok = s_tok[st * 32 + row];          // Q and dO may have different row strides (fused qkv)
-        qr_[it] = __builtin_amdgcn_raw_buffer_load_b128(qrs, __mul24(tok, qstride_b) + ld_off[it], 0, 0);
-        dr_[it] = __builtin_amdgcn_raw_buffer_load_b128(drs, __mul24(tok, dostride_b) + ld_off[it], 0, 0);
+        qr_[sl][it] = __builtin_amdgcn_raw_buffer_load_b128(qrs, __mul24(tok, qstride_b) + ld_off[it], 0, 0);
+        dr_[sl][it] = __builtin_amdgcn_raw_buffer_load_b128(drs, __mul24(tok, dostride_b) + ld_off[it], 0, 0);
       }
     };
-    if (nsteps > 0) load_step(0);
-
-    for (int st = 0; st < nsteps; ++st) {
+    constexpr int TILE = 32 * M * 2;
+    // stage_s(st): the step's Q / dO rows leave the ring for the LDS tiles of parity st & 1 (read as rows here and
+    // transposed in finish), the ring slot is refilled; S = Q K^T + bias and dP = dO V^T are issued
+    auto stage_s = [&](auto slot_, int st, f32x4 (&sacc)[2][KT], f32x4 (&dpacc)[2][KT]) {
+      constexpr int sl = decltype(slot_)::value;
+      char* sq = s_q + (PIPE ? (st & 1) * 2 * TILE : 0);
+      char* sd = sq + TILE;
 #pragma unroll
       for (int it = 0; it < MD; ++it) {
-        *(u32x4*)(s_q + st_off[it]) = qr_[it];
-        *(u32x4*)(s_do + st_off[it]) = dr_[it];
+        *(u32x4*)(sq + st_off[it]) = qr_[sl][it];
+        *(u32x4*)(sd + st_off[it]) = dr_[sl][it];
       }
-      if (st + 1 < nsteps) load_step(st + 1);
+      if (st + PF < nsteps) load_step(slot_, st + PF);
       wave_lds_fence();
-
-      bf16x8 pb[KT], dsb[KT];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         bf16x8 qa[MK], da[MK];
 #pragma unroll
         for (int ks = 0; ks < MK; ++ks) {
           bf16x8 z = {};
-          qa[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(s_q + row_off[hf][ks]) : z;
-          da[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(s_do + row_off[hf][ks]) : z;
+          qa[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(sq + row_off[hf][ks]) : z;
+          da[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(sd + row_off[hf][ks]) : z;
         }
-        const int sb = st * 32 + hf * 16 + lg * 4;
-        const i32x4 aq4 = *(const i32x4*)(s_aq + sb);
-        const f32x4 ls4 = *(const f32x4*)(s_lse + sb);
-        const f32x4 dl4 = *(const f32x4*)(s_dlt + sb);
+        const i32x4 aq4 = *(const i32x4*)(s_aq + st * 32 + hf * 16 + lg * 4);
         lds_cvf tb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) tb[r] = lds_f32((unsigned)aq4[r] - akl);
@@ -579,24 +615,38 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kfb[ks][kt], acc, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[ks], vfb[ks][kt], dp, 0, 0, 0);
           }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], c1, -ls4[r]));
-            pb[kt][hf * 4 + r] = (__bf16)pr;
-            dsb[kt][hf * 4 + r] = (__bf16)(pr * (dp[r] - dl4[r]));
-          }
+          sacc[hf][kt] = acc; dpacc[hf][kt] = dp;
         }
       }
-      // dV^T += dO^T P ; dK^T += Q^T dS
+    };
+    // P = exp2(S c - lse), dS = P o (dP - delta);  dV^T += dO^T P ; dK^T += Q^T dS
+    auto finish = [&](int st, const f32x4 (&sacc)[2][KT], const f32x4 (&dpacc)[2][KT]) {
+      const char* sq = s_q + (PIPE ? (st & 1) * 2 * TILE : 0);
+      const char* sd = sq + TILE;
+      bf16x8 pb[KT], dsb[KT];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int sb = st * 32 + hf * 16 + lg * 4;
+        const f32x4 ls4 = *(const f32x4*)(s_lse + sb);
+        const f32x4 dl4 = *(const f32x4*)(s_dlt + sb);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r]));
+            pb[kt][hf * 4 + r] = (__bf16)pr;
+            dsb[kt][hf * 4 + r] = (__bf16)(pr * (dpacc[hf][kt][r] - dl4[r]));
+          }
+      }
 #pragma unroll
       for (int dt = 0; dt < MD; ++dt) {
         bf16x8 qt_, dt_;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const bf16x4 tq = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(s_q + tr_off[hf][dt])));
+              (s16x4 __attribute__((address_space(3)))*)(sq + tr_off[hf][dt])));
           const bf16x4 td = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(s_do + tr_off[hf][dt])));
+              (s16x4 __attribute__((address_space(3)))*)(sd + tr_off[hf][dt])));
 #pragma unroll
           for (int e = 0; e < 4; ++e) { qt_[hf * 4 + e] = tq[e]; dt_[hf * 4 + e] = td[e]; }
         }
@@ -606,7 +656,31 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
           dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsb[kt], dk[dt][kt], 0, 0, 0);
         }
       }
-      wave_lds_fence();
+    };
+
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, PF - 1> S1;
+    if (nsteps > 0) load_step(S0{}, 0);
+    if constexpr (PF == 2) { if (nsteps > 1) load_step(S1{}, 1); }
+    if constexpr (PIPE) {
+      // software pipeline over steps (see k_mfma_fwd): score / dP MFMAs of step st+1 issued before the VALU of step st
+      f32x4 sA[2][KT], dA[2][KT], sB[2][KT], dB[2][KT];
+      if (nsteps > 0) stage_s(S0{}, 0, sA, dA);
+      for (int st = 0; st < nsteps; st += 2) {
+        if (st + 1 < nsteps) stage_s(S1{}, st + 1, sB, dB);
+        finish(st, sA, dA);
+        if (st + 1 < nsteps) {
+          if (st + 2 < nsteps) stage_s(S0{}, st + 2, sA, dA);
+          finish(st + 1, sB, dB);
+        }
+      }
+    } else {
+      for (int st = 0; st < nsteps; ++st) {
+        f32x4 sA[2][KT], dA[2][KT];
+        stage_s(S0{}, st, sA, dA);
+        finish(st, sA, dA);
+        wave_lds_fence();
+      }
     }
 
     // ---- global-token QUERY rows (vil_attn_bwd_full): G extra queries that attend every key.  The unit's
@@ -872,7 +946,7 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
   bc.nch = g.mx * g.my;
   bc.nsplit = d->G > 0 ? (bc.nch + 8) / 9 : 0;
-  bc.kv_KT = d->M >= 48 ? 2 : 4;
+  bc.kv_KT = d->M >= 48 ? 2 : (d->M == 32 ? VIL_KV_KT32 : 4);
   bc.kv_HQ = (g.W + bc.kv_KT - 1) / bc.kv_KT;
   bc.kv_NWP = (g.W * bc.kv_HQ + 15) / 16;
   bc.units_kv_bh = bc.nch * bc.kv_NWP + bc.nsplit;
@@ -880,7 +954,8 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   const int qch = d->G > 0 ? (bc.nch + bc.nsplit - 1) / bc.nsplit : 0;
   bc.nqs = ((qch > g.nact ? qch : g.nact) * g.W2 + 31) & ~31;
   // slot tables + Q/dO tiles + the q / dO / out rows of the G global queries (vil_attn_bwd_full)
-  bc.kv_wave_lds = ((bc.nqs * 16 + 2 * 32 * d->M * 2 + d->G * 3 * d->M * 2 + 15) / 16) * 16;
+  const int kv_tiles = (d->M == 32 && bc.kv_KT == 2) ? 4 : 2;       // Q + dO tiles (pipelined kernel: two pairs)
+  bc.kv_wave_lds = ((bc.nqs * 16 + kv_tiles * 32 * d->M * 2 + d->G * 3 * d->M * 2 + 15) / 16) * 16;
   bc.kv_wpw = 4;
   while (bc.kv_wpw > 1 && (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
   const int groups = (bc.units_kv_bh + bc.kv_wpw - 1) / bc.kv_wpw;
@@ -889,7 +964,7 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   if (gpw > groups) gpw = groups;
   bc.kv_gpw = gpw;
   bc.kv_wg_per_bh = (groups + gpw - 1) / gpw;
-  bc.dq_wave_lds = ((c.NSP * 8 + 32 * d->M * 2 + 15) / 16) * 16;
+  bc.dq_wave_lds = ((c.NSP * 8 + (d->M <= 32 ? 2 : 1) * 32 * d->M * 2 + 15) / 16) * 16;   // slot tables + K tile(s)
   bc.dq_QT = d->M >= 32 ? 2 : 4;
   bc.dq_HQ = (g.W + bc.dq_QT - 1) / bc.dq_QT;
   bc.dq_NWP = (g.W * bc.dq_HQ + 15) / 16;
@@ -1007,11 +1082,11 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     vil_prof_begin(VIL_K_MFMA_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
     BWD_SWITCH({
       if (lds > 64 * 1024) {
-        hipError_t he = hipFuncSetAttribute((const void*)k_mfma_bwd_dkdv<MD_, (MD_ >= 3 ? 2 : 4)>,
+        hipError_t he = hipFuncSetAttribute((const void*)k_mfma_bwd_dkdv<MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (he != hipSuccess) return (int)he;
       }
-      k_mfma_bwd_dkdv<MD_, (MD_ >= 3 ? 2 : 4)><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
+      k_mfma_bwd_dkdv<MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
