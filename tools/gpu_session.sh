@@ -19,8 +19,8 @@ for STEP in "$@"; do
       echo "pytest rc=$?" >> "$OUT/pytest_gpu.log"; tail -15 "$OUT/pytest_gpu.log"
       cp gpurun_out/parity_report.txt "$OUT/parity_report.txt" 2>/dev/null ;;
     ab)
-      for SH in small_s1 small_s2 meddeep_s1_f7 meddeep_s2_f7 small_s3_dense basedeep_s1_f6_rs; do
-        for LIB in tools/ab/libvilattn_r01.so ""; do
+      for SH in ${AB_SHAPES:-small_s1 small_s2 meddeep_s1_f7 small_s3_dense basedeep_s1_f6_rs}; do
+        for LIB in $(ls tools/ab/*.so) ""; do
           echo "== $SH lib=${LIB:-HEAD}" >> "$OUT/ab.txt"
           VIL_ATTN_LIB=${LIB:+$PWD/$LIB} timeout 200 python tools/kernel_bench.py $SH --reps 10 >> "$OUT/ab.txt" 2>&1
         done
@@ -28,6 +28,9 @@ for STEP in "$@"; do
       cat "$OUT/ab.txt" ;;
     bench)
       timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 3000 "$OUT/bench.json" ;;
+    bench_r01lib)      # same engine, round-1 kernels: isolates kernel changes from box-to-box clock differences
+      VIL_ATTN_LIB=$PWD/tools/ab/libvilattn_r01.so timeout 600 python bench.py --no-cpu-baseline > "$OUT/bench_r01lib.json" 2> "$OUT/bench_r01lib.err"
+      python -c "import json,sys; d=json.load(open('$OUT/bench_r01lib.json')); print('r01 lib:', d['value'], d['ms_per_step'], d['hot_path_ms_per_step'])" ;;
     meddeep)
       timeout 600 python bench.py --config vil_medium_deep_384 --no-cpu-baseline > "$OUT/bench_meddeep.json" 2> "$OUT/bench_meddeep.err"
       tail -c 1500 "$OUT/bench_meddeep.json" ;;
