@@ -184,6 +184,9 @@ int vil_sc2d_mask(void* attn, int BH, int mx, int my, int padx, int pady, int W,
  * HBM bytes / flops of that launch.  Returns the count. */
 int vil_attn_profile_begin(int capacity);
 int vil_attn_profile_end(int capacity, int* kernel_id, float* ms, double* bytes, double* flops);
+/* same, plus the problem tag of every launch: 8 ints per record -- attention kernels {B,H,M,nx,ny,W,G,mode (9 = device
+ * word)}, weight-gradient kernels {T,CO,CI,0...} -- so one roofline per SHAPE can be reported */
+int vil_attn_profile_end2(int capacity, int* kernel_id, float* ms, double* bytes, double* flops, int* tags);
 const char* vil_attn_kernel_name(int kernel_id);
 
 /* ---- host-side geometry helpers (pure CPU, used by the tests to pin the

@@ -21,7 +21,7 @@ ABI_VERSION = 2
 
 EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_attn_workspace_bytes",
            "vil_attn_fwd", "vil_attn_bwd", "vil_geom_mask", "vil_geom_bias_index",
-           "vil_attn_profile_begin", "vil_attn_profile_end", "vil_attn_kernel_name",
+           "vil_attn_profile_begin", "vil_attn_profile_end", "vil_attn_profile_end2", "vil_attn_kernel_name",
            "vil_layernorm_workspace_bytes", "vil_layernorm_fwd", "vil_layernorm_bwd",
            "vil_glo_attn_fwd", "vil_glo_attn_bwd", "vil_attn_bwd_full",
            "vil_colsum_workspace_bytes", "vil_colsum_bf16", "vil_colsum_f32",
@@ -80,6 +80,9 @@ def lib():
         L.vil_attn_profile_begin.argtypes = [ctypes.c_int]
         L.vil_attn_profile_end.restype = ctypes.c_int
         L.vil_attn_profile_end.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
+        if hasattr(L, "vil_attn_profile_end2"):
+            L.vil_attn_profile_end2.restype = ctypes.c_int
+            L.vil_attn_profile_end2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5
         L.vil_attn_kernel_name.restype = ctypes.c_char_p
         L.vil_attn_kernel_name.argtypes = [ctypes.c_int]
         i64 = ctypes.c_int64
@@ -112,11 +115,12 @@ def lib():
         L.vil_gemm_bf16.argtypes = [ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                     ctypes.c_int64, vp, ctypes.c_size_t, vp]
         ci = ctypes.c_int
-        for fn in (L.vil_sc2d_qk, L.vil_sc2d_av, L.vil_sc2d_agrad):
-            fn.restype = ci
-            fn.argtypes = [vp, vp, vp] + [ci] * 7 + [vp]
-        L.vil_sc2d_mask.restype = ci
-        L.vil_sc2d_mask.argtypes = [vp] + [ci] * 9 + [vp, vp]
+        if not (os.environ.get("VIL_ATTN_LIB") and not hasattr(L, "vil_sc2d_qk")):   # (A/B against an older revision)
+            for fn in (L.vil_sc2d_qk, L.vil_sc2d_av, L.vil_sc2d_agrad):
+                fn.restype = ci
+                fn.argtypes = [vp, vp, vp] + [ci] * 7 + [vp]
+            L.vil_sc2d_mask.restype = ci
+            L.vil_sc2d_mask.argtypes = [vp] + [ci] * 9 + [vp, vp]
         L.vil_layernorm_workspace_bytes.restype = ctypes.c_size_t
         L.vil_layernorm_workspace_bytes.argtypes = [i64, ctypes.c_int]
         L.vil_layernorm_fwd.restype = ctypes.c_int
@@ -138,6 +142,22 @@ def check(code):
 
 def profile_begin(capacity=8192):
     check(lib().vil_attn_profile_begin(int(capacity)))
+
+
+def profile_end_tagged(capacity=8192):
+    """Returns a list of (kernel_name, ms, algorithmic_bytes, algorithmic_flops, tag) per launch; tag = the 8-int
+    problem tag (attention: B,H,M,nx,ny,W,G,mode; weight gradient: T,CO,CI,0,...)."""
+    import numpy as np
+    kid = np.zeros(capacity, dtype=np.int32)
+    ms = np.zeros(capacity, dtype=np.float32)
+    by = np.zeros(capacity, dtype=np.float64)
+    fl = np.zeros(capacity, dtype=np.float64)
+    tg = np.zeros((capacity, 8), dtype=np.int32)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    L = lib()
+    n = L.vil_attn_profile_end2(int(capacity), vp(kid), vp(ms), vp(by), vp(fl), vp(tg))
+    return [(L.vil_attn_kernel_name(int(kid[i])).decode(), float(ms[i]), float(by[i]), float(fl[i]),
+             tuple(int(v) for v in tg[i])) for i in range(n)]
 
 
 def profile_end(capacity=8192):

@@ -74,6 +74,7 @@ extern "C" int vil_attn_fwd(const VilAttnDesc* d, const void* q, const void* k, 
                             void* out, float* lse, void* workspace, void* stream) {
   int e = check_common(d);
   if (e) return e;
+  vil_prof_tag_desc(d);
   if (!q || !k || !v || !out || !lse) return VIL_E_NULL;
   const int be = pick_backend(d, 0);
   if (!be) return d->backend == VIL_BACKEND_AUTO ? vil_scalar_supported(d) : VIL_E_BACKEND;
@@ -95,6 +96,7 @@ extern "C" int vil_attn_bwd(const VilAttnDesc* d, const void* q, const void* k, 
                             void* workspace, void* stream) {
   int e = check_common(d);
   if (e) return e;
+  vil_prof_tag_desc(d);
   if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv) return VIL_E_NULL;
   if (bias_table && !dbias_table) return VIL_E_NULL;
   if (g2l && d->G > 0 && !dg2l) return VIL_E_NULL;
@@ -119,6 +121,7 @@ extern "C" int vil_attn_bwd_full(const VilAttnDesc* d, const void* q_all, const 
                                  void* workspace, void* stream) {
   int e = check_common(d);
   if (e) return e;
+  vil_prof_tag_desc(d);
   if (!q_all || !k || !v || !out_all || !dout_all || !lse || !lse_g || !dq_all || !dk || !dv) return VIL_E_NULL;
   if (bias_table && !dbias_table) return VIL_E_NULL;
   if ((g2l && !dg2l) || (g2g && !dg2g)) return VIL_E_NULL;
@@ -183,16 +186,23 @@ extern "C" int vil_geom_bias_index(int W, int mode, int32_t* rel) {
 // ------------------------------------------------------------ profiling sink
 // Process-global and not thread-safe by design: a measurement aid for bench.py, the
 // only state the library keeps.  Events are created once and reused.
-struct ProfRec { int kid; double bytes, flops; };
+static bool g_on = false;
+struct ProfRec { int kid; double bytes, flops; int tag[8]; };
+static int g_tag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+void vil_prof_tag(int a0, int a1, int a2, int a3, int a4, int a5, int a6, int a7) {
+  if (!g_on) return;
+  g_tag[0] = a0; g_tag[1] = a1; g_tag[2] = a2; g_tag[3] = a3; g_tag[4] = a4; g_tag[5] = a5; g_tag[6] = a6; g_tag[7] = a7;
+}
 static std::vector<hipEvent_t> g_ev;
 static std::vector<ProfRec> g_rec;
-static bool g_on = false;
 static size_t g_cap = 0;
 static bool g_open = false;
 
 void vil_prof_begin(int kid, hipStream_t s, double bytes, double flops) {
   if (!g_on || g_rec.size() >= g_cap) return;
-  g_rec.push_back({kid, bytes, flops});
+  ProfRec r; r.kid = kid; r.bytes = bytes; r.flops = flops;
+  for (int i = 0; i < 8; ++i) r.tag[i] = g_tag[i];
+  g_rec.push_back(r);
   g_open = true;
   (void)hipEventRecord(g_ev[2 * (g_rec.size() - 1)], s);
 }
@@ -205,7 +215,7 @@ void vil_prof_end(hipStream_t s) {
 extern "C" const char* vil_attn_kernel_name(int kid) {
   static const char* names[VIL_K_COUNT] = {"k_mfma_table", "k_mfma_fwd", "k_scalar_fwd", "k_delta", "k_scalar_bwd_dq",
                                            "k_scalar_bwd_dkdv", "k_reduce_glo", "k_reduce_bias", "k_mfma_bwd_dq",
-                                           "k_mfma_bwd_dkdv", "k_glo_fwd", "k_glo_bwd"};
+                                           "k_mfma_bwd_dkdv", "k_glo_fwd", "k_glo_bwd", "k_wgrad", "k_wgrad_reduce"};
   return (kid >= 0 && kid < VIL_K_COUNT) ? names[kid] : "?";
 }
 
@@ -221,7 +231,14 @@ extern "C" int vil_attn_profile_begin(int capacity) {
   return VIL_OK;
 }
 
+static int profile_drain(int cap, int* kid, float* ms, double* bytes, double* flops, int* tags);
 extern "C" int vil_attn_profile_end(int cap, int* kid, float* ms, double* bytes, double* flops) {
+  return profile_drain(cap, kid, ms, bytes, flops, nullptr);
+}
+extern "C" int vil_attn_profile_end2(int cap, int* kid, float* ms, double* bytes, double* flops, int* tags) {
+  return profile_drain(cap, kid, ms, bytes, flops, tags);
+}
+static int profile_drain(int cap, int* kid, float* ms, double* bytes, double* flops, int* tags) {
   g_on = false;
   const int n = (int)(g_rec.size() < (size_t)cap ? g_rec.size() : (size_t)cap);
   for (int i = 0; i < n; ++i) {
@@ -232,6 +249,7 @@ extern "C" int vil_attn_profile_end(int cap, int* kid, float* ms, double* bytes,
     if (ms) ms[i] = t;
     if (bytes) bytes[i] = g_rec[i].bytes;
     if (flops) flops[i] = g_rec[i].flops;
+    if (tags) for (int j = 0; j < 8; ++j) tags[8 * i + j] = g_rec[i].tag[j];
   }
   g_rec.clear();
   return n;

@@ -303,6 +303,7 @@ extern "C" int vil_glo_attn_fwd(const VilAttnDesc* d, const void* q_g, const voi
   GloParams p; glo_fill(p, d);
   p.q = q_g; p.k = k; p.v = v; p.o = out_g; p.lse = lse_g; p.g2g = g2g; p.g2l0 = g2l0;
   hipStream_t s = (hipStream_t)stream;
+  vil_prof_tag_desc(d);
   const double e_ = d->dtype == VIL_DTYPE_BF16 ? 2 : 4, n_ = (double)d->G + (double)d->nx * d->ny;
   vil_prof_begin(VIL_K_GLO_FWD, s, d->B * (2 * n_ + 2 * d->G) * d->H * d->M * e_, d->B * 4.0 * d->G * n_ * d->H * d->M);
   GLO_DISPATCH(k_glo_fwd, dim3(d->B * d->H), dim3(GLO_THREADS), 0, s);
@@ -321,6 +322,7 @@ extern "C" int vil_glo_attn_bwd(const VilAttnDesc* d, const void* q_g, const voi
   p.q = q_g; p.k = k; p.v = v; p.out = out_g; p.dout = dout_g; p.lse = (float*)lse_g; p.g2g = g2g; p.g2l0 = g2l0;
   p.dq = dq_g; p.dk = dk; p.dv = dv; p.dg2g = dg2g; p.dg2l0 = dg2l0;
   hipStream_t s = (hipStream_t)stream;
+  vil_prof_tag_desc(d);
   const double e_ = d->dtype == VIL_DTYPE_BF16 ? 2 : 4, n_ = (double)d->G + (double)d->nx * d->ny;
   // reads k, v, dk, dv and rewrites dk, dv (the in-place accumulation), + the G query-side rows
   vil_prof_begin(VIL_K_GLO_BWD, s, d->B * (6 * n_ + 4 * d->G) * d->H * d->M * e_, d->B * 10.0 * d->G * n_ * d->H * d->M);

@@ -56,14 +56,25 @@ __global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out) {
 }
 
 // ------------------------------------------------------------------ forward
+// tuning switches of the head_dim <= 32 instantiations (A/B builds: tools/ab/)
+#ifndef VIL_FWD_PIPE
+#define VIL_FWD_PIPE 0     // software pipeline over steps (S^T of step st+1 issued before the softmax of step st)
+#endif
+#ifndef VIL_FWD_PF
+#define VIL_FWD_PF 2       // depth of the K / V prefetch ring
+#endif
+#ifndef VIL_FWD_WAVES
+#define VIL_FWD_WAVES 2    // waves per SIMD the register allocation is held to (2: 256, 3: 168, 4: 128 VGPRs)
+#endif
+constexpr int fwd_waves(int MD) { return MD <= 2 ? VIL_FWD_WAVES : 2; }
 template <int MD>
-__global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
+__global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, MfmaCfg c) {
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;            // 32-wide K steps over the head dim
   constexpr int VCH = 2 * MD;                 // 16-byte chunks per V row
   constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;  // V tile XOR swizzle needs rows that are multiples of 64 B
-  constexpr int PF = MD <= 2 ? 2 : 1;         // depth of the K / V prefetch ring (register budget: M = 64 runs at 244)
-  constexpr bool PIPE = MD <= 2;              // software pipeline over steps (two score tiles + two LDS V tiles live)
+  constexpr bool PIPE = VIL_FWD_PIPE && MD <= 2;   // software pipeline over steps (two score tiles + two LDS V tiles live)
+  constexpr int PF = MD <= 2 ? (PIPE ? 2 : VIL_FWD_PF) : 1;   // depth of the K / V prefetch ring (M = 64 runs at 244 registers)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VilGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -301,14 +312,18 @@ __global__ __launch_bounds__(256, 2) void k_mfma_fwd(VilParams p, MfmaCfg c) {
         }
       }
     } else {
-      for (int st = 0; st < nsteps; ++st) {
+      auto one = [&](auto slot_, int st) {
         f32x4 sc[2][4];
         bf16x8 pb[4];
-        stage_s(S0{}, st, sc);
+        stage_s(slot_, st, sc);
         softmax(sc, pb);
         wave_lds_fence();
         pv(st, pb);
         wave_lds_fence();
+      };
+      for (int st = 0; st < nsteps; st += PF) {
+        one(S0{}, st);
+        if constexpr (PF == 2) { if (st + 1 < nsteps) one(S1{}, st + 1); }
       }
     }
 
@@ -356,7 +371,7 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   c.NS = d->G + g.nact * g.W2;
   c.NSP = (c.NS + 31) & ~31;
   c.units_bh = g.mx * g.my * c.NWP;
-  c.wave_lds = ((c.NSP * 8 + (d->M <= 32 ? 2 : 1) * 32 * d->M * 2 + 15) / 16) * 16;   // slot tables + V tile(s) (PIPE: two)
+  c.wave_lds = ((c.NSP * 8 + ((VIL_FWD_PIPE && d->M <= 32) ? 2 : 1) * 32 * d->M * 2 + 15) / 16) * 16;   // slot tables + V tile(s) (PIPE: two)
   c.wpw = 4;
   while (c.wpw > 1 && (size_t)c.tabsize * 8 + (size_t)c.wpw * c.wave_lds > 160 * 1024) c.wpw >>= 1;
   const int groups = (c.units_bh + c.wpw - 1) / c.wpw;

@@ -46,17 +46,24 @@ struct BwdCfg {
 // ===================================================================== dQ pass
 // QT = query tiles (of 16 columns) per wave: 4 (64 query slots) for M <= 32, 2 for M >= 48 (two waves per
 // SIMD instead of one; same reasoning as KT of the dK/dV pass)
+#ifndef VIL_DQ_PIPE
+#define VIL_DQ_PIPE 0      // software pipeline over steps at head_dim 32
+#endif
+#ifndef VIL_DQ_PF
+#define VIL_DQ_PF 2        // depth of the K / V prefetch ring at head_dim <= 32
+#endif
+#ifndef VIL_DQ_WAVES
+#define VIL_DQ_WAVES 3     // waves per SIMD of the head_dim 32 instantiation
+#endif
+constexpr int dq_waves(int MD) { return MD == 2 ? VIL_DQ_WAVES : 2; }
 template <int MD, int QT>
-__global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, BwdCfg bc) {
+__global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, BwdCfg bc) {
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;
   constexpr int VCH = 2 * MD;
   constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;
-  constexpr int PF = MD <= 2 ? 2 : 1;         // depth of the K / V prefetch ring
-#ifndef VIL_DQ_PIPE
-#define VIL_DQ_PIPE 1
-#endif
   constexpr bool PIPE = VIL_DQ_PIPE && MD == 2;   // software pipeline over steps (two score tiles + two LDS K tiles live; M = 16 runs QT = 4 and would spill)
+  constexpr int PF = PIPE ? 2 : (MD <= 2 ? VIL_DQ_PF : 1);   // depth of the K / V prefetch ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VilGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -295,12 +302,16 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, 
           }
         }
       } else {
-        for (int st = 0; st < nsteps; ++st) {
+        auto one = [&](auto slot_, int st) {
           f32x4 sA[2][QT], dA[2][QT];
           unsigned iA[2][4];
-          stage_s(S0{}, st, sA, dA, iA);
+          stage_s(slot_, st, sA, dA, iA);
           finish(st, sA, dA, iA);
           wave_lds_fence();
+        };
+        for (int st = 0; st < nsteps; st += PF) {
+          one(S0{}, st);
+          if constexpr (PF == 2) { if (st + 1 < nsteps) one(S1{}, st + 1); }
         }
       }
 #pragma unroll
@@ -387,16 +398,26 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
 // KT = key tiles (of 16 columns) per wave: 4 (64 keys) for M <= 32; 2 (32 keys) for M >= 48, where 64 keys'
 // accumulators (128 registers) + K/V fragments (64) pinned the kernel at one latency-bound wave per SIMD.
 #ifndef VIL_KV_KT32
-#define VIL_KV_KT32 2      // key tiles per wave at head_dim 32 (4: one wave per 7x7 chunk, 248 registers, no pipeline)
+#define VIL_KV_KT32 4      // key tiles per wave at head_dim 32 (4: one wave per 7x7 chunk, 248 registers)
 #endif
+#ifndef VIL_KV_PIPE
+#define VIL_KV_PIPE 0      // software pipeline over steps (head_dim 32 with 2 key tiles per wave only)
+#endif
+#ifndef VIL_KV_PF
+#define VIL_KV_PF 1        // depth of the Q / dO prefetch ring at head_dim 32
+#endif
+#ifndef VIL_KV_WAVES
+#define VIL_KV_WAVES 2     // waves per SIMD of the head_dim 32 instantiation
+#endif
+constexpr int kv_waves(int MD) { return MD == 2 ? VIL_KV_WAVES : 2; }
 template <int MD, int KT>
-__global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
+__global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;
   constexpr int VCH = 2 * MD;
   constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;
-  constexpr bool PIPE = MD == 2 && KT == 2;   // software pipeline over steps (two score / dP tile sets, two LDS Q / dO tiles)
-  constexpr int PF = PIPE ? 2 : 1;            // depth of the Q / dO prefetch ring
+  constexpr bool PIPE = VIL_KV_PIPE && MD == 2 && KT == 2;   // software pipeline over steps (two score / dP tile sets, two LDS Q / dO tiles)
+  constexpr int PF = PIPE ? 2 : (MD == 2 ? VIL_KV_PF : 1);   // depth of the Q / dO prefetch ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const VilGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -675,11 +696,15 @@ __global__ __launch_bounds__(256, 2) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c
         }
       }
     } else {
-      for (int st = 0; st < nsteps; ++st) {
+      auto one = [&](auto slot_, int st) {
         f32x4 sA[2][KT], dA[2][KT];
-        stage_s(S0{}, st, sA, dA);
+        stage_s(slot_, st, sA, dA);
         finish(st, sA, dA);
         wave_lds_fence();
+      };
+      for (int st = 0; st < nsteps; st += PF) {
+        one(S0{}, st);
+        if constexpr (PF == 2) { if (st + 1 < nsteps) one(S1{}, st + 1); }
       }
     }
 
@@ -954,7 +979,7 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   const int qch = d->G > 0 ? (bc.nch + bc.nsplit - 1) / bc.nsplit : 0;
   bc.nqs = ((qch > g.nact ? qch : g.nact) * g.W2 + 31) & ~31;
   // slot tables + Q/dO tiles + the q / dO / out rows of the G global queries (vil_attn_bwd_full)
-  const int kv_tiles = (d->M == 32 && bc.kv_KT == 2) ? 4 : 2;       // Q + dO tiles (pipelined kernel: two pairs)
+  const int kv_tiles = (VIL_KV_PIPE && d->M == 32 && bc.kv_KT == 2) ? 4 : 2;       // Q + dO tiles (pipelined kernel: two pairs)
   bc.kv_wave_lds = ((bc.nqs * 16 + kv_tiles * 32 * d->M * 2 + d->G * 3 * d->M * 2 + 15) / 16) * 16;
   bc.kv_wpw = 4;
   while (bc.kv_wpw > 1 && (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
@@ -964,7 +989,7 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   if (gpw > groups) gpw = groups;
   bc.kv_gpw = gpw;
   bc.kv_wg_per_bh = (groups + gpw - 1) / gpw;
-  bc.dq_wave_lds = ((c.NSP * 8 + (d->M <= 32 ? 2 : 1) * 32 * d->M * 2 + 15) / 16) * 16;   // slot tables + K tile(s)
+  bc.dq_wave_lds = ((c.NSP * 8 + ((VIL_DQ_PIPE && d->M == 32) ? 2 : 1) * 32 * d->M * 2 + 15) / 16) * 16;   // slot tables + K tile(s)
   bc.dq_QT = d->M >= 32 ? 2 : 4;
   bc.dq_HQ = (g.W + bc.dq_QT - 1) / bc.dq_QT;
   bc.dq_NWP = (g.W * bc.dq_HQ + 15) / 16;

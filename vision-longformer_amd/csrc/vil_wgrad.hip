@@ -239,10 +239,17 @@ extern "C" int vil_linear_wgrad(const void* dy, const void* x, int64_t T, int CO
   p.dw = dw; p.db = db; p.out_bf16 = out_bf16;
   hipStream_t s = (hipStream_t)stream;
   p.tiles = tiles_co * p.tiles_ci;
+  // algorithmic traffic of the pair: dY and X read once, dW (+db) written once; the fp32 partials are overhead
+  const double ob = out_bf16 ? 2.0 : 4.0;
+  vil_prof_tag((int)T, CO, CI, 0, 0, 0, 0, 0);
+  vil_prof_begin(VIL_K_WGRAD, s, 2.0 * (double)T * (CO + CI) + ob * ((double)CO * CI + (db ? CO : 0)), 2.0 * (double)T * CO * CI);
   k_wgrad<<<dim3(p.tiles * ((p.nsplit + 7) / 8 * 8)), dim3(256), 0, s>>>(p);
+  vil_prof_end(s);
   int e = (int)hipGetLastError();
   if (e) return e;
   const int64_t n = (int64_t)CO * CI / 4 + (db ? CO : 0);
+  vil_prof_begin(VIL_K_WGRAD_REDUCE, s, 0, 0);
   k_wgrad_reduce<<<dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s>>>(p);
+  vil_prof_end(s);
   return (int)hipGetLastError();
 }
