@@ -56,15 +56,21 @@ __global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out) {
 }
 
 // ------------------------------------------------------------------ forward
-// tuning switches of the head_dim <= 32 instantiations (A/B builds: tools/ab/)
+// Tuning switches of the head_dim <= 32 instantiations (A/B builds: tools/ab/build_variants.sh).  Measured on one
+// MI355X box, ViL-Small stage 1 (56x56, W 7, M 32, B 128), round-1 kernel 285 us:
+//   pipeline 0, ring 2, 2 waves/SIMD  263 us      pipeline 0, ring 1, 3 waves/SIMD (168 VGPRs)  243 us   <- default
+//   pipeline 0, ring 2, 3 waves/SIMD  274 us      pipeline 1 (252 VGPRs, 2 waves)              272 us
+//   4 waves/SIMD (128 VGPRs, 256 B of scratch)  686 us
+// i.e. occupancy beats both a deeper prefetch ring and software pipelining: a wave issues one instruction per ~5
+// cycles whatever it does, so the SIMD's issue rate scales with resident waves until the registers spill.
 #ifndef VIL_FWD_PIPE
 #define VIL_FWD_PIPE 0     // software pipeline over steps (S^T of step st+1 issued before the softmax of step st)
 #endif
 #ifndef VIL_FWD_PF
-#define VIL_FWD_PF 2       // depth of the K / V prefetch ring
+#define VIL_FWD_PF 1       // depth of the K / V prefetch ring
 #endif
 #ifndef VIL_FWD_WAVES
-#define VIL_FWD_WAVES 2    // waves per SIMD the register allocation is held to (2: 256, 3: 168, 4: 128 VGPRs)
+#define VIL_FWD_WAVES 3    // waves per SIMD the register allocation is held to (2: 256, 3: 168, 4: 128 VGPRs)
 #endif
 constexpr int fwd_waves(int MD) { return MD <= 2 ? VIL_FWD_WAVES : 2; }
 template <int MD>

@@ -46,11 +46,13 @@ struct BwdCfg {
 // ===================================================================== dQ pass
 // QT = query tiles (of 16 columns) per wave: 4 (64 query slots) for M <= 32, 2 for M >= 48 (two waves per
 // SIMD instead of one; same reasoning as KT of the dK/dV pass)
+// Tuning switches (see vil_attn_mfma.hip).  ViL-Small stage 1, round-1 kernel 407 us: ring 1 / 3 waves 367 us (default);
+// ring 2 / 3 waves 398; ring 1 / 4 waves (128 VGPRs, 36 B scratch) 389; software pipeline (219 VGPRs, 2 waves) 460.
 #ifndef VIL_DQ_PIPE
 #define VIL_DQ_PIPE 0      // software pipeline over steps at head_dim 32
 #endif
 #ifndef VIL_DQ_PF
-#define VIL_DQ_PF 2        // depth of the K / V prefetch ring at head_dim <= 32
+#define VIL_DQ_PF 1        // depth of the K / V prefetch ring at head_dim <= 32
 #endif
 #ifndef VIL_DQ_WAVES
 #define VIL_DQ_WAVES 3     // waves per SIMD of the head_dim 32 instantiation
@@ -397,6 +399,9 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
 // ===================================================================== dK/dV pass
 // KT = key tiles (of 16 columns) per wave: 4 (64 keys) for M <= 32; 2 (32 keys) for M >= 48, where 64 keys'
 // accumulators (128 registers) + K/V fragments (64) pinned the kernel at one latency-bound wave per SIMD.
+// ViL-Small stage 1, round-1 kernel 427 us: 4 key tiles / 2 waves 411 us (default); 2 key tiles per wave (two waves per
+// 7x7 chunk, each streaming the same Q / dO rows) 510 at 3 waves/SIMD, 506 pipelined, 710 at 4 waves; 4 key tiles held
+// to 168 VGPRs spill 404 B and run 1195 us.
 #ifndef VIL_KV_KT32
 #define VIL_KV_KT32 4      // key tiles per wave at head_dim 32 (4: one wave per 7x7 chunk, 248 registers)
 #endif
