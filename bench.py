@@ -12,11 +12,22 @@ torch.cuda.synchronize(); the elapsed time is the MAX over ranks; rank 0 prints 
 JSON line.  `value` = images of all ranks / that time (weak scaling: fixed per-GPU batch).
 
 Extra objects on the same line:
-  roofline      the dominant hot-path kernel over the timed region: per-launch durations
-                come from hipEvents the library records around each of its launches on
-                the launch stream (vil_attn_profile_begin/_end); achieved = sum of the
-                launches' ALGORITHMIC bytes / sum of their durations.
-  kernels       the same statistics for every hot-path kernel.
+  roofline      k_mfma_bwd_dkdv (the dominant kernel) AT THE STAGE-1 SLIDING-CHUNK SHAPE of the
+                workload -- the hot path proper -- not an average over different problems:
+                per-launch durations come from hipEvents the library records around each of
+                its launches on the launch stream (vil_attn_profile_begin/_end2, every record
+                tagged with its problem shape); achieved = ALGORITHMIC bytes of the launch /
+                its average duration.  `traffic` = PMC HBM bytes per launch of
+                that kernel at that shape, collected inside the real step (tools/pmc_step.sh ->
+                profiles/r02_pmc_traffic.json) and attached ONLY when the kernel sources'
+                fingerprint matches the build that is running.
+  roofline_by_shape   the same for fwd / dQ / dK+dV / delta at every hot-path shape of the
+                workload, plus `backward_unit`: SURVEY 8(d)'s whole-backward definition
+                ((4 Nloc + 4 N) C e + 4 H Nloc bytes over delta + dQ + dK/dV + reduces).
+  wgrad_roofline      k_wgrad (the largest single kernel family of the step).
+  kernels       aggregated statistics of every library kernel.
+  secondary     the other half of BASELINE's metric, ViL-Medium-Deep@384 (B=32/GPU), measured in
+                the same run with the same method (fewer steps): value, ms_per_step, roofline.
   cpu_baseline  the oracle (CPU restatement of the reference path) inside the same host
                 model, timed on this box's host cores on a bounded sample (rank 0, N=1).
 """
@@ -44,7 +55,7 @@ def cpu_baseline(config, seconds):
     from oracle.cpu_model import build_cpu_baseline_model
     from vision_longformer_amd.engine import CONFIGS, make_optimizer, SyntheticBatches, train_step
     cores = len(os.sched_getaffinity(0))
-    threads = min(cores, 64)
+    threads = min(cores, 32)          # measured: 64 threads across two sockets are slower than 8-32
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     img = CONFIGS[config][1]
@@ -91,37 +102,105 @@ def kernel_stats(recs):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="vil_small_224")
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="auto", choices=["auto", "scalar", "mfma"])
-    ap.add_argument("--master-weights", default="on", choices=["on", "off"],
-                    help="bf16 working weights + fp32 master (engine.MasterWeightAdamW) instead of per-call autocast casts")
-    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="run the step as hipGraphs (auto = on; random-shift neighbours are device-side words refreshed per replay); "
-                         "off = eager step under DDP (bucketed all-reduce overlapped with backward)")
-    args = ap.parse_args()
+def shape_label(tag):
+    B, H, M, nx, ny, W, G, mode = tag
+    dense = mode == -1 and W >= max(nx, ny)
+    return f"{nx}x{ny}_w{W}_h{H}m{M}" + ("_dense" if dense else ("_rs" if mode > 0 else ""))
 
-    from vision_longformer_amd import _lib, ops
-    from vision_longformer_amd.engine import (CONFIGS, init_distributed, build_vil, make_optimizer, wrap_ddp,
-                                             SyntheticBatches, train_step, GraphedTrainStep, MasterWeightAdamW)
-    rank, local_rank, world, device = init_distributed()
-    if device.type != "cuda":
-        raise SystemExit("bench.py needs a GPU: the product path is HIP-only (no CPU fallback)")
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    _lib.lib()                                  # fail loudly if the extension is missing
-    ops.DEFAULT_BACKEND = args.backend
-    fam, img, cfg_batch, f1, f2, mode = CONFIGS[args.config]
-    B = args.batch or cfg_batch
+
+def per_shape_stats(recs):
+    """{shape label: {kernel: {launches, avg_ms, bytes_per_launch, GBps, frac_hbm, TFLOPs, frac_mfma}}} for the
+    attention kernels, + the SURVEY 8(d) whole-backward unit per shape."""
+    acc = {}
+    for name, ms, by, fl, tag in recs:
+        if name.startswith("k_wgrad"):
+            continue
+        a = acc.setdefault(shape_label(tag), {"tag": tag, "k": {}})["k"].setdefault(name, [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += by; a[3] += fl
+    out = {}
+    for lab, d in acc.items():
+        B, H, M, nx, ny, W, G, mode = d["tag"]
+        ks = {}
+        for name, (n, ms, by, fl) in d["k"].items():
+            t = ms / n * 1e-3
+            ks[name] = {"launches": n, "avg_ms": round(ms / n, 5), "bytes_per_launch": round(by / n),
+                        "GBps": round(by / n / t / 1e9, 1) if t > 0 else 0.0,
+                        "frac_hbm": round(by / n / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else 0.0,
+                        "TFLOPs": round(fl / n / t / 1e12, 1) if t > 0 else 0.0,
+                        "frac_mfma": round(fl / n / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if t > 0 else 0.0}
+        bw = [k for k in ("k_delta", "k_mfma_bwd_dq", "k_mfma_bwd_dkdv", "k_reduce_glo", "k_reduce_bias", "k_glo_bwd") if k in ks]
+        if "k_mfma_bwd_dkdv" in ks:
+            nloc, n_all, C = nx * ny, nx * ny + G, H * M
+            unit_bytes = B * ((4 * nloc + 4 * n_all) * C * 2 + 4 * H * nloc)
+            t = sum(ks[k]["avg_ms"] for k in bw) * 1e-3
+            ks["backward_unit"] = {"definition": "SURVEY 8(d): (4 Nloc + 4 N) C e + 4 H Nloc bytes over delta + dQ + dK/dV + reduces",
+                                   "bytes": unit_bytes, "ms": round(t * 1e3, 5), "GBps": round(unit_bytes / t / 1e9, 1),
+                                   "frac_hbm": round(unit_bytes / t / 1e9 / HBM_PEAK_GBS, 4)}
+        out[lab] = ks
+    return out, {lab: d["tag"] for lab, d in acc.items()}
+
+
+def hot_shape(tags):
+    """the stage-1 sliding-chunk layer: the non-dense shape with the most local tokens"""
+    best = None
+    for lab, (B, H, M, nx, ny, W, G, mode) in tags.items():
+        if lab.endswith("_dense"):
+            continue
+        if best is None or nx * ny > best[1]:
+            best = (lab, nx * ny)
+    return best[0] if best else None
+
+
+def pmc_traffic(config, B, kernel, label):
+    """PMC HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X guide), collected inside the real step by
+    tools/pmc_step.sh; only for the build whose kernel sources it was collected on."""
+    from vision_longformer_amd import _lib
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        if pm.get("source_fingerprint") != _lib.source_fingerprint():
+            return None
+        e = pm["configs"][config]
+        if e["per_gpu_batch"] != B:
+            return None
+        return round(e["kernels"][kernel][label]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def roofline_of(config, B, shapes, tags, kernel="k_mfma_bwd_dkdv"):
+    lab = hot_shape(tags)
+    if lab is None or kernel not in shapes.get(lab, {}):
+        return None
+    k = shapes[lab][kernel]
+    return {"kernel": kernel, "shape": lab, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": k["frac_hbm"], "traffic": pmc_traffic(config, B, kernel, lab),
+            "algorithmic_bytes_per_launch": k["bytes_per_launch"], "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
+            "achieved_tflops": k["TFLOPs"], "frac_of_bf16_mfma_peak": k["frac_mfma"],
+            "backward_unit_frac": shapes[lab].get("backward_unit", {}).get("frac_hbm")}
+
+
+def wgrad_stats(recs):
+    rows = [(ms, by, fl, tag) for name, ms, by, fl, tag in recs if name == "k_wgrad"]
+    red = sum(ms for name, ms, by, fl, tag in recs if name == "k_wgrad_reduce")
+    if not rows:
+        return None
+    t = sum(r[0] for r in rows) * 1e-3
+    by, fl = sum(r[1] for r in rows), sum(r[2] for r in rows)
+    return {"kernel": "k_wgrad", "launches": len(rows), "total_ms": round(t * 1e3, 3), "reduce_total_ms": round(red, 3),
+            "GBps": round(by / t / 1e9, 1), "frac_hbm": round(by / t / 1e9 / HBM_PEAK_GBS, 4),
+            "TFLOPs": round(fl / t / 1e12, 1), "frac_mfma": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "bound": "mfma" if fl / by > MFMA_BF16_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm"}
+
+
+def measure(args, config, B, steps, warmup, rank, world, device):
+    """Builds the model of `config`, runs W warm-up + K timed steps (barrier + synchronize on both sides), then a
+    profiled eager replay.  Returns the result dict pieces (rank-0 meaningful)."""
+    from vision_longformer_amd import _lib
+    from vision_longformer_amd.engine import (CONFIGS, build_vil, make_optimizer, wrap_ddp, SyntheticBatches, train_step,
+                                             GraphedTrainStep, MasterWeightAdamW)
+    fam, img, cfg_batch, f1, f2, mode = CONFIGS[config]
     torch.manual_seed(0)
-    model = build_vil(args.config).to(device).train()
+    model = build_vil(config).to(device).train()
     use_graph = args.graph in ("on", "auto")
     use_master = args.master_weights == "on"
     opt = MasterWeightAdamW(model, capturable=use_graph) if use_master else make_optimizer(model, capturable=use_graph)
@@ -159,7 +238,7 @@ def main():
             use_graph = False
             torch.cuda.synchronize()
             torch.manual_seed(0)
-            model = build_vil(args.config).to(device).train()
+            model = build_vil(config).to(device).train()
             opt = MasterWeightAdamW(model) if use_master else make_optimizer(model)
     if use_graph:
         step_fn = lambda xb, tb: gstep(xb, tb)
@@ -167,83 +246,133 @@ def main():
         ddp = wrap_ddp(model, device, world)
         step_fn = lambda xb, tb: train_step(ddp, opt, xb, tb)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step_fn(*data.next())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    cap = max(1024, args.steps * 512)
+    cap = max(2048, steps * 1024)
     if not use_graph:                  # (a replayed graph makes no library calls: its kernels are profiled below)
         _lib.profile_begin(cap)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step_fn(*data.next())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    nprof = steps
     if use_graph:
         # per-kernel hipEvent timing needs the library's own launches: run the SAME step eagerly,
         # right after the timed region, on the same weights / shapes (not part of `value`)
+        nprof = min(steps, 5)
         _lib.profile_begin(cap)
-        for _ in range(min(args.steps, 5)):
+        for _ in range(nprof):
             gstep._body(eager=True)
         torch.cuda.synchronize()
-    recs = _lib.profile_end(cap)
+    recs = _lib.profile_end_tagged(cap)
+    dump = os.environ.get("VIL_BENCH_DUMP_TAGS")
+    if dump and rank == 0:       # tools/pmc_step.sh: launch order (kernel, shape, algorithmic bytes) of ONE step
+        per = len(recs) // max(nprof, 1)
+        prev = json.load(open(dump)) if os.path.exists(dump) else {}
+        prev[config] = {"per_gpu_batch": B, "launches": [[r[0], shape_label(r[4]) if not r[0].startswith("k_wgrad")
+                                                          else "T%d_co%d_ci%d" % r[4][:3], r[2]] for r in recs[:per]]}
+        json.dump(prev, open(dump, "w"))
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(loss.item())
+    comm = gstep.comm_summary() if (use_graph and world > 1) else None
+    del step_fn
+    return dict(elapsed=elapsed, recs=recs, nprof=nprof, loss=loss_val, use_graph=use_graph, use_master=use_master,
+                fam=fam, img=img, f1=f1, f2=f2, mode=mode, comm=comm)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="vil_small_224")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the ViL-Medium-Deep@384 leg (the second half of BASELINE's metric) of the default run")
+    ap.add_argument("--backend", default="auto", choices=["auto", "scalar", "mfma"])
+    ap.add_argument("--master-weights", default="on", choices=["on", "off"],
+                    help="bf16 working weights + fp32 master (engine.MasterWeightAdamW) instead of per-call autocast casts")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="run the step as hipGraphs (auto = on; random-shift neighbours are device-side words refreshed per replay); "
+                         "off = eager step under DDP (bucketed all-reduce overlapped with backward)")
+    args = ap.parse_args()
+
+    from vision_longformer_amd import _lib, ops
+    from vision_longformer_amd.engine import CONFIGS, init_distributed
+    rank, local_rank, world, device = init_distributed()
+    if device.type != "cuda":
+        raise SystemExit("bench.py needs a GPU: the product path is HIP-only (no CPU fallback)")
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    _lib.lib()                                  # fail loudly if the extension is missing
+    ops.DEFAULT_BACKEND = args.backend
+    B = args.batch or CONFIGS[args.config][2]
+    m = measure(args, args.config, B, args.steps, args.warmup, rank, world, device)
+
+    def line(config, B_, steps, warmup, m_):
+        ks = kernel_stats([r[:4] for r in m_["recs"]])
+        shapes, tags = per_shape_stats(m_["recs"])
+        hot_ms = sum(k["total_ms"] for n, k in ks.items() if not n.startswith("k_wgrad"))
+        return {
+            "value": round(B_ * world * steps / m_["elapsed"], 2), "unit": "images/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(m_["elapsed"] / steps * 1e3, 3),
+            "config": {"workload": f"{config}: ViL ({m_['fam']}) ATTN_TYPE=longformerhand rpe, {m_['img']}x{m_['img']}, "
+                                   f"windows f{m_['f1']}/f{m_['f2']}, train step fwd+bwd+AdamW, random-init weights",
+                       "global_batch": B_ * world, "per_gpu_batch": B_, "parallelism": f"dp{world}",
+                       "backend": args.backend, "random_shift_mode": m_["mode"],
+                       "precision": "bf16 compute, fp32 master weights + fp32 AdamW state"
+                                    + (" (bf16 working copy, foreach refresh)" if m_["use_master"] else " (autocast casts)"),
+                       "launch": ("hipGraph replay (fwd+bwd+AdamW)" if world == 1 else
+                                  "hipGraph replay per stage segment (fwd+bwd), flat-gradient RCCL all-reduce per segment on a side "
+                                  "stream overlapped with the next segment's replay, hipGraph replay (AdamW)")
+                                 if m_["use_graph"] else "eager (DDP bucketed all-reduce)"},
+            "roofline": roofline_of(config, B_, shapes, tags),
+            "roofline_by_shape": shapes,
+            "wgrad_roofline": wgrad_stats(m_["recs"]),
+            "hot_path_ms_per_step": round(hot_ms / m_["nprof"], 3),
+            "kernels": ks,
+            "comm": m_["comm"],
+            "final_loss": round(m_["loss"], 4),
+        }
+
+    out = None
+    if rank == 0:
+        out = {"metric": "images/sec (train) ViL-Small@224" if args.config == "vil_small_224"
+                         else f"images/sec (train) {args.config}"}
+        body = line(args.config, B, args.steps, args.warmup, m)
+        out.update({k: body[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")})
+        out.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic"})
+        out.update({k: body[k] for k in ("config", "roofline", "roofline_by_shape", "wgrad_roofline", "hot_path_ms_per_step",
+                                         "kernels", "comm", "final_loss")})
+    del m
+    torch.cuda.empty_cache()
+
+    # ---- the other half of BASELINE's metric in the same run: ViL-Medium-Deep@384, B=32 per GPU
+    if args.config == "vil_small_224" and not args.no_secondary and not args.batch:
+        cfg2 = "vil_medium_deep_384"
+        B2, steps2, warm2 = CONFIGS[cfg2][2], max(5, args.steps // 2), max(2, args.warmup // 2)
+        m2 = measure(args, cfg2, B2, steps2, warm2, rank, world, device)
+        if rank == 0:
+            sec = line(cfg2, B2, steps2, warm2, m2)
+            sec["metric"] = "images/sec (train) ViL-Medium-Deep@384"
+            sec.pop("kernels")
+            out["secondary"] = sec
+        del m2
+        torch.cuda.empty_cache()
 
     if rank == 0:
-        ks = kernel_stats(recs)
-        nprof = min(args.steps, 5) if use_graph else args.steps
-        hot_ms = sum(k["total_ms"] for k in ks.values())
-        dom = max(ks, key=lambda n: ks[n]["total_ms"]) if ks else None
-        roofline = None
-        if dom:
-            k = ks[dom]
-            tot_b = sum(r[2] for r in recs if r[0] == dom)
-            tot_f = sum(r[3] for r in recs if r[0] == dom)
-            ai = tot_f / tot_b if tot_b else 0.0
-            # the fused kernels sit just below the bf16 ridge (2.5 PF / 8 TB/s = 312 F/B) -> HBM roof
-            traffic = None
-            try:       # PMC HBM bytes per launch, collected offline with rocprofv3 --pmc (profiles/)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                if pm["config"] == args.config and pm["per_gpu_batch"] == B and dom in pm["kernels"]:
-                    traffic = round(pm["kernels"][dom]["hbm_bytes_per_launch"])
-            except (OSError, KeyError, ValueError):
-                pass
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(k["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": round(tot_b / k["launches"]),
-                        "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
-                        "arith_intensity_flop_per_byte": round(ai, 1),
-                        "achieved_tflops": k["TFLOPs"],
-                        "frac_of_bf16_mfma_peak": round(k["TFLOPs"] / MFMA_BF16_PEAK_TFLOPS, 4),
-                        "share_of_hot_path_time": round(k["total_ms"] / hot_ms, 3) if hot_ms else None}
-        out = {
-            "metric": "images/sec (train) ViL-Small@224" if args.config == "vil_small_224"
-                      else f"images/sec (train) {args.config}",
-            "value": round(B * world * args.steps / elapsed, 2), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.config}: ViL ({fam}) ATTN_TYPE=longformerhand rpe, {img}x{img}, "
-                                   f"windows f{f1}/f{f2}, train step fwd+bwd+AdamW, random-init weights",
-                       "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "backend": args.backend, "random_shift_mode": mode,
-                       "precision": "bf16 compute, fp32 master weights + fp32 AdamW state"
-                                    + (" (bf16 working copy, foreach refresh)" if use_master else " (autocast casts)"),
-                       "launch": "hipGraph replay (fwd+bwd" + ("+AdamW)" if world == 1 else "), flat-gradient RCCL all-reduce, "
-                                                                     "hipGraph replay (AdamW)")
-                                 if use_graph else "eager (DDP bucketed all-reduce)"},
-            "roofline": roofline,
-            "hot_path_ms_per_step": round(hot_ms / nprof, 3),
-            "kernels": ks,
-            "final_loss": round(loss_val, 4),
-        }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -113,7 +113,7 @@ def test_graphed_train_step_multi_rank_path(dev, monkeypatch):
     eager trajectory exactly like the single-graph flavour."""
     import vision_longformer_amd.engine as E
     calls = []
-    monkeypatch.setattr(E.dist, "all_reduce", lambda t, op=None: calls.append(t.numel()))
+    monkeypatch.setattr(E.dist, "all_reduce", lambda t, op=None, async_op=False: calls.append(t.numel()))
     arch = "l1,h1,d32,n1,s1,g1,p4,f4,a0_l2,h2,d64,n2,s1,g1,p2,f4,a0_l3,h2,d64,n1,s0,g1,p2,f7,a0"
     g = torch.Generator().manual_seed(5)
     xs = [torch.randn(8, 3, 64, 64, generator=g).to(dev) for _ in range(3)]
@@ -128,7 +128,7 @@ def test_graphed_train_step_multi_rank_path(dev, monkeypatch):
             sd = {k: v.clone() for k, v in m.state_dict().items()}
             msd = [mm.clone() for mm in opt.master]
             gs = E.GraphedTrainStep(m, opt, xs[0], ts[0], world=2, warmup=2)
-            assert gs.opt_graph is not None and len(gs.flats) >= 2
+            assert gs.opt_graph is not None and len(gs.graphs) == 3 and len(gs.flats) >= 3      # three backward segments
             with torch.no_grad():
                 for k, v in m.state_dict().items():
                     v.copy_(sd[k])
@@ -153,3 +153,48 @@ def test_graphed_train_step_multi_rank_path(dev, monkeypatch):
     report(f"     graph(world>1 path)-vs-eager losses {le} {lg}  max|dparam| {float((pe - pg).abs().max()):.3e}")
     assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-2
     assert float((pe - pg).abs().max()) < 2e-2
+
+
+def test_graphed_step_two_processes_one_gpu(dev, tmp_path):
+    """The DEFAULT multi-GPU path of bench.py (segment graphs -> asynchronous flat-gradient all-reduce per segment ->
+    optimizer graph) with a REAL process group: two processes share cuda:0 (VIL_SHARE_DEVICE=1, gloo), each trains on
+    its half of the batch through the HIP kernels for three steps; the ranks must end bit-identical, and equal (bf16
+    tolerance) to one process training eagerly on the concatenated batch."""
+    import socket
+    import sys
+    import ddp_graph_worker as W
+    from vision_longformer_amd.engine import MasterWeightAdamW, train_step
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    out = str(tmp_path / "rank0.pt")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VIL_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_graph_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p_ in procs:
+        try:
+            o, _ = p_.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p_.returncode == 0 for p_ in procs), "\n".join(logs)[-4000:]
+    got = torch.load(out)
+    assert got["same"], "ranks diverged"
+    assert got["ngraphs"] == 3 and got["comm"]["exposed_bytes"] < got["comm"]["total_bytes"]
+    # single process, eager, whole batch
+    m = W.build(dev)
+    opt = MasterWeightAdamW(m, lr=1e-3)
+    xs, ts = W.batches(dev)
+    le = [float(train_step(m, opt, x, t)) for x, t in zip(xs, ts)]
+    torch.cuda.synchronize()
+    pe = torch.cat([p.detach().float().reshape(-1) for p in m.parameters()]).cpu()
+    dl = max(abs(a - float(b)) for a, b in zip(le, got["losses"]))
+    dp = float((pe - got["params"]).abs().max())
+    report(f"     2-process graphed step (shared GPU, gloo) vs 1-process eager: max|dloss| {dl:.3e} max|dparam| {dp:.3e}; comm {got['comm']['segments_bytes']}")
+    assert dl < 2e-2 and dp < 2e-2

@@ -37,6 +37,8 @@ for STEP in "$@"; do
     pmc_*)
       SH=${STEP#pmc_}
       bash tools/pmc.sh $SH "$OUT/pmc_$SH" > "$OUT/pmc_$SH.txt" 2>&1; grep -A40 "k_mfma_fwd\|k_mfma_bwd" "$OUT/pmc_$SH.txt" | grep -- "--\|^k_" ;;
+    pmcstep)
+      bash tools/pmc_step.sh "$OUT/pmcstep" > "$OUT/pmcstep.txt" 2>&1; tail -30 "$OUT/pmcstep.txt" ;;
     smoke)
       python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" ;;
     *) echo "unknown step $STEP" ;;

@@ -135,6 +135,21 @@ def lib():
     return _lib
 
 
+def source_fingerprint():
+    """sha256 (16 hex digits) over the kernel sources and the ABI header: ties a PMC traffic file collected under
+    rocprofv3 to the build it was collected on (bench.py attaches `traffic` only when they match)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "vil_attn.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def check(code):
     if code != 0:
         raise VilAttnError(code, lib().vil_attn_strerror(code).decode())

@@ -240,41 +240,60 @@ def train_step(model, optimizer, images, targets, amp_dtype=torch.bfloat16):
 class GraphedTrainStep:
     """The training step as hipGraphs (HIP streams + graphs instead of per-op eager launches).
 
-    A ViL-Small step is ~900 kernel launches; once the hot path and the glue kernels are fast the host,
-    not the GPU, bounds the eager step (measured on MI355X: 23.4 ms of kernel time in a 24.8-26 ms step).
-    Graph A holds zero-grad + forward + backward on static buffers, graph B the optimizer step
-    (fp32-master AdamW or the capturable fused AdamW):
-      * autograd writes every gradient into the graph's private memory pool (p.grad is None on entry, so
-        nothing is zeroed or accumulated);
-      * world == 1: A and B are one graph;
-      * world > 1: neither graph contains a collective: graph A ends by packing the gradients into one
-        flat buffer per dtype (multi-tensor copy, 16-byte aligned views that become p.grad); replay A,
-        all-reduce (mean) the flat buffers in one RCCL call each over xGMI (bf16 gradients of the working
-        weights: ~50 MB for ViL-Small), replay B.  This gives up comm/compute overlap (~0.5 ms of ring
-        time per step) for no host launch cost.
+    A ViL-Small step is ~600 kernel launches; the host, not the GPU, bounds the eager step.
+      * world == 1: ONE graph: zero-grad + forward + backward + optimizer step (fp32-master AdamW or the capturable
+        fused AdamW) on static buffers; autograd writes every gradient into the graph's private memory pool
+        (p.grad is None on entry, so nothing is zeroed or accumulated).
+      * world > 1: the backward is cut into SEGMENTS at stage boundaries -- [last stage + norm + head], [stage
+        before it], [the first stages] -- each captured as its own graph (segment 0 also holds the forward); a
+        segment's graph ends by packing that segment's gradients into one flat buffer per dtype (16-byte aligned views
+        that become p.grad).  Per step: replay segment 0, start the RCCL all-reduce (mean) of its flat buffers
+        asynchronously (the collective runs on the process group's own stream, ordered after the replay), replay
+        segment 1 while that all-reduce is on the xGMI links, ... ; wait for the collectives; replay the optimizer
+        graph.  No graph contains a collective.  Only the LAST segment's all-reduce (the first stages: 1.3 MB of the
+        49 MB of bf16 gradients of ViL-Small) has no backward compute left to hide under: `comm_summary()`.
     Random-shift training (mode > 0) stays graphable: the neighbour of each layer is a device word read by the
     kernels (VilAttnDesc.mode_dev), refreshed from the host before every replay."""
 
-    def __init__(self, model, optimizer, images, targets, world=1, amp_dtype=torch.bfloat16, warmup=3):
+    def __init__(self, model, optimizer, images, targets, world=1, amp_dtype=torch.bfloat16, warmup=3, segments=3):
         self.model, self.opt, self.world, self.amp = model, optimizer, world, amp_dtype
         dev = images.device
         self.x = torch.empty_like(images)
         self.t = torch.empty_like(targets)
         self.params = [p for p in model.parameters() if p.requires_grad]
-        # world > 1: one flat gradient buffer per dtype for the all-reduce (16-byte aligned views)
-        self.flats, self.views = [], {}
+        # ---- backward segments (world > 1): parameters by the stage they belong to, last stage first
+        self.seg_params, self.cut_stages = [self.params], []
+        self.flats, self.views, self.seg_flats = [], {}, [[]]
         if world > 1:
-            by_dt = {}
-            for p in self.params:
-                by_dt.setdefault(p.dtype, []).append(p)
-            for dt, ps in by_dt.items():
-                sizes = [(p.numel() + 7) // 8 * 8 for p in ps]
-                flat = torch.zeros(sum(sizes), dtype=dt, device=dev)
-                off = 0
-                for p, n in zip(ps, sizes):
-                    self.views[p] = flat[off:off + p.numel()].view_as(p)
-                    off += n
-                self.flats.append(flat)
+            L = model.num_layers
+            nseg = max(1, min(int(segments), L))
+            stage_of = {}
+            for li in range(L):
+                for p in getattr(model, "layer%d" % (li + 1)).parameters():
+                    stage_of[id(p)] = li
+            # segment k covers stages [lo_k, hi_k]; cuts at the inputs of the last (nseg - 1) stages
+            self.cut_stages = list(range(L - 1, L - nseg, -1))          # e.g. L=4, nseg=3 -> [3, 2] (0-based stage index)
+            bounds = [L] + self.cut_stages + [0]
+            self.seg_params = []
+            for k in range(nseg):                                       # (norm / head: with the last stage)
+                lo, hi = bounds[k + 1], bounds[k]
+                self.seg_params.append([p for p in self.params if lo <= stage_of.get(id(p), L - 1) < hi])
+            assert sum(len(ps) for ps in self.seg_params) == len(self.params)
+            self.seg_flats = []
+            for ps in self.seg_params:                                 # one flat buffer per (segment, dtype)
+                by_dt, fl = {}, []
+                for p in ps:
+                    by_dt.setdefault(p.dtype, []).append(p)
+                for dt, pl in by_dt.items():
+                    sizes = [(p.numel() + 7) // 8 * 8 for p in pl]
+                    flat = torch.zeros(sum(sizes), dtype=dt, device=dev)
+                    off = 0
+                    for p, n in zip(pl, sizes):
+                        self.views[p] = flat[off:off + p.numel()].view_as(p)
+                        off += n
+                    fl.append(flat)
+                self.seg_flats.append(fl)
+                self.flats += fl
         # random-shift layers: the neighbour of every layer is a device word the kernels read at launch time;
         # it is drawn on the host before each replay with the reference's RNG call (one random.randrange(1, 9)
         # per layer forward, in layer order: longformer2d.py:114-123) and uploaded with one small copy
@@ -301,16 +320,26 @@ class GraphedTrainStep:
                 self._body(eager=True)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._fwd_bwd()
-            if world == 1:
+        self.graphs, self.opt_graph = [], None
+        if world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._segment(0, None)
                 self.opt.step()
-        self.opt_graph = None
-        if world > 1:
+            self.graphs.append(g)
+        else:
+            state, pool = None, None
+            for k in range(len(self.seg_params)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    state = self._segment(k, state)
+                pool = pool or g.pool()
+                self.graphs.append(g)
+            del state
             self.opt_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.opt_graph):
+            with torch.cuda.graph(self.opt_graph, pool=pool):
                 self.opt.step()
+        self.graph = self.graphs[0]
 
     def _draw_modes(self):
         if self.rs_layers and self.model.training:
@@ -327,47 +356,86 @@ class GraphedTrainStep:
                 self.modes_evt[k] = torch.cuda.Event()
             self.modes_evt[k].record()
 
-    def _fwd_bwd(self):
-        # p.grad = None: autograd then WRITES each gradient (into the graph's private pool: static addresses)
-        # instead of accumulating into a pre-zeroed buffer -- ~200 fewer tiny add kernels per ViL-Small step
-        for p in self.params:
-            p.grad = None
-        with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
-            loss = soft_target_cross_entropy(self.model(self.x), self.t)
-        loss.backward()
-        self.loss = loss.detach()
-        if self.world > 1:                      # pack for the all-reduce (multi-tensor copies)
-            with torch.no_grad():
-                ps = [p for p in self.params if p.grad is not None]
-                torch._foreach_copy_([self.views[p] for p in ps], [p.grad for p in ps])
-                for p in ps:
-                    p.grad = self.views[p]
+    def _segment(self, k, state):
+        """Segment k of the step.  k == 0: forward + loss + the backward of the last stage(s) (the whole backward when
+        there is one segment); k > 0: the backward from the previous cut down to the next one.  `state` carries the
+        cut activations and the gradient flowing into the current cut.  p.grad is WRITTEN (never accumulated)."""
+        nseg = len(self.seg_params)
+        if k == 0:
+            for p in self.params:
+                p.grad = None
+            self.model._seg_points = {} if nseg > 1 else None
+            with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
+                loss = soft_target_cross_entropy(self.model(self.x), self.t)
+            self.loss = loss.detach()
+            cuts = self.model._seg_points
+            self.model._seg_points = None
+            if nseg == 1:
+                loss.backward()
+                return None
+            outs, gouts = [loss], None
+        else:
+            cuts, outs, gouts = state["cuts"], [state["cut_act"]], [state["cut_grad"]]
+        ps = self.seg_params[k]
+        nxt = cuts[self.cut_stages[k]] if k < nseg - 1 else None          # activation entering this segment's first stage
+        ins = ([nxt] if nxt is not None else []) + ps
+        grads = torch.autograd.grad(outs, ins, grad_outputs=gouts, allow_unused=True)
+        gp = grads[1:] if nxt is not None else grads
+        with torch.no_grad():                       # pack for the all-reduce (multi-tensor copy); views become p.grad
+            pairs = [(self.views[p], g) for p, g in zip(ps, gp) if g is not None]
+            if pairs:
+                torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
+            for p, g in zip(ps, gp):
+                p.grad = self.views[p] if g is not None else None
+        return {"cuts": cuts, "cut_act": nxt, "cut_grad": grads[0]} if nxt is not None else None
 
-    def _allreduce(self):
+    def _allreduce(self, flats, async_op=False):
         # gloo (single-device tests) has no AVG; without a process group (unit test with the collective
         # stubbed) there is no backend to ask
         avg = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
-        for f in self.flats:
+        works = []
+        for f in flats:
             if avg:
-                dist.all_reduce(f, op=dist.ReduceOp.AVG)
+                w = dist.all_reduce(f, op=dist.ReduceOp.AVG, async_op=async_op)
             else:
-                dist.all_reduce(f)
+                w = dist.all_reduce(f, async_op=False)
                 f.div_(self.world)
+            if async_op and w is not None:
+                works.append(w)
+        return works
+
+    def comm_summary(self):
+        """Bytes all-reduced per step and segment, and the bytes whose all-reduce has no backward compute left to run
+        under (the last segment's)."""
+        seg = [sum(f.numel() * f.element_size() for f in fl) for fl in self.seg_flats]
+        return {"collective": "all-reduce (mean) of one flat gradient buffer per (backward segment, dtype)",
+                "segments_bytes": seg, "total_bytes": sum(seg), "exposed_bytes": seg[-1] if seg else 0,
+                "overlap": "segment k's all-reduce runs on the process group's stream under segment k+1's graph replay"}
 
     def _body(self, eager):
         """the same step launched op by op (warm-up, and the per-kernel profile of bench.py)"""
         self._draw_modes()
-        self._fwd_bwd()
-        if self.world > 1:
-            self._allreduce()
+        state = None
+        for k in range(len(self.seg_params)):
+            state = self._segment(k, state)
+            if self.world > 1:
+                self._allreduce(self.seg_flats[k])
         self.opt.step()
 
     def __call__(self, images, targets):
         self.x.copy_(images, non_blocking=True)
         self.t.copy_(targets, non_blocking=True)
         self._draw_modes()
-        self.graph.replay()
-        if self.opt_graph is not None:
-            self._allreduce()
-            self.opt_graph.replay()
+        if self.opt_graph is None:
+            self.graphs[0].replay()
+            return self.loss
+        works = []
+        for k, g in enumerate(self.graphs):
+            g.replay()
+            # asynchronous: the collective is ordered after this replay on the process group's stream and overlaps
+            # the next segment's replay on the compute stream
+            works += self._allreduce(self.seg_flats[k], async_op=True)
+        for w in works:
+            w.wait()                              # compute stream waits for the collectives (no host block with nccl)
+        self.opt_graph.replay()
         return self.loss

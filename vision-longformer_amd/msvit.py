@@ -405,6 +405,8 @@ class MsViT(nn.Module):
             tokens = False
             if i > 0:   # drop the previous stage's global tokens, back to an image
                 x = self._settle(x, pend)
+                if getattr(self, "_seg_points", None) is not None:
+                    self._seg_points[i] = x          # activation entering stage i: a backward-segment cut (engine.GraphedTrainStep)
                 x = x[:, self.Nglos[i - 1]:]
                 tokens = layer[0].tokens_ok(x, nx, ny)
                 if not tokens:
