@@ -430,8 +430,9 @@ def test_model_vil_tiny_vs_reference_logits(dev, golden_dir):
                 ref_s = torch.from_numpy(gold["gsample/" + n])
                 got_s = GC.model_grad_sample(p_.grad)
                 err = (got_s - ref_s).abs()
-                # (head.weight is heavy-tailed -- two target-class rows carry the norm -- hence the max-abs term)
-                lim = k * max(rms(ref_s), 1e-12) + rtol * ref_s.abs() + 0.1 * k * float(ref_s.abs().max())
+                # (head.weight is heavy-tailed: two target-class rows carry the norm, and an element of such a row is
+                # 0.5 * feature, whose bf16 LayerNorm error is absolute, ~4e-3 of an O(1) feature -- hence the max-abs term)
+                lim = k * max(rms(ref_s), 1e-12) + rtol * ref_s.abs() + k * float(ref_s.abs().max())
                 cos = float((got_s * ref_s).sum() / (got_s.norm() * ref_s.norm()).clamp_min(1e-30))
                 worst_r, worst_c = max(worst_r, float((err / lim).max())), min(worst_c, cos)
                 assert bool((err <= lim).all()), (tag, n, float(err.max()), rms(ref_s))

@@ -37,6 +37,17 @@ for STEP in "$@"; do
     pmc_*)
       SH=${STEP#pmc_}
       bash tools/pmc.sh $SH "$OUT/pmc_$SH" > "$OUT/pmc_$SH.txt" 2>&1; grep -A40 "k_mfma_fwd\|k_mfma_bwd" "$OUT/pmc_$SH.txt" | grep -- "--\|^k_" ;;
+    trafficab)      # isolated HBM traffic of the three MFMA kernels at one shape, for every A/B library
+      cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+      for LIB in $(ls tools/ab/*.so) ""; do
+        N=$(basename "${LIB:-HEAD}" .so)
+        for P in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+          D="$OUT/traffic_$N/p_${P%% *}"
+          VIL_ATTN_LIB=${LIB:+$PWD/$LIB} timeout 300 rocprofv3 --pmc $P --output-format csv -d "$D" -o pmc -- python tools/kernel_bench.py ${TRAFFIC_SHAPE:-small_s1} --reps 2 > "$D.log" 2>&1
+        done
+        echo "== $N" >> "$OUT/trafficab.txt"; python tools/pmc_summary.py "$OUT/traffic_$N" 2>/dev/null | grep -A3 "^k_mfma_fwd\|^k_mfma_bwd" | grep "^k_\|HBM" >> "$OUT/trafficab.txt"
+      done
+      cat "$OUT/trafficab.txt" ;;
     pmcstep)
       bash tools/pmc_step.sh "$OUT/pmcstep" > "$OUT/pmcstep.txt" 2>&1; tail -30 "$OUT/pmcstep.txt" ;;
     smoke)

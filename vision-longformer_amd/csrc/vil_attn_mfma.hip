@@ -381,7 +381,10 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   c.wpw = 4;
   while (c.wpw > 1 && (size_t)c.tabsize * 8 + (size_t)c.wpw * c.wave_lds > 160 * 1024) c.wpw >>= 1;
   const int groups = (c.units_bh + c.wpw - 1) / c.wpw;
-  int gpw = (int)(((int64_t)d->B * d->H * groups) / 2048);
+#ifndef VIL_FWD_WGS
+#define VIL_FWD_WGS 2048   // target workgroup count: a workgroup walks gpw groups of chunks one after the other
+#endif
+  int gpw = (int)(((int64_t)d->B * d->H * groups) / VIL_FWD_WGS);
   if (gpw < 1) gpw = 1;
   if (gpw > groups) gpw = groups;
   c.gpw = gpw;

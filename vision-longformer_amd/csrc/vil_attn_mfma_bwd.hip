@@ -989,7 +989,10 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   bc.kv_wpw = 4;
   while (bc.kv_wpw > 1 && (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
   const int groups = (bc.units_kv_bh + bc.kv_wpw - 1) / bc.kv_wpw;
-  int gpw = (int)(((int64_t)d->B * d->H * groups) / 2048);
+#ifndef VIL_KV_WGS
+#define VIL_KV_WGS 2048
+#endif
+  int gpw = (int)(((int64_t)d->B * d->H * groups) / VIL_KV_WGS);
   if (gpw < 1) gpw = 1;
   if (gpw > groups) gpw = groups;
   bc.kv_gpw = gpw;
@@ -1003,7 +1006,10 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   while (bc.dq_wpw > 1 && (size_t)c.tabsize * 8 + (size_t)bc.dq_wpw * bc.dq_wave_lds > 160 * 1024) bc.dq_wpw >>= 1;
   {
     const int dgroups = (bc.dq_units_bh + bc.dq_wpw - 1) / bc.dq_wpw;
-    int dgpw = (int)(((int64_t)d->B * d->H * dgroups) / 4096);
+#ifndef VIL_DQ_WGS
+#define VIL_DQ_WGS 4096
+#endif
+    int dgpw = (int)(((int64_t)d->B * d->H * dgroups) / VIL_DQ_WGS);
     if (dgpw < 1) dgpw = 1;
     if (dgpw > dgroups) dgpw = dgroups;
     bc.dq_gpw = dgpw;
