@@ -42,7 +42,7 @@ for STEP in "$@"; do
       for LIB in $(ls tools/ab/*.so) ""; do
         N=$(basename "${LIB:-HEAD}" .so)
         for P in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
-          D="$OUT/traffic_$N/p_${P%% *}"
+          D="$OUT/traffic_$N/p_${P%% *}"; mkdir -p "$OUT/traffic_$N"
           VIL_ATTN_LIB=${LIB:+$PWD/$LIB} timeout 300 rocprofv3 --pmc $P --output-format csv -d "$D" -o pmc -- python tools/kernel_bench.py ${TRAFFIC_SHAPE:-small_s1} --reps 2 > "$D.log" 2>&1
         done
         echo "== $N" >> "$OUT/trafficab.txt"; python tools/pmc_summary.py "$OUT/traffic_$N" 2>/dev/null | grep -A3 "^k_mfma_fwd\|^k_mfma_bwd" | grep "^k_\|HBM" >> "$OUT/trafficab.txt"

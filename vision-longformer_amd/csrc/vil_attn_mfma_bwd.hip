@@ -990,7 +990,7 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   while (bc.kv_wpw > 1 && (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
   const int groups = (bc.units_kv_bh + bc.kv_wpw - 1) / bc.kv_wpw;
 #ifndef VIL_KV_WGS
-#define VIL_KV_WGS 2048
+#define VIL_KV_WGS 8192
 #endif
   int gpw = (int)(((int64_t)d->B * d->H * groups) / VIL_KV_WGS);
   if (gpw < 1) gpw = 1;
