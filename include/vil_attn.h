@@ -19,8 +19,10 @@
  *
  * Conventions: plain pointers and sizes only; all device buffers (inputs,
  * outputs, workspace) are caller-owned; calls are asynchronous on `stream`
- * (a hipStream_t passed as void*), never allocate, never synchronise, keep no
- * global mutable state.  Return value: 0 = success, negative = argument error
+ * (a hipStream_t passed as void*), never allocate device memory and never
+ * synchronise -- the two documented exceptions synchronise by design:
+ * vil_gemm_tune and vil_attn_profile_end.  Process-global state: the
+ * profiling sink and the GEMM plan cache (both described at their entry points).  Return value: 0 = success, negative = argument error
  * (VIL_E_*), positive = hipError_t of the failing launch.
  *
  * Tensor layout: q is addressed as q[b*q_sb + i*q_st + h*q_sh + d] with
@@ -235,8 +237,11 @@ int vil_resln_bwd(const void* dy, int dy_dtype, const float* gres, const float* 
                   float* dx, void* gbranch, int gb_dtype, float* dgamma, float* dbeta, void* workspace,
                   int64_t rows, int C, void* stream);
 
-/* ---- the plain library GEMMs of the projections (hipBLASLt, algorithm selected by measurement per problem on first
- * use outside stream capture; reference call sites: every nn.Linear of msvit.py / longformer2d.py).
+/* ---- the plain library GEMMs of the projections (hipBLASLt; reference call sites: every nn.Linear of msvit.py /
+ * longformer2d.py).  vil_gemm_bf16 launches asynchronously and never synchronises; the algorithm it runs is the one
+ * vil_gemm_tune selected for that problem (same arguments; times the heuristic's candidates on the caller's operands,
+ * SYNCHRONISES, must be called outside stream capture, idempotent) or the heuristic's first choice when the problem
+ * was never tuned.  The plan cache (problem -> descriptors + algorithm) is process-global, mutex-guarded state.
  *   op 0: out[T][N] = in[T][K] * w[N][K]^T (+ bias[N])      (forward;  w = nn.Linear.weight)
  *   op 1: out[T][N] = in[T][K] * w[K][N]                    (input gradient: in = dY, w = nn.Linear.weight)
  *   op 2: out[N][K] = w[T][N]^T * in[T][K], bias[N] = colsum(w)  (weight / bias gradient: in = x, w = dY,
@@ -244,6 +249,8 @@ int vil_resln_bwd(const void* dy, int dy_dtype, const float* gres, const float* 
  * bf16 operands, fp32 accumulate; row strides in elements (multiples of 8); workspace of vil_gemm_workspace_bytes(). */
 size_t vil_gemm_workspace_bytes(void);
 int vil_gemm_bf16(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
+                  int64_t in_row_stride, int64_t out_row_stride, void* workspace, size_t workspace_bytes, void* stream);
+int vil_gemm_tune(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
                   int64_t in_row_stride, int64_t out_row_stride, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus

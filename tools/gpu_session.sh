@@ -50,6 +50,8 @@ for STEP in "$@"; do
       cat "$OUT/trafficab.txt" ;;
     pmcstep)
       bash tools/pmc_step.sh "$OUT/pmcstep" > "$OUT/pmcstep.txt" 2>&1; tail -30 "$OUT/pmcstep.txt" ;;
+    opbench)
+      timeout 900 python tools/op_benchmark.py > "$OUT/op_benchmark.jsonl" 2> "$OUT/op_benchmark.err"; cat "$OUT/op_benchmark.jsonl" ;;
     smoke)
       python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" ;;
     *) echo "unknown step $STEP" ;;

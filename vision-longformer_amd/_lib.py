@@ -26,7 +26,7 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_glo_attn_fwd", "vil_glo_attn_bwd", "vil_attn_bwd_full",
            "vil_colsum_workspace_bytes", "vil_colsum_bf16", "vil_colsum_f32",
            "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad",
-           "vil_resln_fwd", "vil_resln_bwd", "vil_gemm_workspace_bytes", "vil_gemm_bf16",
+           "vil_resln_fwd", "vil_resln_bwd", "vil_gemm_workspace_bytes", "vil_gemm_bf16", "vil_gemm_tune",
            "vil_sc2d_qk", "vil_sc2d_av", "vil_sc2d_agrad", "vil_sc2d_mask")
 
 
@@ -121,6 +121,9 @@ def lib():
                 fn.argtypes = [vp, vp, vp] + [ci] * 7 + [vp]
             L.vil_sc2d_mask.restype = ci
             L.vil_sc2d_mask.argtypes = [vp] + [ci] * 9 + [vp, vp]
+        if hasattr(L, "vil_gemm_tune"):
+            L.vil_gemm_tune.restype = ctypes.c_int
+            L.vil_gemm_tune.argtypes = L.vil_gemm_bf16.argtypes
         L.vil_layernorm_workspace_bytes.restype = ctypes.c_size_t
         L.vil_layernorm_workspace_bytes.argtypes = [i64, ctypes.c_int]
         L.vil_layernorm_fwd.restype = ctypes.c_int

@@ -183,6 +183,24 @@ extern "C" int vil_geom_bias_index(int W, int mode, int32_t* rel) {
   return kv;
 }
 
+// ------------------------------------------------------------ dynamic-LDS limits
+#include <map>
+#include <mutex>
+int vil_ensure_dyn_lds(const void* kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return 0;
+  static std::map<std::pair<int, const void*>, size_t> done;
+  static std::mutex mu;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = done[std::make_pair(dev, kernel)];
+  if (have >= bytes) return 0;
+  hipError_t he = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (he != hipSuccess) return (int)he;
+  have = bytes;
+  return 0;
+}
+
 // ------------------------------------------------------------ profiling sink
 // Process-global and not thread-safe by design: a measurement aid for bench.py, the
 // only state the library keeps.  Events are created once and reused.

@@ -108,12 +108,13 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   int* s_akey = s_koff + c.NSP;                    // [NSP] bias-table address term (bytes)
   char* s_v = (char*)(s_akey + c.NSP);             // [32][M] bf16 V tile of the current step
 
-  const __amdgpu_buffer_rsrc_t krs = make_rsrc((const __bf16*)p.k + b * p.k_sb + h * p.k_sh);
-  const __amdgpu_buffer_rsrc_t vrs = make_rsrc((const __bf16*)p.v + b * p.v_sb + h * p.v_sh);
-  const __bf16* qb = (const __bf16*)p.q + b * p.q_sb + h * p.q_sh;
-  __bf16* ob = (__bf16*)p.o + b * p.o_sb + h * p.o_sh;
   const int Nloc = g.nx * g.ny;
   const int kstride_b = (int)p.k_st * 2;
+  const unsigned kv_bytes = (unsigned)(p.G + Nloc - 1) * (unsigned)kstride_b + M * 2;    // K / V rows of this (image, head)
+  const __amdgpu_buffer_rsrc_t krs = make_rsrc_n((const __bf16*)p.k + b * p.k_sb + h * p.k_sh, kv_bytes);
+  const __amdgpu_buffer_rsrc_t vrs = make_rsrc_n((const __bf16*)p.v + b * p.v_sb + h * p.v_sh, kv_bytes);
+  const __bf16* qb = (const __bf16*)p.q + b * p.q_sb + h * p.q_sh;
+  __bf16* ob = (__bf16*)p.o + b * p.o_sb + h * p.o_sh;
   const float c1 = p.scale * LOG2E;               // scores are kept unscaled: s*c1 is log2-domain
   const float thr = 8.0f / p.scale;               // deferred-max threshold (8 nats)
   const int W = g.W;
@@ -403,7 +404,6 @@ int vil_mfma_supported(const VilAttnDesc* d, int pass) {
   if (d->dtype != VIL_DTYPE_BF16) return VIL_E_DTYPE;
   if (d->M != 16 && d->M != 32 && d->M != 48 && d->M != 64) return VIL_E_HEAD_DIM;
   if (d->W < 1 || d->W > 32) return VIL_E_WINDOW;
-  if (d->exact == -1 || d->only_glo) return VIL_E_BACKEND;   // cyclic padding / only-global: scalar family
   if (d->G > 16) return VIL_E_BACKEND;
   // 16-byte row loads: token/batch/head strides and M must keep rows 16-byte aligned
   if ((d->q_st | d->k_st | d->v_st | d->q_sb | d->k_sb | d->v_sb | d->q_sh | d->k_sh | d->v_sh) & 7) return VIL_E_ALIGN;
@@ -440,11 +440,7 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   const size_t lds = mfma_lds_bytes(c);
 #define LAUNCH_FWD(MD_)                                                                              \
   {                                                                                                  \
-    if (lds > 64 * 1024) {                                                                           \
-      hipError_t he = hipFuncSetAttribute((const void*)k_mfma_fwd<MD_>,                               \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-      if (he != hipSuccess) return (int)he;                                                          \
-    }                                                                                                \
+    if (int he = vil_ensure_dyn_lds((const void*)k_mfma_fwd<MD_>, lds)) return he;                    \
     k_mfma_fwd<MD_><<<dim3(grid), dim3(64 * c.wpw), lds, s>>>(p, c);                                 \
   }
   switch (d->M) {

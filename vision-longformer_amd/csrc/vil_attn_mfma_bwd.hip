@@ -115,12 +115,13 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
   char* s_k = (char*)(s_akey + c.NSP);              // [32][M] bf16 K tile of the current step
 
   const __bf16* qb = (const __bf16*)p.q + b * p.q_sb + h * p.q_sh;
-  const __amdgpu_buffer_rsrc_t krs = make_rsrc((const __bf16*)p.k + b * p.k_sb + h * p.k_sh);
-  const __amdgpu_buffer_rsrc_t vrs = make_rsrc((const __bf16*)p.v + b * p.v_sb + h * p.v_sh);
-  const __bf16* dob = (const __bf16*)p.dout + b * p.do_sb + h * p.do_sh;
-  __bf16* dqb = (__bf16*)p.dq + b * p.dq_sb + h * p.dq_sh;
   const int Nloc = g.nx * g.ny;
   const int kstride_b = (int)p.k_st * 2;
+  const unsigned kv_bytes = (unsigned)(p.G + Nloc - 1) * (unsigned)kstride_b + M * 2;    // (zero keys of cyclic padding: vil_mfma_common.h)
+  const __amdgpu_buffer_rsrc_t krs = make_rsrc_n((const __bf16*)p.k + b * p.k_sb + h * p.k_sh, kv_bytes);
+  const __amdgpu_buffer_rsrc_t vrs = make_rsrc_n((const __bf16*)p.v + b * p.v_sb + h * p.v_sh, kv_bytes);
+  const __bf16* dob = (const __bf16*)p.dout + b * p.do_sb + h * p.do_sh;
+  __bf16* dqb = (__bf16*)p.dq + b * p.dq_sb + h * p.dq_sh;
   const float c1 = p.scale * LOG2E;
   const int W = g.W;
 
@@ -512,6 +513,10 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     int nchunks;
     if (glo) {
       nchunks = (bc.nch - split + bc.nsplit - 1) / bc.nsplit;
+    } else if (p.only_glo) {
+      nchunks = 0;                                   // local keys are attended by nobody
+    } else if (g.exact == -1) {
+      nchunks = g.nact;                              // cyclic: every neighbour offset reaches a chunk (by wrap-around)
     } else {
       nchunks = 0;
       for (int a = 0; a < g.nact; ++a) {
@@ -532,8 +537,13 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           const int a3 = (a * 11) >> 5;
           const int ar = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : adr1);
           const int ac = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : adc1);
-          const int m_ = km - ar, n_ = kn - ac;
-          const bool ok = m_ >= 0 && m_ < g.mx && n_ >= 0 && n_ < g.my;
+          int m_ = km - ar, n_ = kn - ac;
+          bool ok = m_ >= 0 && m_ < g.mx && n_ >= 0 && n_ < g.my;
+          if (g.exact == -1) {                     // cyclic: the query chunk that reaches this key chunk through (ar, ac)
+            m_ = m_ < 0 ? m_ + g.mx : (m_ >= g.mx ? m_ - g.mx : m_);
+            n_ = n_ < 0 ? n_ + g.my : (n_ >= g.my ? n_ - g.my : n_);
+            ok = true;
+          }
           if (ok && cnt == ci) { qm = m_; qn = n_; dr = ar; dc = ac; }
           cnt += ok;
         }
@@ -1102,11 +1112,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     const size_t lds = dq_lds(c, bc);
     vil_prof_begin(VIL_K_MFMA_DQ, s, w.dq_bytes(), w.dq_flops());
     BWD_SWITCH({
-      if (lds > 64 * 1024) {
-        hipError_t he = hipFuncSetAttribute((const void*)k_mfma_bwd_dq<MD_, (MD_ >= 2 ? 2 : 4)>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (he != hipSuccess) return (int)he;
-      }
+      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dq<MD_, (MD_ >= 2 ? 2 : 4)>, lds)) return he;
       k_mfma_bwd_dq<MD_, (MD_ >= 2 ? 2 : 4)><<<dim3((unsigned)bc.dq_nwg), dim3(64 * bc.dq_wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);
@@ -1117,11 +1123,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     const unsigned grid = (unsigned)(p.B * p.H * bc.kv_wg_per_bh);
     vil_prof_begin(VIL_K_MFMA_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
     BWD_SWITCH({
-      if (lds > 64 * 1024) {
-        hipError_t he = hipFuncSetAttribute((const void*)k_mfma_bwd_dkdv<MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (he != hipSuccess) return (int)he;
-      }
+      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dkdv<MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))>, lds)) return he;
       k_mfma_bwd_dkdv<MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);

@@ -3,9 +3,12 @@
 // stay on hipBLASLt"; reference call sites: every nn.Linear of msvit.py / longformer2d.py.)
 // hipblasLtMatmulAlgoGetHeuristic returns a ranked list; its first entry (what a framework call gets) loses
 // 5-25 % against the best of the top 16 on this model's skinny shapes (tools/ubench/hipblaslt_algos.cpp), and the
-// framework's own dispatch was another 10-50 % behind on several of them.  First use of a problem (outside stream
-// capture): time the candidates on the caller's operands with hipEvents, cache the winner; later calls (and calls
-// that arrive during capture before a problem was tuned) just launch.
+// framework's own dispatch was another 10-50 % behind on several of them.  Selection is an EXPLICIT call,
+// vil_gemm_tune: it times the candidates on scratch operands with hipEvents (it synchronises -- call it outside
+// stream capture, once per problem) and caches the winner; vil_gemm_bf16 itself only launches (asynchronous, never
+// synchronises; an untuned problem runs the heuristic's first choice).
+// State: the plan cache below (problem -> descriptors + selected algorithm) is process-global and mutex-guarded; it
+// is the library's only mutable state besides the profiling sink of vil_attn_api.hip.
 #include "vil_internal.h"
 #include <hipblaslt/hipblaslt.h>
 #include <map>
@@ -83,54 +86,89 @@ int make_plan(Plan& pl, int op, int64_t T, int K, int N, int64_t in_rs, int64_t 
 
 extern "C" size_t vil_gemm_workspace_bytes(void) { return (size_t)32 << 20; }
 
+static int get_plan(Plan*& out, int op, int64_t T, int K, int N, int64_t in_rs, int64_t out_rs, bool bias, size_t wsz) {
+  if (!g_handle && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return VIL_E_BACKEND;
+  const Key key(op, T, K, N, in_rs, out_rs, bias ? 1 : 0);
+  Plan& pl = g_plans[key];
+  if (!pl.valid && make_plan(pl, op, T, K, N, in_rs, out_rs, bias, wsz)) return VIL_E_BACKEND;
+  out = &pl;
+  return VIL_OK;
+}
+
+static hipblasStatus_t run_plan(Plan& pl, const hipblasLtMatmulAlgo_t& a, int op, const void* in, const void* w, void* out,
+                                void* workspace, size_t workspace_bytes, hipStream_t s) {
+  const float alpha = 1.f, beta = 0.f;
+  if (op == 2)      // A = x (`in`), B = dY (`w`)
+    return hipblasLtMatmul(g_handle, pl.md, &alpha, in, pl.la, w, pl.lb, &beta, out, pl.lc, out, pl.lc, &a, workspace,
+                           workspace_bytes, s);
+  return hipblasLtMatmul(g_handle, pl.md, &alpha, w, pl.la, in, pl.lb, &beta, out, pl.lc, out, pl.lc, &a, workspace,
+                         workspace_bytes, s);
+}
+
+static int check_gemm_args(int op, const void* in, const void* w, const void* bias, const void* out, int64_t T, int K, int N,
+                           int64_t in_rs, int64_t out_rs, const void* workspace) {
+  if (!in || !w || !out || !workspace) return VIL_E_NULL;
+  if (T <= 0 || K <= 0 || N <= 0 || op < 0 || op > 2 || (op == 1 && bias)) return VIL_E_SHAPE;
+  if ((K & 7) || (N & 7) || (in_rs & 7) || (out_rs & 7) ||
+      (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out | (uintptr_t)workspace) & 15)) return VIL_E_ALIGN;
+  return VIL_OK;
+}
+
+// Selects the algorithm of one problem by measurement on the caller's operands (`out` is overwritten with the
+// product, exactly as vil_gemm_bf16 would).  SYNCHRONISES the stream; returns VIL_E_BACKEND during stream capture.
+// Idempotent: a problem that is already tuned returns at once.
+extern "C" int vil_gemm_tune(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
+                             int64_t in_row_stride, int64_t out_row_stride, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  int e = check_gemm_args(op, in, w, bias, out, T, K, N, in_row_stride, out_row_stride, workspace);
+  if (e) return e;
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cs);
+  if (cs != hipStreamCaptureStatusNone) return VIL_E_BACKEND;
+  std::lock_guard<std::mutex> lock(g_mu);
+  Plan* plp = nullptr;
+  if ((e = get_plan(plp, op, T, K, N, in_row_stride, out_row_stride, bias != nullptr, workspace_bytes))) return e;
+  Plan& pl = *plp;
+  if (pl.tuned) return VIL_OK;
+  if (bias) hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+  if (pl.cand.size() > 1) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (const auto& c : pl.cand) {
+      if (run_plan(pl, c.algo, op, in, w, out, workspace, workspace_bytes, s) != HIPBLAS_STATUS_SUCCESS) continue;   // warm-up / validity
+      (void)hipEventRecord(e0, s);
+      bool ok = true;
+      for (int r = 0; r < 4 && ok; ++r) ok = run_plan(pl, c.algo, op, in, w, out, workspace, workspace_bytes, s) == HIPBLAS_STATUS_SUCCESS;
+      (void)hipEventRecord(e1, s);
+      if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (ms < best) { best = ms; pl.algo = c.algo; pl.ws = c.workspaceSize; }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  pl.tuned = true;
+  return VIL_OK;
+}
+
 // op 0: out[T][N] = in[T][K] * w[N][K]^T (+ bias[N]);   op 1: out[T][N] = in[T][K] * w[K][N]   (w row-major)
 // op 2: out[N][K] = w[T][N]^T * in[T][K]  (weight gradient: in = x, w = dY, `out_row_stride` = row stride of dY),
 //       bias != NULL: bias[N] = column sums of dY (bias gradient, written by the GEMM's epilogue)
 // bf16 everywhere, fp32 accumulate; row strides in elements (multiples of 8), 16-byte aligned bases.
+// Asynchronous on `stream`, never synchronises; runs the algorithm vil_gemm_tune selected for this problem, or the
+// heuristic's first choice when the problem was never tuned.
 extern "C" int vil_gemm_bf16(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
                              int64_t in_row_stride, int64_t out_row_stride, void* workspace, size_t workspace_bytes,
                              void* stream) {
-  if (!in || !w || !out || !workspace) return VIL_E_NULL;
-  if (T <= 0 || K <= 0 || N <= 0 || op < 0 || op > 2 || (op == 1 && bias)) return VIL_E_SHAPE;
-  if ((K & 7) || (N & 7) || (in_row_stride & 7) || (out_row_stride & 7) ||
-      (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out | (uintptr_t)workspace) & 15)) return VIL_E_ALIGN;
+  int e = check_gemm_args(op, in, w, bias, out, T, K, N, in_row_stride, out_row_stride, workspace);
+  if (e) return e;
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lock(g_mu);
-  if (!g_handle && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return VIL_E_BACKEND;
-  const Key key(op, T, K, N, in_row_stride, out_row_stride, bias ? 1 : 0);
-  Plan& pl = g_plans[key];
-  if (!pl.valid && make_plan(pl, op, T, K, N, in_row_stride, out_row_stride, bias != nullptr, workspace_bytes))
-    return VIL_E_BACKEND;
+  Plan* plp = nullptr;
+  if ((e = get_plan(plp, op, T, K, N, in_row_stride, out_row_stride, bias != nullptr, workspace_bytes))) return e;
+  Plan& pl = *plp;
   if (bias) hipblasLtMatmulDescSetAttribute(pl.md, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
-  const float alpha = 1.f, beta = 0.f;
-  auto run = [&](const hipblasLtMatmulAlgo_t& a) {
-    if (op == 2)      // A = x (`in`), B = dY (`w`)
-      return hipblasLtMatmul(g_handle, pl.md, &alpha, in, pl.la, w, pl.lb, &beta, out, pl.lc, out, pl.lc, &a, workspace,
-                             workspace_bytes, s);
-    return hipblasLtMatmul(g_handle, pl.md, &alpha, w, pl.la, in, pl.lb, &beta, out, pl.lc, out, pl.lc, &a, workspace,
-                           workspace_bytes, s);
-  };
-  if (!pl.tuned) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(s, &cs);
-    if (cs == hipStreamCaptureStatusNone && pl.cand.size() > 1) {
-      hipEvent_t e0, e1;
-      (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-      float best = 1e30f;
-      for (const auto& c : pl.cand) {
-        if (run(c.algo) != HIPBLAS_STATUS_SUCCESS) continue;                      // warm-up / validity
-        (void)hipEventRecord(e0, s);
-        bool ok = true;
-        for (int r = 0; r < 4 && ok; ++r) ok = run(c.algo) == HIPBLAS_STATUS_SUCCESS;
-        (void)hipEventRecord(e1, s);
-        if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best) { best = ms; pl.algo = c.algo; pl.ws = c.workspaceSize; }
-      }
-      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-      pl.tuned = true;
-    }
-  }
-  return run(pl.algo) == HIPBLAS_STATUS_SUCCESS ? VIL_OK : VIL_E_BACKEND;
+  return run_plan(pl, pl.algo, op, in, w, out, workspace, workspace_bytes, s) == HIPBLAS_STATUS_SUCCESS ? VIL_OK : VIL_E_BACKEND;
 }

@@ -78,6 +78,10 @@ static inline void vil_prof_tag_desc(const VilAttnDesc* d) {
   vil_prof_tag(d->B, d->H, d->M, d->nx, d->ny, d->W, d->G, d->mode_dev ? 9 : d->mode);
 }
 
+// Raises a kernel's dynamic-LDS limit above 64 KB once per (device, kernel, size) instead of on every launch
+// (hipFuncSetAttribute is a driver call; the remembered maxima are an idempotent process-global cache).
+int vil_ensure_dyn_lds(const void* kernel, size_t bytes);
+
 // algorithmic (minimum) HBM bytes / flops of one launch over the whole batch; SURVEY.md 8(d)
 struct VilWork {
   double nloc, n, c, e, k, h, b, tbl;

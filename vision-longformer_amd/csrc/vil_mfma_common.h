@@ -75,6 +75,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, 0x7fffffff, 0x00020000);
 }
+// bounded descriptor: loads at byte offsets >= nbytes return zeros.  The K / V descriptors of one (image, head) slice
+// are bounded so that the ZERO keys of cyclic padding (exact = -1: a zero-padded position reached by wrap-around stays
+// in the softmax with k = v = 0, reference slidingchunk_2d.py:249-267) are ordinary key slots whose row offset is
+// VIL_ZERO_OFF -- no branch and no zero row in memory.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_n(const void* p, unsigned nbytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, (int)nbytes, 0x00020000);
+}
+#define VIL_ZERO_OFF 0x7fff0000
 __device__ __forceinline__ bf16x8 buf_load8(__amdgpu_buffer_rsrc_t r, int byte_off) {
   return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
@@ -108,27 +116,49 @@ __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg
                                                int row_stride_b, int* s_koff, int* s_akey, int adr1, int adc1) {
   const VilGeom& g = p.g;
   const int W = g.W;
+  const bool cyc = g.exact == -1;
   for (int s = lane; s < p.G; s += 64) {
     s_koff[s] = __mul24(s, row_stride_b); s_akey[s] = -(c.glo0 + s * c.gsz) * 4;
   }
-  const int nrows = g.nact * W;
+  const int nrows = p.only_glo ? 0 : g.nact * W;             // only_glo: the G global keys are the whole key set
   int base = p.G;                                            // wave-uniform running slot offset
   for (int r0 = 0; r0 < nrows; r0 += 64) {
     const int rid = r0 + lane;
-    int nvalid = 0, off = 0, ak = 0;
+    // a neighbourhood row contributes na slots of one kind (real tokens, or -- cyclic padding only -- zero keys),
+    // then nb zero-key slots (cyclic: its columns beyond the image, unless this neighbour is reached without wrap)
+    int na = 0, nb = 0, off = 0, ak = 0;
+    bool real = true;
     if (rid < nrows) {
       const int a = fdiv(rid, c.magicW), xt = rid - a * W;
       const int a3 = (a * 11) >> 5;                           // a / 3 for a in [0, 9)
       const int dr = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : adr1);
       const int dc = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : adc1);
-      const int rm = cm + dr, rn = cn + dc, kr = rm * W + xt;
-      if (rm >= 0 && rm < g.mx && rn >= 0 && rn < g.my && kr < g.nx) {
-        const int kc0 = rn * W;
-        nvalid = min(W, g.ny - kc0);
-        off = __mul24(p.G + kr * g.ny + kc0, row_stride_b);
-        ak = ((dr * W + xt) * c.P + dc * W - c.aconst) * 4;
+      int rm = cm + dr, rn = cn + dc;
+      ak = ((dr * W + xt) * c.P + dc * W - c.aconst) * 4;
+      if (!cyc) {
+        const int kr = rm * W + xt;
+        if (rm >= 0 && rm < g.mx && rn >= 0 && rn < g.my && kr < g.nx) {
+          const int kc0 = rn * W;
+          na = min(W, g.ny - kc0);
+          off = __mul24(p.G + kr * g.ny + kc0, row_stride_b);
+        }
+      } else {
+        // reference _get_invalid_locations_mask_cyclic: a padded row / column is masked only when its chunk is the
+        // last one reached WITHOUT wrap-around (cm + dr + 1 == mx); reached by wrap it is a zero key
+        const bool last_r = rm + 1 == g.mx, last_c = rn + 1 == g.my;
+        rm = rm < 0 ? rm + g.mx : (rm >= g.mx ? rm - g.mx : rm);
+        rn = rn < 0 ? rn + g.my : (rn >= g.my ? rn - g.my : rn);
+        const int kr = rm * W + xt, kc0 = rn * W;
+        const bool row_pad = kr >= g.nx;
+        if (!(row_pad && last_r)) {
+          na = min(W, max(g.ny - kc0, 0));
+          nb = last_c ? 0 : W - na;
+          real = !row_pad;
+          off = real ? __mul24(p.G + kr * g.ny + kc0, row_stride_b) : VIL_ZERO_OFF;
+        }
       }
     }
+    const int nvalid = na + nb;
     int incl = nvalid;                                        // inclusive prefix sum over the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -136,9 +166,13 @@ __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg
       if (lane >= o) incl += t;
     }
     int s = base + incl - nvalid;
-    for (int yt = 0; yt < nvalid; ++yt) {
+    for (int yt = 0; yt < na; ++yt) {
       s_koff[s] = off; s_akey[s] = ak;
-      ++s; off += row_stride_b; ak += 4;
+      ++s; off += real ? row_stride_b : 0; ak += 4;
+    }
+    for (int yt = 0; yt < nb; ++yt) {
+      s_koff[s] = VIL_ZERO_OFF; s_akey[s] = ak;
+      ++s; ak += 4;
     }
     base += __shfl(incl, 63, 64);
   }

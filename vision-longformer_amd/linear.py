@@ -80,6 +80,7 @@ def _wgrad(dy2, x2, want_db):
 
 
 _GEMM_WS = {}
+_GEMM_TUNED = set()
 
 
 def _gemm(op, inp2, w, bias):
@@ -100,9 +101,16 @@ def _gemm(op, inp2, w, bias):
         ws = _GEMM_WS[inp2.device] = torch.empty(L.vil_gemm_workspace_bytes(), dtype=torch.uint8, device=inp2.device)
     out = torch.empty(T, N, dtype=torch.bfloat16, device=inp2.device)
     vp = ctypes.c_void_p
-    rc = L.vil_gemm_bf16(op, vp(inp2.data_ptr()), vp(w.data_ptr()), vp(bias.data_ptr()) if bias is not None else None,
-                         vp(out.data_ptr()), T, K, N, inp2.stride(0), N, vp(ws.data_ptr()), ws.numel(),
-                         vp(torch.cuda.current_stream(inp2.device).cuda_stream))
+    args = (op, vp(inp2.data_ptr()), vp(w.data_ptr()), vp(bias.data_ptr()) if bias is not None else None,
+            vp(out.data_ptr()), T, K, N, inp2.stride(0), N, vp(ws.data_ptr()), ws.numel(),
+            vp(torch.cuda.current_stream(inp2.device).cuda_stream))
+    key = (inp2.device, op, T, K, N, inp2.stride(0), bias is not None)
+    if key not in _GEMM_TUNED and hasattr(L, "vil_gemm_tune") and not torch.cuda.is_current_stream_capturing():
+        # explicit, one-off algorithm selection per problem (synchronises; never inside a captured region):
+        # the launch call itself stays asynchronous
+        _GEMM_TUNED.add(key)
+        L.vil_gemm_tune(*args)
+    rc = L.vil_gemm_bf16(*args)
     if rc == _lib.VIL_E_BACKEND:
         return None
     _lib.check(rc)

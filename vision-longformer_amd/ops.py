@@ -59,9 +59,22 @@ def _make_desc(q, k, v, out, cfg, backend):
     return d
 
 
+_WS = {}
+
+
 def _workspace(d, pass_, device):
-    n = _lib.lib().vil_attn_workspace_bytes(ctypes.byref(d), pass_)
-    return torch.empty(max(int(n), 4) // 4 + 1, dtype=torch.float32, device=device)
+    """Scratch of one library call.  The library uses it only between the call's own launches, and launches on one
+    stream are ordered, so ONE buffer per (device, stream) is reused by every call on that stream (grown on demand)
+    instead of a torch.empty per call (host cost in the eager step).  During stream capture a fresh allocation is
+    taken from the graph's private pool, as before."""
+    n = max(int(_lib.lib().vil_attn_workspace_bytes(ctypes.byref(d), pass_)), 4) // 4 + 1
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(n, dtype=torch.float32, device=device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _WS[key] = torch.empty(int(n * 1.25) + 1024, dtype=torch.float32, device=device)
+    return ws
 
 
 class _VilLocalAttention(torch.autograd.Function):
