@@ -103,7 +103,7 @@ def compare(tag, got, ref, tols):
         assert a is not None, f"{tag}: {k} missing"
         assert torch.isfinite(a).all(), f"{tag}: {k} has non-finite values"
         if tol[0] == "rms":
-            atol, rtol = tol[1] * max(rms(b), 1e-6), tol[2]
+            atol, rtol = tol[1] * max(rms(b), 1e-4), tol[2]      # (floor: an identically-zero reference, e.g. dq of only_glo)
         else:
             atol, rtol = tol
         err = (a - b).abs()
