@@ -71,7 +71,7 @@ typedef struct VilAttnDesc {
   int32_t G;                /* number of global tokens = leading rows of k/v             */
   int32_t mode;             /* 0: 3x3 chunks, -1: own chunk, 1..8: own + one neighbour   */
   int32_t exact;            /* 0 zero-pad chunks, -1 cyclic chunks, 1 exact window       */
-  int32_t dtype;            /* VIL_DTYPE_* of q/k/v/out/dout/dq/dk/dv                    */
+  int32_t dtype;            /* VIL_DTYPE_F32 / _BF16 / _F16 of q/k/v/out/dout/dq/dk/dv    */
   int32_t only_glo;         /* local rows attend the global tokens only                  */
   int32_t backend;          /* VIL_BACKEND_*                                             */
   float   scale;            /* softmax scale; scores = scale*q.k + bias                  */

@@ -586,3 +586,61 @@ def test_reference_test_protocol(dev, exact_sliding):
                 assert torch.allclose(a, b, atol=1e-4, rtol=1e-3), f"{tag} {nm} it={it}: {(a - b).abs().max().item():.3e}"
         report(f"ok   reference test protocol exact={exact_sliding} it={it}: operator |dc| {(c1 - c2).abs().max().item():.2e}, "
                f"fused |dc| {(c3h - c2).abs().max().item():.2e}")
+
+
+# ---------------------------------------------------------------- fp16 I/O: the reference's actual AMP dtype
+F16_CASES = [c for c in SMALL if c["M"] in (16, 32, 48, 64)][::2] + [case(3, 32, 7, 56, 56, 1, B=1), case(3, 64, 7, 28, 28, 1, B=1)]
+
+
+@pytest.mark.parametrize("backend", ["mfma", "scalar"])
+@pytest.mark.parametrize("c", F16_CASES, ids=cid)
+def test_f16_vs_oracle(c, backend, dev):
+    """float16 q / kv / dout (the reference trains under fp16 autocast + GradScaler, src/engine.py:84): both kernel
+    families against the fp64 oracle on the same fp16-rounded inputs; output bound = the reference's own fp16
+    tolerance (src/tests/test_slidingchunk_2d.py:167-175: atol 2e-2 / rtol 1e-1), gradients rms-relative as for bf16
+    (fp16 has 3 more mantissa bits than bf16, so the bf16 bounds hold with margin)."""
+    inp = make_inputs(c, torch.float16)
+    ref = run_oracle(c, *inp)
+    got = run_hip(c, *inp, torch.float16, backend, dev)
+    compare(f"{backend}/f16 " + cid(c), got, ref, dict(LOW_TOL, out=(2e-2, 1e-1)))
+
+
+@pytest.mark.parametrize("c", [c for c in GC.MODULE_CASES if c["name"] in
+                               ("d32h2w4_8x8_g1", "d32h2w4_8x8_g1_nosharew", "d48h3w3_7x7_g2_mode7", "d32h2w4_10x9_g1_cyclic",
+                                "d64h2w7_16x15_g1_mode3", "small_s1_d96h3w7_56x56_g1")], ids=lambda c: c["name"])
+def test_module_fp16_autocast_vs_golden(c, dev, golden_dir):
+    """The drop-in module under torch.autocast(float16) -- what the reference's engine.train does unedited
+    (src/engine.py:84) -- against the reference's fp64 fixtures: output, dx and every parameter gradient."""
+    import random
+    gold = np.load(os.path.join(golden_dir, "module_cases.npz"))
+    mod, x, dout = _load_module(c, dev, torch.float32)
+    mod.train()
+    orig = random.randrange
+    random.randrange = (lambda a, b=None, _m=c["mode"]: _m)
+    try:
+        xd = x.float().to(dev).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = mod(xd, c["nx"], c["ny"])
+        assert out.dtype == torch.float16
+        out.backward(dout.to(dev, out.dtype))
+    finally:
+        random.randrange = orig
+    torch.cuda.synchronize()
+    pre = c["name"] + "/"
+
+    def ref_of(nm, t):
+        t = t.detach().double().cpu()
+        if pre + nm in gold.files:
+            return t, torch.from_numpy(gold[pre + nm])
+        if pre + nm + "@sample" in gold.files:
+            return GC.sample_big(t)[0], torch.from_numpy(gold[pre + nm + "@sample"])
+        return None, None
+
+    got, want, tols = {}, {}, {}
+    for nm, t in [("out", out), ("dx", xd.grad)] + [("d_" + n, p_.grad) for n, p_ in mod.named_parameters() if p_.grad is not None]:
+        a, b = ref_of(nm, t)
+        if b is not None:
+            got[nm], want[nm] = a, b
+            tols[nm] = (2e-2, 1e-1) if nm == "out" else ("rms", 0.2 if nm == "dx" else 0.1, 5e-2)
+    assert len(tols) >= 6
+    compare("module/fp16-autocast " + c["name"], got, want, tols)

@@ -34,7 +34,7 @@ static int check_common(const VilAttnDesc* d) {
   if (d->mode < -1 || d->mode > 8) return VIL_E_MODE;
   if (d->exact < -1 || d->exact > 1) return VIL_E_EXACT;
   if (d->exact == 1 && d->mode != 0 && !d->only_glo) return VIL_E_EXACT;
-  if (d->dtype != VIL_DTYPE_F32 && d->dtype != VIL_DTYPE_BF16) return VIL_E_DTYPE;
+  if (d->dtype != VIL_DTYPE_F32 && d->dtype != VIL_DTYPE_BF16 && d->dtype != VIL_DTYPE_F16) return VIL_E_DTYPE;
   if (d->mode_dev && (d->mode < 1 || d->mode > 8)) return VIL_E_MODE;
   if (d->bias_side < 0 || (d->bias_side > 0 && (d->bias_side % 2 == 0 || d->bias_side > 4 * d->W - 1))) return VIL_E_SHAPE;
   return VIL_OK;
@@ -128,7 +128,7 @@ extern "C" int vil_attn_bwd_full(const VilAttnDesc* d, const void* q_all, const 
   if (d->G < 1 || d->G > 4 || d->only_glo) return VIL_E_BACKEND;
   if (d->backend == VIL_BACKEND_SCALAR || vil_mfma_supported(d, 1) != VIL_OK) return VIL_E_BACKEND;
   if (!workspace) return VIL_E_WORKSPACE;
-  const int64_t es = 2;                                   // the MFMA family is bf16
+  const int64_t es = 2;                                   // the MFMA family: bf16 or fp16
   VilParams p; memset(&p, 0, sizeof(p));
   vil_fill_params(p, d);
   const int64_t HG = (int64_t)d->H * d->G;

@@ -20,12 +20,16 @@ template <> struct GIO<vil_bf16> {
   static __device__ __forceinline__ float ld(const vil_bf16* p) { return vil_bf2f(*p); }
   static __device__ __forceinline__ void st(vil_bf16* p, float v) { *p = vil_f2bf(v); }
 };
+template <> struct GIO<_Float16> {
+  static __device__ __forceinline__ float ld(const _Float16* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(_Float16* p, float v) { *p = (_Float16)v; }
+};
 
 // DPL consecutive elements of one row into registers: 16-byte loads where the layout allows (bf16, DPL % 8 == 0;
 // rows are 16-byte aligned by the descriptor checks), element loads otherwise
 template <typename T, int DPL>
 __device__ __forceinline__ void glo_ld(const T* p, float (&v)[DPL]) {
-  if constexpr (sizeof(T) == 2 && DPL % 8 == 0) {
+  if constexpr (sizeof(T) == 2 && DPL % 8 == 0 && !__is_same(T, _Float16)) {     // (bf16 bit layout)
     typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int c = 0; c < DPL / 8; ++c) {
@@ -263,7 +267,7 @@ static int glo_check(const VilAttnDesc* d) {
   if (d->B <= 0 || d->H <= 0 || d->G <= 0 || d->nx <= 0 || d->ny <= 0) return VIL_E_SHAPE;
   if (d->G > GLO_MAXG) return VIL_E_BACKEND;      // bias-gradient bookkeeping is sized for G <= 4
   switch (d->M) { case 8: case 16: case 32: case 48: case 64: break; default: return VIL_E_HEAD_DIM; }
-  if (d->dtype != VIL_DTYPE_F32 && d->dtype != VIL_DTYPE_BF16) return VIL_E_DTYPE;
+  if (d->dtype != VIL_DTYPE_F32 && d->dtype != VIL_DTYPE_BF16 && d->dtype != VIL_DTYPE_F16) return VIL_E_DTYPE;
   // 16-byte row loads of K / V in the bf16 kernels with M % 32 == 0
   if (d->dtype == VIL_DTYPE_BF16 && d->M % 32 == 0 &&
       ((d->k_st | d->k_sb | d->k_sh | d->v_st | d->v_sb | d->v_sh) & 7)) return VIL_E_ALIGN;
@@ -280,6 +284,16 @@ static void glo_fill(GloParams& p, const VilAttnDesc* d) {
 }
 
 #define GLO_DISPATCH(KERN, ...)                                                      \
+  if (d->dtype == VIL_DTYPE_F16) {                                                   \
+    switch (d->M) {                                                                  \
+      case 8: KERN<_Float16, 8><<<__VA_ARGS__>>>(p, 0); break;                        \
+      case 16: KERN<_Float16, 16><<<__VA_ARGS__>>>(p, 0); break;                      \
+      case 32: KERN<_Float16, 32><<<__VA_ARGS__>>>(p, 0); break;                      \
+      case 48: KERN<_Float16, 48><<<__VA_ARGS__>>>(p, 0); break;                      \
+      case 64: KERN<_Float16, 64><<<__VA_ARGS__>>>(p, 0); break;                      \
+      default: return VIL_E_HEAD_DIM;                                                \
+    }                                                                                \
+  } else                                                                             \
   switch (d->M * 2 + (d->dtype == VIL_DTYPE_BF16)) {                                 \
     case 16: KERN<float, 8><<<__VA_ARGS__>>>(p, 0); break;                            \
     case 17: KERN<vil_bf16, 8><<<__VA_ARGS__>>>(p, 0); break;                         \
@@ -304,7 +318,7 @@ extern "C" int vil_glo_attn_fwd(const VilAttnDesc* d, const void* q_g, const voi
   p.q = q_g; p.k = k; p.v = v; p.o = out_g; p.lse = lse_g; p.g2g = g2g; p.g2l0 = g2l0;
   hipStream_t s = (hipStream_t)stream;
   vil_prof_tag_desc(d);
-  const double e_ = d->dtype == VIL_DTYPE_BF16 ? 2 : 4, n_ = (double)d->G + (double)d->nx * d->ny;
+  const double e_ = d->dtype == VIL_DTYPE_F32 ? 4 : 2, n_ = (double)d->G + (double)d->nx * d->ny;
   vil_prof_begin(VIL_K_GLO_FWD, s, d->B * (2 * n_ + 2 * d->G) * d->H * d->M * e_, d->B * 4.0 * d->G * n_ * d->H * d->M);
   GLO_DISPATCH(k_glo_fwd, dim3(d->B * d->H), dim3(GLO_THREADS), 0, s);
   vil_prof_end(s);
@@ -323,7 +337,7 @@ extern "C" int vil_glo_attn_bwd(const VilAttnDesc* d, const void* q_g, const voi
   p.dq = dq_g; p.dk = dk; p.dv = dv; p.dg2g = dg2g; p.dg2l0 = dg2l0;
   hipStream_t s = (hipStream_t)stream;
   vil_prof_tag_desc(d);
-  const double e_ = d->dtype == VIL_DTYPE_BF16 ? 2 : 4, n_ = (double)d->G + (double)d->nx * d->ny;
+  const double e_ = d->dtype == VIL_DTYPE_F32 ? 4 : 2, n_ = (double)d->G + (double)d->nx * d->ny;
   // reads k, v, dk, dv and rewrites dk, dv (the in-place accumulation), + the G query-side rows
   vil_prof_begin(VIL_K_GLO_BWD, s, d->B * (6 * n_ + 4 * d->G) * d->H * d->M * e_, d->B * 10.0 * d->G * n_ * d->H * d->M);
   GLO_DISPATCH(k_glo_bwd, dim3(d->B * d->H), dim3(GLO_THREADS), 0, s);

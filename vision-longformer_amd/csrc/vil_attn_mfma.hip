@@ -73,8 +73,10 @@ __global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out) {
 #define VIL_FWD_WAVES 3    // waves per SIMD the register allocation is held to (2: 256, 3: 168, 4: 128 VGPRs)
 #endif
 constexpr int fwd_waves(int MD) { return MD <= 2 ? VIL_FWD_WAVES : 2; }
-template <int MD>
+template <typename T, int MD>
 __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, MfmaCfg c) {
+  typedef typename V16<T>::x8 X8;
+  typedef typename V16<T>::x4 X4;
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;            // 32-wide K steps over the head dim
   constexpr int VCH = 2 * MD;                 // 16-byte chunks per V row
@@ -111,18 +113,18 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   const int Nloc = g.nx * g.ny;
   const int kstride_b = (int)p.k_st * 2;
   const unsigned kv_bytes = (unsigned)(p.G + Nloc - 1) * (unsigned)kstride_b + M * 2;    // K / V rows of this (image, head)
-  const __amdgpu_buffer_rsrc_t krs = make_rsrc_n((const __bf16*)p.k + b * p.k_sb + h * p.k_sh, kv_bytes);
-  const __amdgpu_buffer_rsrc_t vrs = make_rsrc_n((const __bf16*)p.v + b * p.v_sb + h * p.v_sh, kv_bytes);
-  const __bf16* qb = (const __bf16*)p.q + b * p.q_sb + h * p.q_sh;
-  __bf16* ob = (__bf16*)p.o + b * p.o_sb + h * p.o_sh;
+  const __amdgpu_buffer_rsrc_t krs = make_rsrc_n((const T*)p.k + b * p.k_sb + h * p.k_sh, kv_bytes);
+  const __amdgpu_buffer_rsrc_t vrs = make_rsrc_n((const T*)p.v + b * p.v_sb + h * p.v_sh, kv_bytes);
+  const T* qb = (const T*)p.q + b * p.q_sb + h * p.q_sh;
+  T* ob = (T*)p.o + b * p.o_sb + h * p.o_sh;
   const float c1 = p.scale * LOG2E;               // scores are kept unscaled: s*c1 is log2-domain
   const float thr = 8.0f / p.scale;               // deferred-max threshold (8 nats)
   const int W = g.W;
 
   // constant A operand whose row 0 is all ones: D[0][j] = sum_k P^T[k][j]
-  bf16x8 ones;
+  X8 ones;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)(lj == 0 ? 1.0f : 0.0f);
+  for (int e = 0; e < 8; ++e) ones[e] = (T)(lj == 0 ? 1.0f : 0.0f);
 
   // lane-constant pieces of the V staging / tr-read addresses
   int vst_off[MD], vld_off[MD], vtr_off[2][MD];
@@ -164,14 +166,14 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
       qreal[qt] = qx < W && qy < W && qr < g.nx && qc < g.ny;
       qtok[qt] = qreal[qt] ? qr * g.ny + qc : (cm * W) * g.ny + cn * W;
     }
-    bf16x8 qf[MK][4];
+    X8 qf[MK][4];
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
       for (int ks = 0; ks < MK; ++ks) {
         const int d0 = ks * 32 + lg * 8;
-        bf16x8 z = {};
-        qf[ks][qt] = d0 < M ? *(const bf16x8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
+        X8 z = {};
+        qf[ks][qt] = d0 < M ? *(const X8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
       }
 
     f32x4 o[MD][4], lacc[4];
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
     const int nsteps = nslots >> 5;
     // global -> register prefetch ring, PF steps deep (2 where the registers allow it: one step of compute is
     // shorter than an L2 / HBM round trip under load, so a 1-deep ring left the wave parked at vmcnt(0))
-    bf16x8 kf[PF][2][MK];
+    X8 kf[PF][2][MK];
     u32x4 vr[PF][MD];
     auto load_step = [&](auto slot_, int st) {
       constexpr int sl = decltype(slot_)::value;
@@ -196,8 +198,8 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
         const int off = s_koff[st * 32 + hf * 16 + lj] + lgo;
 #pragma unroll
         for (int ks = 0; ks < MK; ++ks) {
-          bf16x8 z = {};
-          kf[sl][hf][ks] = (ks * 32 + lg * 8) < M ? buf_load8(krs, off + ks * 64) : z;
+          X8 z = {};
+          kf[sl][hf][ks] = (ks * 32 + lg * 8) < M ? buf_load8<T>(krs, off + ks * 64) : z;
         }
       }
 #pragma unroll
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
     auto stage_s = [&](auto slot_, int st, f32x4 (&sc)[2][4]) {
       constexpr int sl = decltype(slot_)::value;
       char* sv = s_v + (PIPE ? (st & 1) * (32 * M * 2) : 0);
-      bf16x8 kc_[2][MK];
+      X8 kc_[2][MK];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -234,14 +236,14 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
           f32x4 acc = {tb[0][qt], tb[1][qt], tb[2][qt], tb[3][qt]};
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_[hf][ks], qf[ks][qt], acc, 0, 0, 0);
+            acc = mfma16(kc_[hf][ks], qf[ks][qt], acc);
           sc[hf][qt] = acc;
         }
       }
     };
     // online softmax with a deferred maximum: ONE (rare) branch per step covers all four query tiles, so the
     // common path of a step is a single basic block the scheduler can interleave with the neighbouring MFMAs
-    auto softmax = [&](const f32x4 (&sc)[2][4], bf16x8 (&pb)[4]) {
+    auto softmax = [&](const f32x4 (&sc)[2][4], X8 (&pb)[4]) {
       float pm[4];
       bool grow = false;
 #pragma unroll
@@ -269,30 +271,30 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            pb[qt][hf * 4 + r] = (__bf16)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[hf][qt][r], c1, -mc));
+            pb[qt][hf * 4 + r] = (T)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[hf][qt][r], c1, -mc));
       }
     };
     // O^T += V^T P^T ; row sums via the ones-row
-    auto pv = [&](int st, const bf16x8 (&pb)[4]) {
+    auto pv = [&](int st, const X8 (&pb)[4]) {
       const char* sv = s_v + (PIPE ? (st & 1) * (32 * M * 2) : 0);
 #pragma unroll
       for (int dt = 0; dt < MD; ++dt) {
-        bf16x8 vt;
+        X8 vt;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const s16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (s16x4 __attribute__((address_space(3)))*)(sv + vtr_off[hf][dt]));
-          const bf16x4 tb4 = __builtin_bit_cast(bf16x4, t4);
+          const X4 tb4 = __builtin_bit_cast(X4, t4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) vt[hf * 4 + e] = tb4[e];
         }
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt)
-          o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[qt], o[dt][qt], 0, 0, 0);
+          o[dt][qt] = mfma16(vt, pb[qt], o[dt][qt]);
       }
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt)
-        lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qt], lacc[qt], 0, 0, 0);
+        lacc[qt] = mfma16(ones, pb[qt], lacc[qt]);
     };
 
     typedef std::integral_constant<int, 0> S0;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
       // exp -> LDS transpose-read -> MFMA) with two waves per SIMD to cover it: PMC showed the wave issuing 42 %
       // of its cycles, and cutting the VALU instructions per step from 196 to 120 moved the time by only 7 %.
       f32x4 scA[2][4], scB[2][4];
-      bf16x8 pb[4];
+      X8 pb[4];
       stage_s(S0{}, 0, scA);
       for (int st = 0; st < nsteps; st += 2) {
         if (st + 1 < nsteps) stage_s(S1{}, st + 1, scB);
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
     } else {
       auto one = [&](auto slot_, int st) {
         f32x4 sc[2][4];
-        bf16x8 pb[4];
+        X8 pb[4];
         stage_s(slot_, st, sc);
         softmax(sc, pb);
         wave_lds_fence();
@@ -342,10 +344,10 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
       if (qreal[qt]) {
 #pragma unroll
         for (int dt = 0; dt < MD; ++dt) {
-          bf16x4 w;
+          X4 w;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) w[r] = (__bf16)(o[dt][qt][r] * inv);
-          *(bf16x4*)(ob + (int64_t)qtok[qt] * p.o_st + dt * 16 + lg * 4) = w;
+          for (int r = 0; r < 4; ++r) w[r] = (T)(o[dt][qt][r] * inv);
+          *(X4*)(ob + (int64_t)qtok[qt] * p.o_st + dt * 16 + lg * 4) = w;
         }
         if (lg == 0)
           p.lse[(int64_t)bh * Nloc + qtok[qt]] = mrow[qt] * p.scale + __logf(l);
@@ -401,7 +403,7 @@ int vil_mfma_bwd_supported(const VilAttnDesc* d);
 size_t vil_mfma_bwd_workspace(const VilAttnDesc* d);
 
 int vil_mfma_supported(const VilAttnDesc* d, int pass) {
-  if (d->dtype != VIL_DTYPE_BF16) return VIL_E_DTYPE;
+  if (d->dtype != VIL_DTYPE_BF16 && d->dtype != VIL_DTYPE_F16) return VIL_E_DTYPE;
   if (d->M != 16 && d->M != 32 && d->M != 48 && d->M != 64) return VIL_E_HEAD_DIM;
   if (d->W < 1 || d->W > 32) return VIL_E_WINDOW;
   if (d->G > 16) return VIL_E_BACKEND;
@@ -440,8 +442,13 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   const size_t lds = mfma_lds_bytes(c);
 #define LAUNCH_FWD(MD_)                                                                              \
   {                                                                                                  \
-    if (int he = vil_ensure_dyn_lds((const void*)k_mfma_fwd<MD_>, lds)) return he;                    \
-    k_mfma_fwd<MD_><<<dim3(grid), dim3(64 * c.wpw), lds, s>>>(p, c);                                 \
+    if (d->dtype == VIL_DTYPE_F16) {                                                                 \
+      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_fwd<_Float16, MD_>, lds)) return he;        \
+      k_mfma_fwd<_Float16, MD_><<<dim3(grid), dim3(64 * c.wpw), lds, s>>>(p, c);                      \
+    } else {                                                                                         \
+      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_fwd<__bf16, MD_>, lds)) return he;          \
+      k_mfma_fwd<__bf16, MD_><<<dim3(grid), dim3(64 * c.wpw), lds, s>>>(p, c);                        \
+    }                                                                                                \
   }
   switch (d->M) {
     case 16: LAUNCH_FWD(1); break;

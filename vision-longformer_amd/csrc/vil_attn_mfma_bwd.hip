@@ -58,8 +58,10 @@ struct BwdCfg {
 #define VIL_DQ_WAVES 3     // waves per SIMD of the head_dim 32 instantiation
 #endif
 constexpr int dq_waves(int MD) { return MD == 2 ? VIL_DQ_WAVES : 2; }
-template <int MD, int QT>
+template <typename T, int MD, int QT>
 __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, BwdCfg bc) {
+  typedef typename V16<T>::x8 X8;
+  typedef typename V16<T>::x4 X4;
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;
   constexpr int VCH = 2 * MD;
@@ -114,14 +116,14 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
   int* s_akey = s_koff + c.NSP;
   char* s_k = (char*)(s_akey + c.NSP);              // [32][M] bf16 K tile of the current step
 
-  const __bf16* qb = (const __bf16*)p.q + b * p.q_sb + h * p.q_sh;
+  const T* qb = (const T*)p.q + b * p.q_sb + h * p.q_sh;
   const int Nloc = g.nx * g.ny;
   const int kstride_b = (int)p.k_st * 2;
   const unsigned kv_bytes = (unsigned)(p.G + Nloc - 1) * (unsigned)kstride_b + M * 2;    // (zero keys of cyclic padding: vil_mfma_common.h)
-  const __amdgpu_buffer_rsrc_t krs = make_rsrc_n((const __bf16*)p.k + b * p.k_sb + h * p.k_sh, kv_bytes);
-  const __amdgpu_buffer_rsrc_t vrs = make_rsrc_n((const __bf16*)p.v + b * p.v_sb + h * p.v_sh, kv_bytes);
-  const __bf16* dob = (const __bf16*)p.dout + b * p.do_sb + h * p.do_sh;
-  __bf16* dqb = (__bf16*)p.dq + b * p.dq_sb + h * p.dq_sh;
+  const __amdgpu_buffer_rsrc_t krs = make_rsrc_n((const T*)p.k + b * p.k_sb + h * p.k_sh, kv_bytes);
+  const __amdgpu_buffer_rsrc_t vrs = make_rsrc_n((const T*)p.v + b * p.v_sb + h * p.v_sh, kv_bytes);
+  const T* dob = (const T*)p.dout + b * p.do_sb + h * p.do_sh;
+  T* dqb = (T*)p.dq + b * p.dq_sb + h * p.dq_sh;
   const float c1 = p.scale * LOG2E;
   const int W = g.W;
 
@@ -170,15 +172,15 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
         lse2[qt] = qreal[qt] ? p.lse[(int64_t)bh * Nloc + qtok[qt]] * LOG2E - (float)lfx : LSE_PAD;
         dlt[qt] = qreal[qt] ? p.delta[(int64_t)bh * Nloc + qtok[qt]] : 0.f;
       }
-      bf16x8 qf[MK][QT], dof[MK][QT];
+      X8 qf[MK][QT], dof[MK][QT];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int ks = 0; ks < MK; ++ks) {
           const int d0 = ks * 32 + lg * 8;
-          bf16x8 z = {};
-          qf[ks][qt] = d0 < M ? *(const bf16x8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
-          dof[ks][qt] = d0 < M ? *(const bf16x8*)(dob + (int64_t)qtok[qt] * p.do_st + d0) : z;
+          X8 z = {};
+          qf[ks][qt] = d0 < M ? *(const X8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
+          dof[ks][qt] = d0 < M ? *(const X8*)(dob + (int64_t)qtok[qt] * p.do_st + d0) : z;
         }
       f32x4 dq[MD][QT];
 #pragma unroll
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
         for (int dt = 0; dt < MD; ++dt) dq[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
       const int nsteps = nslots >> 5;
-      bf16x8 vf[PF][2][MK];
+      X8 vf[PF][2][MK];
       u32x4 kr_[PF][MD];
       auto load_step = [&](auto slot_, int st) {
         constexpr int sl = decltype(slot_)::value;
@@ -196,8 +198,8 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
           const int off = s_koff[st * 32 + hf * 16 + lj] + lgo;
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) {
-            bf16x8 z = {};
-            vf[sl][hf][ks] = (ks * 32 + lg * 8) < M ? buf_load8(vrs, off + ks * 64) : z;
+            X8 z = {};
+            vf[sl][hf][ks] = (ks * 32 + lg * 8) < M ? buf_load8<T>(vrs, off + ks * 64) : z;
           }
         }
 #pragma unroll
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
       auto stage_s = [&](auto slot_, int st, f32x4 (&sacc)[2][QT], f32x4 (&dpacc)[2][QT], unsigned (&i0)[2][4]) {
         constexpr int sl = decltype(slot_)::value;
         char* sk = s_k + (PIPE ? (st & 1) * (32 * M * 2) : 0);
-        bf16x8 vc[2][MK];
+        X8 vc[2][MK];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -227,11 +229,11 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           // K rows of this half as the A operand (natural layout, from the LDS tile)
-          bf16x8 kc_[MK];
+          X8 kc_[MK];
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) {
-            bf16x8 z = {};
-            kc_[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(sk + krow_off[hf][ks]) : z;
+            X8 z = {};
+            kc_[ks] = (ks * 32 + lg * 8) < M ? *(const X8*)(sk + krow_off[hf][ks]) : z;
           }
           lds_cvf tb[4];
 #pragma unroll
@@ -245,8 +247,8 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
             f32x4 dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < MK; ++ks) {
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc_[ks], qf[ks][qt], acc, 0, 0, 0);
-              dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc[hf][ks], dof[ks][qt], dp, 0, 0, 0);
+              acc = mfma16(kc_[ks], qf[ks][qt], acc);
+              dp = mfma16(vc[hf][ks], dof[ks][qt], dp);
             }
             sacc[hf][qt] = acc; dpacc[hf][qt] = dp;
           }
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
       // dS^T = P^T o (dP^T - delta) (+ the bias-gradient histogram), then dQ^T += K^T dS^T
       auto finish = [&](int st, const f32x4 (&sacc)[2][QT], const f32x4 (&dpacc)[2][QT], const unsigned (&i0)[2][4]) {
         const char* sk = s_k + (PIPE ? (st & 1) * (32 * M * 2) : 0);
-        bf16x8 dsb[QT];
+        X8 dsb[QT];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -264,25 +266,25 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
             for (int r = 0; r < 4; ++r) {
               const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][qt][r], c1, -lse2[qt]));
               const float ds = pr * (dpacc[hf][qt][r] - dlt[qt]);
-              dsb[qt][hf * 4 + r] = (__bf16)ds;
+              dsb[qt][hf * 4 + r] = (T)ds;
               if (bc.do_hist)
                 __hip_atomic_fetch_add(lds_i32(i0[hf][r] + hist_off) + qt, __float2int_rn(ds),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
 #pragma unroll
         for (int dt = 0; dt < MD; ++dt) {
-          bf16x8 kt_;
+          X8 kt_;
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
             const s16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (s16x4 __attribute__((address_space(3)))*)(sk + ktr_off[hf][dt]));
-            const bf16x4 tb = __builtin_bit_cast(bf16x4, t4);
+            const X4 tb = __builtin_bit_cast(X4, t4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) kt_[hf * 4 + e] = tb[e];
           }
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt)
-            dq[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsb[qt], dq[dt][qt], 0, 0, 0);
+            dq[dt][qt] = mfma16(kt_, dsb[qt], dq[dt][qt]);
         }
       };
 
@@ -322,10 +324,10 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
         if (qreal[qt]) {
 #pragma unroll
           for (int dt = 0; dt < MD; ++dt) {
-            bf16x4 w;
+            X4 w;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w[r] = (__bf16)(dq[dt][qt][r] * unscale);
-            *(bf16x4*)(dqb + (int64_t)qtok[qt] * p.dq_st + dt * 16 + lg * 4) = w;
+            for (int r = 0; r < 4; ++r) w[r] = (T)(dq[dt][qt][r] * unscale);
+            *(X4*)(dqb + (int64_t)qtok[qt] * p.dq_st + dt * 16 + lg * 4) = w;
           }
         }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -416,8 +418,10 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
 #define VIL_KV_WAVES 2     // waves per SIMD of the head_dim 32 instantiation
 #endif
 constexpr int kv_waves(int MD) { return MD == 2 ? VIL_KV_WAVES : 2; }
-template <int MD, int KT>
+template <typename T, int MD, int KT>
 __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
+  typedef typename V16<T>::x8 X8;
+  typedef typename V16<T>::x4 X4;
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;
   constexpr int VCH = 2 * MD;
@@ -452,12 +456,12 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   char* s_q = (char*)(s_dlt + bc.nqs);            // [32][M] bf16 Q tile, then the [32][M] dO tile (PIPE: two such pairs)
   char* s_gq = s_q + (PIPE ? 4 : 2) * 32 * M * 2;   // [G][3][M] bf16: q, dO, out rows of the global queries
 
-  const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const __bf16*)p.q + b * p.q_sb + h * p.q_sh);
-  const __amdgpu_buffer_rsrc_t drs = make_rsrc((const __bf16*)p.dout + b * p.do_sb + h * p.do_sh);
-  const __bf16* kb = (const __bf16*)p.k + b * p.k_sb + h * p.k_sh;
-  const __bf16* vb = (const __bf16*)p.v + b * p.v_sb + h * p.v_sh;
-  __bf16* dkb = (__bf16*)p.dk + b * p.dk_sb + h * p.dk_sh;
-  __bf16* dvb = (__bf16*)p.dv + b * p.dv_sb + h * p.dv_sh;
+  const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const T*)p.q + b * p.q_sb + h * p.q_sh);
+  const __amdgpu_buffer_rsrc_t drs = make_rsrc((const T*)p.dout + b * p.do_sb + h * p.do_sh);
+  const T* kb = (const T*)p.k + b * p.k_sb + h * p.k_sh;
+  const T* vb = (const T*)p.v + b * p.v_sb + h * p.v_sh;
+  T* dkb = (T*)p.dk + b * p.dk_sb + h * p.dk_sh;
+  T* dvb = (T*)p.dv + b * p.dv_sb + h * p.dv_sh;
   const int Nloc = g.nx * g.ny;
   const int qstride_b = (int)p.q_st * 2, dostride_b = (int)p.do_st * 2;
   const float c1 = p.scale * LOG2E;
@@ -503,10 +507,10 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     if (p.glo_rows) {       // staged now so that the unit's tail does not wait on HBM with one wave per SIMD
       for (int i = lane; i < p.G * 3 * (M / 8); i += 64) {
         const int c8 = i % (M / 8), wh = (i / (M / 8)) % 3, gq = i / (3 * (M / 8));
-        const __bf16* src = wh == 0 ? (const __bf16*)p.q_g + b * p.q_sb + (int64_t)gq * p.q_st + h * p.q_sh
-                          : wh == 1 ? (const __bf16*)p.do_g + b * p.do_sb + (int64_t)gq * p.do_st + h * p.do_sh
-                                    : (const __bf16*)p.o_g + b * p.o_sb + (int64_t)gq * p.o_st + h * p.o_sh;
-        *(bf16x8*)(s_gq + i * 16) = *(const bf16x8*)(src + c8 * 8);
+        const T* src = wh == 0 ? (const T*)p.q_g + b * p.q_sb + (int64_t)gq * p.q_st + h * p.q_sh
+                          : wh == 1 ? (const T*)p.do_g + b * p.do_sb + (int64_t)gq * p.do_st + h * p.do_sh
+                                    : (const T*)p.o_g + b * p.o_sb + (int64_t)gq * p.o_st + h * p.o_sh;
+        *(X8*)(s_gq + i * 16) = *(const X8*)(src + c8 * 8);
       }
     }
     wave_lds_fence();
@@ -583,15 +587,15 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
         ktok[kt] = p.G + (kreal[kt] ? kr * g.ny + kc : (km * W) * g.ny + kn * W);
       }
     }
-    bf16x8 kfb[MK][KT], vfb[MK][KT];
+    X8 kfb[MK][KT], vfb[MK][KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int ks = 0; ks < MK; ++ks) {
         const int d0 = ks * 32 + lg * 8;
-        bf16x8 z = {};
-        kfb[ks][kt] = d0 < M ? *(const bf16x8*)(kb + (int64_t)ktok[kt] * p.k_st + d0) : z;
-        vfb[ks][kt] = d0 < M ? *(const bf16x8*)(vb + (int64_t)ktok[kt] * p.v_st + d0) : z;
+        X8 z = {};
+        kfb[ks][kt] = d0 < M ? *(const X8*)(kb + (int64_t)ktok[kt] * p.k_st + d0) : z;
+        vfb[ks][kt] = d0 < M ? *(const X8*)(vb + (int64_t)ktok[kt] * p.v_st + d0) : z;
       }
     f32x4 dk[MD][KT], dv[MD][KT];
 #pragma unroll
@@ -631,12 +635,12 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       wave_lds_fence();
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        bf16x8 qa[MK], da[MK];
+        X8 qa[MK], da[MK];
 #pragma unroll
         for (int ks = 0; ks < MK; ++ks) {
-          bf16x8 z = {};
-          qa[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(sq + row_off[hf][ks]) : z;
-          da[ks] = (ks * 32 + lg * 8) < M ? *(const bf16x8*)(sd + row_off[hf][ks]) : z;
+          X8 z = {};
+          qa[ks] = (ks * 32 + lg * 8) < M ? *(const X8*)(sq + row_off[hf][ks]) : z;
+          da[ks] = (ks * 32 + lg * 8) < M ? *(const X8*)(sd + row_off[hf][ks]) : z;
         }
         const i32x4 aq4 = *(const i32x4*)(s_aq + st * 32 + hf * 16 + lg * 4);
         lds_cvf tb[4];
@@ -648,8 +652,8 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           f32x4 dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], kfb[ks][kt], acc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[ks], vfb[ks][kt], dp, 0, 0, 0);
+            acc = mfma16(qa[ks], kfb[ks][kt], acc);
+            dp = mfma16(da[ks], vfb[ks][kt], dp);
           }
           sacc[hf][kt] = acc; dpacc[hf][kt] = dp;
         }
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     auto finish = [&](int st, const f32x4 (&sacc)[2][KT], const f32x4 (&dpacc)[2][KT]) {
       const char* sq = s_q + (PIPE ? (st & 1) * 2 * TILE : 0);
       const char* sd = sq + TILE;
-      bf16x8 pb[KT], dsb[KT];
+      X8 pb[KT], dsb[KT];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int sb = st * 32 + hf * 16 + lg * 4;
@@ -670,26 +674,26 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r]));
-            pb[kt][hf * 4 + r] = (__bf16)pr;
-            dsb[kt][hf * 4 + r] = (__bf16)(pr * (dpacc[hf][kt][r] - dl4[r]));
+            pb[kt][hf * 4 + r] = (T)pr;
+            dsb[kt][hf * 4 + r] = (T)(pr * (dpacc[hf][kt][r] - dl4[r]));
           }
       }
 #pragma unroll
       for (int dt = 0; dt < MD; ++dt) {
-        bf16x8 qt_, dt_;
+        X8 qt_, dt_;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          const bf16x4 tq = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          const X4 tq = __builtin_bit_cast(X4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (s16x4 __attribute__((address_space(3)))*)(sq + tr_off[hf][dt])));
-          const bf16x4 td = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          const X4 td = __builtin_bit_cast(X4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (s16x4 __attribute__((address_space(3)))*)(sd + tr_off[hf][dt])));
 #pragma unroll
           for (int e = 0; e < 4; ++e) { qt_[hf * 4 + e] = tq[e]; dt_[hf * 4 + e] = td[e]; }
         }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-          dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt_, pb[kt], dv[dt][kt], 0, 0, 0);
-          dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsb[kt], dk[dt][kt], 0, 0, 0);
+          dv[dt][kt] = mfma16(dt_, pb[kt], dv[dt][kt]);
+          dk[dt][kt] = mfma16(qt_, dsb[kt], dk[dt][kt]);
         }
       }
     };
@@ -730,19 +734,19 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     if (p.glo_rows && (!glo || split == 0)) {
       float* rec = bc.gq_parts + ((int64_t)bh * (nown + 1) + (glo ? nown : unit)) * p.G * (M + 4);
       for (int gq = 0; gq < p.G; ++gq) {
-        const __bf16* qg = (const __bf16*)(s_gq + gq * 3 * M * 2);
-        const __bf16* dg = qg + M;
-        const __bf16* og = dg + M;
-        bf16x8 qf[MK], df[MK];
+        const T* qg = (const T*)(s_gq + gq * 3 * M * 2);
+        const T* dg = qg + M;
+        const T* og = dg + M;
+        X8 qf[MK], df[MK];
         float dl = 0.f;
 #pragma unroll
         for (int ks = 0; ks < MK; ++ks) {
           const int d0 = ks * 32 + lg * 8;
-          bf16x8 z = {};
+          X8 z = {};
           qf[ks] = z; df[ks] = z;
           if (d0 < M) {
-            qf[ks] = *(const bf16x8*)(qg + d0); df[ks] = *(const bf16x8*)(dg + d0);
-            const bf16x8 of = *(const bf16x8*)(og + d0);
+            qf[ks] = *(const X8*)(qg + d0); df[ks] = *(const X8*)(dg + d0);
+            const X8 of = *(const X8*)(og + d0);
 #pragma unroll
             for (int e = 0; e < 8; ++e) dl = __builtin_fmaf((float)df[ks][e], (float)of[e], dl);
           }
@@ -803,21 +807,21 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
         }
         // dK/dV of the unit's keys: on the MFMA like every other query (the accumulators never leave
         // their registers): the global query is query 0 of an otherwise empty 32-query step
-        bf16x8 pb0[KT], dsb0[KT];
+        X8 pb0[KT], dsb0[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-          bf16x8 z = {};
+          X8 z = {};
           pb0[kt] = z; dsb0[kt] = z;
-          if (lg == 0) { pb0[kt][0] = (__bf16)pr[kt]; dsb0[kt][0] = (__bf16)ds[kt]; }
+          if (lg == 0) { pb0[kt][0] = (T)pr[kt]; dsb0[kt][0] = (T)ds[kt]; }
         }
 #pragma unroll
         for (int dt = 0; dt < MD; ++dt) {
-          bf16x8 qt0 = {}, dt0 = {};
+          X8 qt0 = {}, dt0 = {};
           if (lg == 0) { qt0[0] = qg[dt * 16 + lj]; dt0[0] = dg[dt * 16 + lj]; }
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt) {
-            dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt0, pb0[kt], dv[dt][kt], 0, 0, 0);
-            dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt0, dsb0[kt], dk[dt][kt], 0, 0, 0);
+            dv[dt][kt] = mfma16(dt0, pb0[kt], dv[dt][kt]);
+            dk[dt][kt] = mfma16(qt0, dsb0[kt], dk[dt][kt]);
           }
         }
       }
@@ -830,14 +834,14 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
         if (kreal[kt]) {
 #pragma unroll
           for (int dt = 0; dt < MD; ++dt) {
-            bf16x4 wk, wv;
+            X4 wk, wv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              wk[r] = (__bf16)(dk[dt][kt][r] * p.scale);
-              wv[r] = (__bf16)dv[dt][kt][r];
+              wk[r] = (T)(dk[dt][kt][r] * p.scale);
+              wv[r] = (T)dv[dt][kt][r];
             }
-            *(bf16x4*)(dkb + (int64_t)ktok[kt] * p.dk_st + dt * 16 + lg * 4) = wk;
-            *(bf16x4*)(dvb + (int64_t)ktok[kt] * p.dv_st + dt * 16 + lg * 4) = wv;
+            *(X4*)(dkb + (int64_t)ktok[kt] * p.dk_st + dt * 16 + lg * 4) = wk;
+            *(X4*)(dvb + (int64_t)ktok[kt] * p.dv_st + dt * 16 + lg * 4) = wv;
           }
         }
     } else if (kreal[0]) {
@@ -857,6 +861,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
 // One workgroup per (image, head, global token gk):
 //   dk/dv rows of global KEY gk   = sum over the splits' fp32 partials (glo_parts)
 //   dq row of global QUERY gk     = scale * sum over the units' partials (gq_parts), and its d(g2l[0]) share
+template <typename T>
 __global__ __launch_bounds__(256) void k_mfma_reduce_glo(VilParams p, BwdCfg bc, int nslots) {
   __shared__ float red[4][2][64];
   const int M = p.M, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -865,9 +870,9 @@ __global__ __launch_bounds__(256) void k_mfma_reduce_glo(VilParams p, BwdCfg bc,
   if (tid < 2 * M) {
     float sk = 0.f;
     for (int s = 0; s < bc.nsplit; ++s) sk += bc.glo_parts[((((int64_t)bh * bc.nsplit + s) * p.G + gk) * 2) * M + tid];
-    vil_bf16* dst = tid < M ? (vil_bf16*)p.dk + b * p.dk_sb + (int64_t)gk * p.dk_st + h * p.dk_sh + tid
-                            : (vil_bf16*)p.dv + b * p.dv_sb + (int64_t)gk * p.dv_st + h * p.dv_sh + (tid - M);
-    *dst = vil_f2bf(sk);
+    T* dst = tid < M ? (T*)p.dk + b * p.dk_sb + (int64_t)gk * p.dk_st + h * p.dk_sh + tid
+                     : (T*)p.dv + b * p.dv_sb + (int64_t)gk * p.dv_st + h * p.dv_sh + (tid - M);
+    *dst = (T)sk;
   }
   if (!p.glo_rows) return;
   const int RS = M + 4;
@@ -897,8 +902,8 @@ __global__ __launch_bounds__(256) void k_mfma_reduce_glo(VilParams p, BwdCfg bc,
   if (wv == 0) {
     a0 = red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane];
     a1 = red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane];
-    vil_bf16* dq = (vil_bf16*)p.dq_g + b * p.dq_sb + (int64_t)gk * p.dq_st + h * p.dq_sh;
-    if (lane < M) dq[lane] = vil_f2bf(a0 * p.scale);
+    T* dq = (T*)p.dq_g + b * p.dq_sb + (int64_t)gk * p.dq_st + h * p.dq_sh;
+    if (lane < M) dq[lane] = (T)(a0 * p.scale);
     const float bs = M == 64 ? a1 : a0;              // column M
     if (p.dg2l0 && lane == (M & 63)) atomicAdd(&p.dg2l0[h * p.G + gk], bs);
   }
@@ -908,8 +913,9 @@ __global__ __launch_bounds__(256) void k_mfma_reduce_glo(VilParams p, BwdCfg bc,
 // row, so a wave reads whole 64..128-byte row segments (one thread per row left 7/8 of every line fetched
 // by a load instruction to the other lanes' later loads)
 // also: max_q |dO_q|^2 and max_k |v_k|^2 (float bits, atomicMax) for the histogram's fixed-point scale
-template <int MD>
+template <typename T, int MD>
 __global__ void k_mfma_delta(VilParams p, unsigned* norm2) {
+  typedef typename V16<T>::x8 X8;
   constexpr int M = 16 * MD;
   constexpr int LPR = MD == 4 ? 8 : (MD == 2 ? 4 : 2);
   constexpr int NL = M / (8 * LPR);
@@ -922,13 +928,13 @@ __global__ void k_mfma_delta(VilParams p, unsigned* norm2) {
   const int64_t i = (int64_t)bh * Nloc + tok;
   float n_do = 0.f, n_v = 0.f, s = 0.f, n_vg = 0.f;
   if (live) {
-    const __bf16* op = (const __bf16*)p.out + b * p.o_sb + (int64_t)tok * p.o_st + h * p.o_sh;
-    const __bf16* dp = (const __bf16*)p.dout + b * p.do_sb + (int64_t)tok * p.do_st + h * p.do_sh;
-    const __bf16* vp = (const __bf16*)p.v + b * p.v_sb + (int64_t)(p.G + tok) * p.v_st + h * p.v_sh;
+    const T* op = (const T*)p.out + b * p.o_sb + (int64_t)tok * p.o_st + h * p.o_sh;
+    const T* dp = (const T*)p.dout + b * p.do_sb + (int64_t)tok * p.do_st + h * p.do_sh;
+    const T* vp = (const T*)p.v + b * p.v_sb + (int64_t)(p.G + tok) * p.v_st + h * p.v_sh;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       const int d0 = (sub * NL + l) * 8;
-      const bf16x8 a = *(const bf16x8*)(op + d0), c = *(const bf16x8*)(dp + d0), v = *(const bf16x8*)(vp + d0);
+      const X8 a = *(const X8*)(op + d0), c = *(const X8*)(dp + d0), v = *(const X8*)(vp + d0);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         s = __builtin_fmaf((float)a[e], (float)c[e], s);
@@ -937,7 +943,7 @@ __global__ void k_mfma_delta(VilParams p, unsigned* norm2) {
       }
     }
     if (tok < p.G && sub == 0) {        // the G global rows of v
-      const __bf16* vg = (const __bf16*)p.v + b * p.v_sb + (int64_t)tok * p.v_st + h * p.v_sh;
+      const T* vg = (const T*)p.v + b * p.v_sb + (int64_t)tok * p.v_st + h * p.v_sh;
       for (int d = 0; d < M; ++d) n_vg = __builtin_fmaf((float)vg[d], (float)vg[d], n_vg);
     }
   }
@@ -1081,14 +1087,17 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   const VilWork w(d);
   const int64_t rows = (int64_t)p.B * p.H * p.g.nx * p.g.ny;
   int e;
-#define BWD_SWITCH(...)                          \
+#define BWD_SWITCH_T(T_, ...)                    \
   switch (d->M) {                                \
-    case 16: { constexpr int MD_ = 1; __VA_ARGS__; } break; \
-    case 32: { constexpr int MD_ = 2; __VA_ARGS__; } break; \
-    case 48: { constexpr int MD_ = 3; __VA_ARGS__; } break; \
-    case 64: { constexpr int MD_ = 4; __VA_ARGS__; } break; \
+    case 16: { typedef T_ TT_; constexpr int MD_ = 1; __VA_ARGS__; } break; \
+    case 32: { typedef T_ TT_; constexpr int MD_ = 2; __VA_ARGS__; } break; \
+    case 48: { typedef T_ TT_; constexpr int MD_ = 3; __VA_ARGS__; } break; \
+    case 64: { typedef T_ TT_; constexpr int MD_ = 4; __VA_ARGS__; } break; \
     default: return VIL_E_HEAD_DIM;              \
   }
+#define BWD_SWITCH(...)                                                   \
+  if (d->dtype == VIL_DTYPE_F16) { BWD_SWITCH_T(_Float16, __VA_ARGS__) }  \
+  else { BWD_SWITCH_T(__bf16, __VA_ARGS__) }
   vil_prof_begin(VIL_K_TABLE, s, 0, 0);
   k_mfma_table<<<dim3((c.tabsize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
   vil_prof_end(s);
@@ -1104,7 +1113,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     }
   }
   vil_prof_begin(VIL_K_DELTA, s, w.delta_bytes(), 0);
-  BWD_SWITCH((k_mfma_delta<MD_><<<dim3((unsigned)((p.g.nx * p.g.ny * (MD_ == 4 ? 8 : (MD_ == 2 ? 4 : 2)) + 255) / 256), p.B * p.H), dim3(256), 0, s>>>(
+  BWD_SWITCH((k_mfma_delta<TT_, MD_><<<dim3((unsigned)((p.g.nx * p.g.ny * (MD_ == 4 ? 8 : (MD_ == 2 ? 4 : 2)) + 255) / 256), p.B * p.H), dim3(256), 0, s>>>(
       p, bc.do_hist ? bc.norm2 : nullptr)));
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
@@ -1112,8 +1121,8 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     const size_t lds = dq_lds(c, bc);
     vil_prof_begin(VIL_K_MFMA_DQ, s, w.dq_bytes(), w.dq_flops());
     BWD_SWITCH({
-      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dq<MD_, (MD_ >= 2 ? 2 : 4)>, lds)) return he;
-      k_mfma_bwd_dq<MD_, (MD_ >= 2 ? 2 : 4)><<<dim3((unsigned)bc.dq_nwg), dim3(64 * bc.dq_wpw), lds, s>>>(p, c, bc);
+      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dq<TT_, MD_, (MD_ >= 2 ? 2 : 4)>, lds)) return he;
+      k_mfma_bwd_dq<TT_, MD_, (MD_ >= 2 ? 2 : 4)><<<dim3((unsigned)bc.dq_nwg), dim3(64 * bc.dq_wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
@@ -1123,15 +1132,16 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     const unsigned grid = (unsigned)(p.B * p.H * bc.kv_wg_per_bh);
     vil_prof_begin(VIL_K_MFMA_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
     BWD_SWITCH({
-      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dkdv<MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))>, lds)) return he;
-      k_mfma_bwd_dkdv<MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
+      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dkdv<TT_, MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))>, lds)) return he;
+      k_mfma_bwd_dkdv<TT_, MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
   }
   if (p.G > 0) {
     vil_prof_begin(VIL_K_REDUCE_GLO, s, 0, 0);
-    k_mfma_reduce_glo<<<dim3((unsigned)(p.B * p.H * p.G)), dim3(256), 0, s>>>(p, bc, bc.nch * bc.kv_NWP + 1);
+    if (d->dtype == VIL_DTYPE_F16) k_mfma_reduce_glo<_Float16><<<dim3((unsigned)(p.B * p.H * p.G)), dim3(256), 0, s>>>(p, bc, bc.nch * bc.kv_NWP + 1);
+    else k_mfma_reduce_glo<__bf16><<<dim3((unsigned)(p.B * p.H * p.G)), dim3(256), 0, s>>>(p, bc, bc.nch * bc.kv_NWP + 1);
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
   }

@@ -23,6 +23,10 @@ template <> struct IOT<vil_bf16> {
   static __device__ __forceinline__ float ld(const vil_bf16* p) { return vil_bf2f(*p); }
   static __device__ __forceinline__ void st(vil_bf16* p, float v) { *p = vil_f2bf(v); }
 };
+template <> struct IOT<_Float16> {      // the reference's AMP dtype (fp16 autocast)
+  static __device__ __forceinline__ float ld(const _Float16* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(_Float16* p, float v) { *p = (_Float16)v; }
+};
 
 template <typename T, int M>
 __device__ __forceinline__ void load_row(const T* p, float (&r)[M]) {
@@ -429,7 +433,7 @@ static int scalar_part_stride(const VilAttnDesc* d, bool has_bias) {
 int vil_scalar_supported(const VilAttnDesc* d) {
   switch (d->M) { case 8: case 16: case 32: case 48: case 64: break; default: return VIL_E_HEAD_DIM; }
   if (d->W < 1 || d->W > 32) return VIL_E_WINDOW;
-  if (d->dtype != VIL_DTYPE_F32 && d->dtype != VIL_DTYPE_BF16) return VIL_E_DTYPE;
+  if (d->dtype != VIL_DTYPE_F32 && d->dtype != VIL_DTYPE_BF16 && d->dtype != VIL_DTYPE_F16) return VIL_E_DTYPE;
   if (d->mode_dev) return VIL_E_BACKEND;                                           // device-side mode: MFMA family only
   if (d->bias_side != 0 && d->bias_side != 4 * d->W - 1) return VIL_E_BACKEND;   // non-default table side: MFMA family only
   return VIL_OK;
@@ -461,6 +465,8 @@ int vil_scalar_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   const unsigned grid = (unsigned)(p.B * p.H * g.mx * g.my * nq);
   if (d->dtype == VIL_DTYPE_F32) {
     DISPATCH_M(d->M, k_scalar_fwd<float, MM><<<dim3(grid), dim3(64), 0, s>>>(p));
+  } else if (d->dtype == VIL_DTYPE_F16) {
+    DISPATCH_M(d->M, k_scalar_fwd<_Float16, MM><<<dim3(grid), dim3(64), 0, s>>>(p));
   } else {
     DISPATCH_M(d->M, k_scalar_fwd<vil_bf16, MM><<<dim3(grid), dim3(64), 0, s>>>(p));
   }
@@ -481,19 +487,22 @@ int vil_scalar_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   const size_t accb = (size_t)p.part_stride * sizeof(float);
   int e;
   const VilWork w(d);
-  const bool f32 = d->dtype == VIL_DTYPE_F32;
+  const bool f32 = d->dtype == VIL_DTYPE_F32, f16 = d->dtype == VIL_DTYPE_F16;
   vil_prof_begin(VIL_K_DELTA, s, w.delta_bytes(), 0);
   if (f32) { DISPATCH_M(d->M, k_delta<float, MM><<<dim3(gd), dim3(256), 0, s>>>(p)); }
+  else if (f16) { DISPATCH_M(d->M, k_delta<_Float16, MM><<<dim3(gd), dim3(256), 0, s>>>(p)); }
   else { DISPATCH_M(d->M, k_delta<vil_bf16, MM><<<dim3(gd), dim3(256), 0, s>>>(p)); }
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
   vil_prof_begin(VIL_K_SCALAR_DQ, s, w.dq_bytes(), w.dq_flops());
   if (f32) { DISPATCH_M(d->M, k_scalar_bwd_dq<float, MM><<<dim3(gq), dim3(64), accb, s>>>(p)); }
+  else if (f16) { DISPATCH_M(d->M, k_scalar_bwd_dq<_Float16, MM><<<dim3(gq), dim3(64), accb, s>>>(p)); }
   else { DISPATCH_M(d->M, k_scalar_bwd_dq<vil_bf16, MM><<<dim3(gq), dim3(64), accb, s>>>(p)); }
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
   vil_prof_begin(VIL_K_SCALAR_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
   if (f32) { DISPATCH_M(d->M, k_scalar_bwd_dkdv<float, MM><<<dim3(gk), dim3(64), 0, s>>>(p)); }
+  else if (f16) { DISPATCH_M(d->M, k_scalar_bwd_dkdv<_Float16, MM><<<dim3(gk), dim3(64), 0, s>>>(p)); }
   else { DISPATCH_M(d->M, k_scalar_bwd_dkdv<vil_bf16, MM><<<dim3(gk), dim3(64), 0, s>>>(p)); }
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
@@ -501,6 +510,7 @@ int vil_scalar_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     vil_prof_begin(VIL_K_REDUCE_GLO, s, 0, 0);
     const unsigned gg = (unsigned)((p.B * p.H * p.G * p.M + 255) / 256);
     if (f32) hipLaunchKernelGGL((k_reduce_glo<float>), dim3(gg), dim3(256), 0, s, p);
+    else if (f16) hipLaunchKernelGGL((k_reduce_glo<_Float16>), dim3(gg), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_reduce_glo<vil_bf16>), dim3(gg), dim3(256), 0, s, p);
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;

@@ -88,7 +88,7 @@ struct VilWork {
   explicit VilWork(const VilAttnDesc* d) {
     VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
     nloc = (double)d->nx * d->ny; n = nloc + d->G; c = (double)d->H * d->M;
-    e = d->dtype == VIL_DTYPE_BF16 ? 2 : 4; h = d->H; b = d->B;
+    e = d->dtype == VIL_DTYPE_F32 ? 4 : 2; h = d->H; b = d->B;
     k = d->only_glo ? d->G : (double)g.nact * g.W2 + d->G; tbl = d->bias_side > 0 ? (double)d->bias_side * d->bias_side : (double)g.tbl * g.tbl;
   }
   double fwd_bytes() const { return b * ((2 * nloc + 2 * n) * c * e + 4 * h * nloc + 4 * h * tbl); }

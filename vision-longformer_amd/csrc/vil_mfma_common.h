@@ -6,6 +6,15 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// The MFMA kernels are templated on the 16-bit I/O element type T: __bf16 (the build's training precision) or
+// _Float16 (the reference's AMP dtype: fp16 autocast + GradScaler, src/engine.py:84, run_experiment.py:206).
+// Accumulation, softmax and every reduction are fp32 for both.
+template <typename T> struct V16 {
+  typedef T x8 __attribute__((ext_vector_type(8)));
+  typedef T x4 __attribute__((ext_vector_type(4)));
+};
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -83,9 +92,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_n(const void* p, uns
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, (int)nbytes, 0x00020000);
 }
 #define VIL_ZERO_OFF 0x7fff0000
-__device__ __forceinline__ bf16x8 buf_load8(__amdgpu_buffer_rsrc_t r, int byte_off) {
-  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+template <typename T>
+__device__ __forceinline__ typename V16<T>::x8 buf_load8(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(typename V16<T>::x8, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

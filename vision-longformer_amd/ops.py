@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 
-_DT = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16}
+_DT = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
 _BACKENDS = {"auto": _lib.BACKEND_AUTO, "scalar": _lib.BACKEND_SCALAR, "mfma": _lib.BACKEND_MFMA}
 
 # process-wide default kernel family ("auto" | "scalar" | "mfma"); tests override per call
@@ -84,7 +84,7 @@ class _VilLocalAttention(torch.autograd.Function):
             raise RuntimeError("vil_local_attention needs device tensors: the product path is the HIP "
                                "kernels (libvilattn.so); there is no CPU fallback")
         if q.dtype not in _DT or kv.dtype != q.dtype:
-            raise TypeError(f"vil_local_attention supports float32/bfloat16 q,kv of one dtype; got {q.dtype}, {kv.dtype}")
+            raise TypeError(f"vil_local_attention supports float32 / bfloat16 / float16 q,kv of one dtype; got {q.dtype}, {kv.dtype}")
         L = _lib.lib()
         q = _last_contig(q)
         kv = _last_contig(kv)
@@ -230,7 +230,7 @@ def _check_dev(t, name):
         raise RuntimeError(f"{name} needs device tensors: the product path is the HIP kernels "
                            "(libvilattn.so); there is no CPU fallback")
     if t.dtype not in _DT:
-        raise TypeError(f"{name} supports float32/bfloat16 tensors; got {t.dtype}")
+        raise TypeError(f"{name} supports float32 / bfloat16 / float16 tensors; got {t.dtype}")
 
 
 def _f32c(t):
