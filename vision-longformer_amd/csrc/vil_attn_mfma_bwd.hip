@@ -109,7 +109,11 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
       lfx = max(-60, min(60, lfx));
     }
   }
-  const float unscale = p.scale * __builtin_amdgcn_exp2f((float)-lfx);
+  // bf16 has fp32's exponent range, so 2^lfx rides on P for free (folded into lse) and leaves dQ in the epilogue;
+  // fp16 would overflow (2^lfx dS reaches 2^20): there the scale is applied to the histogram value only
+  constexpr bool FOLD = !__is_same(T, _Float16);
+  const float hscale = FOLD ? 1.0f : __builtin_amdgcn_exp2f((float)lfx);
+  const float unscale = FOLD ? p.scale * __builtin_amdgcn_exp2f((float)-lfx) : p.scale;
 
   char* wbase = smem + (size_t)c.tabsize * 8 + (size_t)wave * bc.dq_wave_lds;
   int* s_koff = (int*)wbase;
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
         qreal[qt] = qx < W && qy < W && qr < g.nx && qc < g.ny;
         qtok[qt] = qreal[qt] ? qr * g.ny + qc : (cm * W) * g.ny + cn * W;
         // a non-existent query slot gets lse = +big: its probabilities (hence dS) are exactly 0
-        lse2[qt] = qreal[qt] ? p.lse[(int64_t)bh * Nloc + qtok[qt]] * LOG2E - (float)lfx : LSE_PAD;
+        lse2[qt] = qreal[qt] ? p.lse[(int64_t)bh * Nloc + qtok[qt]] * LOG2E - (FOLD ? (float)lfx : 0.f) : LSE_PAD;
         dlt[qt] = qreal[qt] ? p.delta[(int64_t)bh * Nloc + qtok[qt]] : 0.f;
       }
       X8 qf[MK][QT], dof[MK][QT];
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
               const float ds = pr * (dpacc[hf][qt][r] - dlt[qt]);
               dsb[qt][hf * 4 + r] = (T)ds;
               if (bc.do_hist)
-                __hip_atomic_fetch_add(lds_i32(i0[hf][r] + hist_off) + qt, __float2int_rn(ds),
+                __hip_atomic_fetch_add(lds_i32(i0[hf][r] + hist_off) + qt, __float2int_rn(FOLD ? ds : ds * hscale),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
 #pragma unroll
