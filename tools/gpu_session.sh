@@ -56,10 +56,10 @@ for STEP in "$@"; do
         timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$CFG" -o t -- python bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > "$OUT/trace_$CFG.json" 2> "$OUT/trace_$CFG.err"
         KT=$(find "$OUT/trace_$CFG" -name "*kernel_trace.csv" | head -1)
         ST=$(find "$OUT/trace_$CFG" -name "*kernel_stats.csv" | head -1)
-        MARK="void k_mfma_fwd<__bf16, 2>"
+        MARK="void k_mfma_fwd<bf16,2>"
         python tools/trace_summary.py "$KT" "$MARK" 1 60 > "$OUT/steady_$CFG.txt" 2>&1
         cp "$ST" "$OUT/kernel_stats_$CFG.csv" 2>/dev/null
-        rm -rf "$OUT/trace_$CFG"            # (the raw trace is tens of MB)
+        gzip -c "$KT" > "$OUT/kernel_trace_$CFG.csv.gz"; rm -rf "$OUT/trace_$CFG"            # (the raw trace is tens of MB)
         head -14 "$OUT/steady_$CFG.txt"
       done ;;
     opbench)

@@ -21,7 +21,12 @@ SINK = {"k_mfma_table": "k_mfma_table", "k_mfma_fwd": "k_mfma_fwd", "k_mfma_delt
 
 
 def base(name):
-    n = name.replace("void ", "").split("(")[0].split("<")[0].strip()
+    import re
+    m = re.match(r"_Z(\d+)", name)          # rocprofv3 leaves names with __bf16 / _Float16 template arguments mangled
+    if m:
+        n = name[m.end():m.end() + int(m.group(1))]
+    else:
+        n = name.replace("void ", "").split("(")[0].split("<")[0].strip()
     return SINK.get(n)
 
 

@@ -5,6 +5,11 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        import re
+        m = re.match(r"_Z(\d+)", name)      # mangled (template arguments __bf16 / _Float16): keep name + raw argument list
+        if m:
+            rest = name[m.end() + int(m.group(1)):]
+            name = name[m.end():m.end() + int(m.group(1))] + "<" + rest.split("Ev")[0].lstrip("I") + ">"
         if not ("k_mfma" in name or "k_scalar" in name or "k_delta" in name):
             continue
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -3,7 +3,20 @@ import csv, collections, sys
 path = sys.argv[1]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marker = sys.argv[2] if len(sys.argv) > 2 else "void k_mfma_fwd<2>"
+import re
+def pretty(n):
+    """rocprofv3 leaves names whose template arguments are __bf16 / _Float16 mangled: _Z10k_mfma_fwdIDF16bLi2EEv... -> k_mfma_fwd<bf16,2>"""
+    m = re.match(r"_Z(\d+)", n)
+    if not m:
+        return n
+    name = n[m.end():m.end() + int(m.group(1))]
+    args = n[m.end() + int(m.group(1)):].split("Ev")[0].lstrip("I")
+    args = args.replace("DF16b", "bf16,").replace("DF16_", "f16,")
+    args = re.sub(r"Li(\d+)E", r"\1,", args).rstrip("E,").rstrip(",")
+    return f"void {name}<{args}>"
+for r in rows:
+    r["Kernel_Name"] = pretty(r["Kernel_Name"])
+marker = sys.argv[2] if len(sys.argv) > 2 else "void k_mfma_fwd<bf16,2>"
 idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(marker)]
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 1       # marker launches per step
 nsteps = 3
