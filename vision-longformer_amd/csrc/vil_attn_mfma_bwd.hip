@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
       const unsigned aq0b = tab_lds + (min(qx, W - 1) * c.P + QT * qhq) * 4;
       int qtok[QT];
       bool qreal[QT];
-      float lse2[QT], dlt[QT];
+      float lse2[QT], ndlt[QT];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         const int qy = QT * qhq + qt;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
         qtok[qt] = qreal[qt] ? qr * g.ny + qc : (cm * W) * g.ny + cn * W;
         // a non-existent query slot gets lse = +big: its probabilities (hence dS) are exactly 0
         lse2[qt] = qreal[qt] ? p.lse[(int64_t)bh * Nloc + qtok[qt]] * LOG2E - (FOLD ? (float)lfx : 0.f) : LSE_PAD;
-        dlt[qt] = qreal[qt] ? p.delta[(int64_t)bh * Nloc + qtok[qt]] : 0.f;
+        ndlt[qt] = qreal[qt] ? -p.delta[(int64_t)bh * Nloc + qtok[qt]] : 0.f;
       }
       X8 qf[MK][QT], dof[MK][QT];
 #pragma unroll
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) {
             f32x4 acc = {tb[0][qt], tb[1][qt], tb[2][qt], tb[3][qt]};
-            f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+            f32x4 dp = {ndlt[qt], ndlt[qt], ndlt[qt], ndlt[qt]};      // dP - delta: the subtraction rides in the accumulator
 #pragma unroll
             for (int ks = 0; ks < MK; ++ks) {
               acc = mfma16(kc_[ks], qf[ks][qt], acc);
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][qt][r], c1, -lse2[qt]));
-              const float ds = pr * (dpacc[hf][qt][r] - dlt[qt]);
+              const float ds = pr * dpacc[hf][qt][r];
               dsb[qt][hf * 4 + r] = (T)ds;
               if (bc.do_hist)
                 __hip_atomic_fetch_add(lds_i32(i0[hf][r] + hist_off) + qt, __float2int_rn(FOLD ? ds : ds * hscale),
@@ -647,13 +647,14 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           da[ks] = (ks * 32 + lg * 8) < M ? *(const X8*)(sd + row_off[hf][ks]) : z;
         }
         const i32x4 aq4 = *(const i32x4*)(s_aq + st * 32 + hf * 16 + lg * 4);
+        const f32x4 nd4 = -*(const f32x4*)(s_dlt + st * 32 + hf * 16 + lg * 4);   // dP - delta rides in the accumulator
         lds_cvf tb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) tb[r] = lds_f32((unsigned)aq4[r] - akl);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
           f32x4 acc = {tb[0][kt], tb[1][kt], tb[2][kt], tb[3][kt]};
-          f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+          f32x4 dp = nd4;
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) {
             acc = mfma16(qa[ks], kfb[ks][kt], acc);
@@ -672,14 +673,13 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       for (int hf = 0; hf < 2; ++hf) {
         const int sb = st * 32 + hf * 16 + lg * 4;
         const f32x4 ls4 = *(const f32x4*)(s_lse + sb);
-        const f32x4 dl4 = *(const f32x4*)(s_dlt + sb);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r]));
             pb[kt][hf * 4 + r] = (T)pr;
-            dsb[kt][hf * 4 + r] = (T)(pr * (dpacc[hf][kt][r] - dl4[r]));
+            dsb[kt][hf * 4 + r] = (T)(pr * dpacc[hf][kt][r]);
           }
       }
 #pragma unroll
