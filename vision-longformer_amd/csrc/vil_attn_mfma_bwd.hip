@@ -421,6 +421,10 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
 #ifndef VIL_KV_WAVES
 #define VIL_KV_WAVES 2     // waves per SIMD of the head_dim 32 instantiation
 #endif
+#ifndef VIL_KV_ABL
+#define VIL_KV_ABL 0       // ablation bits for TIMING diagnostics only (results are wrong when non-zero): 1 no bias gather,
+#endif                     // 2 no exp, 4 no dV/dK MFMAs + transpose reads, 8 no S/dP MFMAs, 16 no global loads, 32 no LDS tiles,
+                           // 64 no step loop, 128 no global-row part, 256 no lse / delta gathers in the slot-table build
 constexpr int kv_waves(int MD) { return MD == 2 ? VIL_KV_WAVES : 2; }
 template <typename T, int MD, int KT>
 __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
@@ -565,12 +569,13 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
         int s = ci * W2 + xl * W;
         for (int yl = 0; yl < nvalid; ++yl) {
           s_tok[s] = tok; s_aq[s] = aq;
-          s_lse[s] = lse_bh[tok] * LOG2E; s_dlt[s] = dlt_bh[tok];
+          if (VIL_KV_ABL & 256) { s_lse[s] = 1.0f; s_dlt[s] = 0.f; }
+          else { s_lse[s] = lse_bh[tok] * LOG2E; s_dlt[s] = dlt_bh[tok]; }
           ++s; ++tok; aq += glo ? 0 : 4;
         }
       }
     }
-    const int nsteps = (nchunks * W2 + 31) >> 5;
+    const int nsteps = (VIL_KV_ABL & 64) ? 0 : (nchunks * W2 + 31) >> 5;
 
     // ---- this lane's key slots: column j of key-tile kt is key (x, y = KT*hq + KT-1 - kt)
     const int jj = wp * 16 + lj;
@@ -619,6 +624,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       for (int it = 0; it < MD; ++it) {
         const int row = (it * 64 + lane) / VCH;
         const int tok = s_tok[st * 32 + row];          // Q and dO may have different row strides (fused qkv)
+        if ((VIL_KV_ABL & 16) && st > 0) continue;
         qr_[sl][it] = __builtin_amdgcn_raw_buffer_load_b128(qrs, __mul24(tok, qstride_b) + ld_off[it], 0, 0);
         dr_[sl][it] = __builtin_amdgcn_raw_buffer_load_b128(drs, __mul24(tok, dostride_b) + ld_off[it], 0, 0);
       }
@@ -632,6 +638,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       char* sd = sq + TILE;
 #pragma unroll
       for (int it = 0; it < MD; ++it) {
+        if ((VIL_KV_ABL & 32) && st > 0) break;
         *(u32x4*)(sq + st_off[it]) = qr_[sl][it];
         *(u32x4*)(sd + st_off[it]) = dr_[sl][it];
       }
@@ -654,9 +661,11 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
           f32x4 acc = {tb[0][kt], tb[1][kt], tb[2][kt], tb[3][kt]};
+          if (VIL_KV_ABL & 1) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
           f32x4 dp = nd4;
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) {
+            if (VIL_KV_ABL & 8) { acc[0] += (float)qa[ks][0]; dp[0] += (float)da[ks][0]; continue; }
             acc = mfma16(qa[ks], kfb[ks][kt], acc);
             dp = mfma16(da[ks], vfb[ks][kt], dp);
           }
@@ -677,13 +686,19 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r]));
+            const float pr = (VIL_KV_ABL & 2) ? __builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r])
+                                              : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r]));
             pb[kt][hf * 4 + r] = (T)pr;
             dsb[kt][hf * 4 + r] = (T)(pr * dpacc[hf][kt][r]);
           }
       }
 #pragma unroll
       for (int dt = 0; dt < MD; ++dt) {
+        if (VIL_KV_ABL & 4) {
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) { dv[dt][kt][0] += (float)pb[kt][dt]; dk[dt][kt][0] += (float)dsb[kt][dt]; }
+          continue;
+        }
         X8 qt_, dt_;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -735,7 +750,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     // K / V fragments are still in registers: scores by VALU dot products (G is 1..4, no MFMA tile to
     // fill), dK/dV added straight into the accumulators, the unit's share of dq_g / d(bias) to a partial
     // record.  Replaces a separate pass that re-read k, v, dk, dv and rewrote dk, dv.
-    if (p.glo_rows && (!glo || split == 0)) {
+    if (!(VIL_KV_ABL & 128) && p.glo_rows && (!glo || split == 0)) {
       float* rec = bc.gq_parts + ((int64_t)bh * (nown + 1) + (glo ? nown : unit)) * p.G * (M + 4);
       for (int gq = 0; gq < p.G; ++gq) {
         const T* qg = (const T*)(s_gq + gq * 3 * M * 2);
