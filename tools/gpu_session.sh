@@ -31,6 +31,10 @@ for STEP in "$@"; do
     bench_r01lib)      # same engine, round-1 kernels: isolates kernel changes from box-to-box clock differences
       VIL_ATTN_LIB=$PWD/tools/ab/libvilattn_r01.so timeout 600 python bench.py --no-cpu-baseline > "$OUT/bench_r01lib.json" 2> "$OUT/bench_r01lib.err"
       python -c "import json,sys; d=json.load(open('$OUT/bench_r01lib.json')); print('r01 lib:', d['value'], d['ms_per_step'], d['hot_path_ms_per_step'])" ;;
+    bench2)      # the driver's multi-GPU command line, two ranks SHARING this box's one GPU (gloo): exercises the whole N > 1 flow
+      VIL_SHARE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 \
+        bench.py --gpus 2 --steps 5 --warmup 2 > "$OUT/bench2.json" 2> "$OUT/bench2.err"
+      tail -c 600 "$OUT/bench2.err"; python -c "import json; d=json.loads(open('$OUT/bench2.json').read().strip().splitlines()[-1]); print('2 ranks on 1 GPU:', d['value'], d['ms_per_step'], d['config']['launch'], d['comm'], d['secondary']['value'])" ;;
     meddeep)
       timeout 600 python bench.py --config vil_medium_deep_384 --no-cpu-baseline > "$OUT/bench_meddeep.json" 2> "$OUT/bench_meddeep.err"
       tail -c 1500 "$OUT/bench_meddeep.json" ;;
