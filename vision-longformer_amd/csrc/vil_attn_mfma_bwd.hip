@@ -27,6 +27,8 @@
 struct BwdCfg {
   int nch;            // query/key chunks per (image, head) = mx*my
   int nsplit;         // global-key owner units per (image, head)
+  int glo_from_dq;    // G <= 4: dK/dV of the global keys are a by-product of the dQ pass (one owner unit, streaming nothing)
+  int glo_nrec;       // partial records per (image, head) in glo_parts: dq units + 1, or nsplit
   int units_kv_bh;    // nch*NWP + (G ? nsplit : 0)
   int kv_wg_per_bh, kv_gpw, kv_wpw;
   int dq_QT, dq_HQ, dq_NWP, dq_units_bh, dq_wg_per_bh, dq_gpw, dq_wpw;   // dQ pass: query tiles per wave, ...
@@ -35,7 +37,7 @@ struct BwdCfg {
   int kv_wave_lds, dq_wave_lds;
   int do_hist;
   float* hist_parts;  // (dq workgroups, tabsize) int32
-  float* glo_parts;   // (B*H, nsplit, G, 2, M)
+  float* glo_parts;   // (B*H, glo_nrec, G, 2, M)
   float* gq_parts;    // (B*H, nch*NWP + 1, G, M + 4): per-unit partial dq of the global QUERY rows, [M] = sum of dS
   int dq_nwg;
   int hist_nmax;      // upper bound of contributions one histogram bin can receive in one workgroup
@@ -186,6 +188,76 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
           qf[ks][qt] = d0 < M ? *(const X8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
           dof[ks][qt] = d0 < M ? *(const X8*)(dob + (int64_t)qtok[qt] * p.do_st + d0) : z;
         }
+      if (bc.glo_from_dq) {
+        // dK / dV of the G global keys as a by-product of this pass: the wave holds the Q / dO rows, lse and delta of its
+        // queries; its share of dK_g = scale * sum_q dS[q,g] Q[q] and dV_g = sum_q P[q,g] dO[q] is ~250 VALU instructions
+        // once per unit, done here while few registers are live (scores by dot products, as the global QUERY rows of
+        // the dK/dV pass do).  It replaces owner units of the dK/dV pass that streamed every query chunk through
+        // 64-key MFMA tiles with one live key column (11 % of that pass's units at 8x8 chunks).
+        const float lfx2 = FOLD ? __builtin_amdgcn_exp2f((float)-lfx) : 1.0f;      // lse2 carries -lfx in the bf16 build
+        float* rec = bc.glo_parts + (((int64_t)bh * bc.glo_nrec + unit) * p.G) * 2 * M;
+#pragma unroll 1
+        for (int r = 0; r < p.G; ++r) {
+          X8 kg[MK], vg[MK];
+#pragma unroll
+          for (int ks = 0; ks < MK; ++ks) {
+            X8 z = {};
+            const bool ok = (ks * 32 + lg * 8) < M;
+            kg[ks] = ok ? buf_load8<T>(krs, r * kstride_b + lgo + ks * 64) : z;
+            vg[ks] = ok ? buf_load8<T>(vrs, r * kstride_b + lgo + ks * 64) : z;
+          }
+          const float bias_g = tab[c.glo0 + r * c.gsz];                    // g2l[h][g] / scale (0 without rpe)
+          float ak_[MK][8], av_[MK][8];
+#pragma unroll
+          for (int ks = 0; ks < MK; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ak_[ks][e] = 0.f; av_[ks][e] = 0.f; }
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) {
+            float sc = 0.f, dp = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < MK; ++ks)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                sc = __builtin_fmaf((float)qf[ks][qt][e], (float)kg[ks][e], sc);
+                dp = __builtin_fmaf((float)dof[ks][qt][e], (float)vg[ks][e], dp);
+              }
+            sc += __shfl_xor(sc, 16, 64); sc += __shfl_xor(sc, 32, 64);
+            dp += __shfl_xor(dp, 16, 64); dp += __shfl_xor(dp, 32, 64);
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc + bias_g, c1, -lse2[qt])) * lfx2;   // 0 for padding slots
+            const float ds = pr * (dp + ndlt[qt]);
+#pragma unroll
+            for (int ks = 0; ks < MK; ++ks)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                ak_[ks][e] = __builtin_fmaf(ds, (float)qf[ks][qt][e], ak_[ks][e]);
+                av_[ks][e] = __builtin_fmaf(pr, (float)dof[ks][qt][e], av_[ks][e]);
+              }
+          }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int ks = 0; ks < MK; ++ks)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                ak_[ks][e] += __shfl_xor(ak_[ks][e], o, 64);
+                av_[ks][e] += __shfl_xor(av_[ks][e], o, 64);
+              }
+          if (lj == 0) {
+#pragma unroll
+            for (int ks = 0; ks < MK; ++ks) {
+              const int d0 = ks * 32 + lg * 8;
+              if (d0 < M) {
+                float* rk = rec + (r * 2) * M + d0;
+                *(f32x4*)rk = (f32x4){ak_[ks][0], ak_[ks][1], ak_[ks][2], ak_[ks][3]} * p.scale;
+                *(f32x4*)(rk + 4) = (f32x4){ak_[ks][4], ak_[ks][5], ak_[ks][6], ak_[ks][7]} * p.scale;
+                *(f32x4*)(rk + M) = (f32x4){av_[ks][0], av_[ks][1], av_[ks][2], av_[ks][3]};
+                *(f32x4*)(rk + M + 4) = (f32x4){av_[ks][4], av_[ks][5], av_[ks][6], av_[ks][7]};
+              }
+            }
+          }
+        }
+      }
       f32x4 dq[MD][QT];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt)
@@ -524,7 +596,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     wave_lds_fence();
     int nchunks;
     if (glo) {
-      nchunks = (bc.nch - split + bc.nsplit - 1) / bc.nsplit;
+      nchunks = bc.glo_from_dq ? 0 : (bc.nch - split + bc.nsplit - 1) / bc.nsplit;
     } else if (p.only_glo) {
       nchunks = 0;                                   // local keys are attended by nobody
     } else if (g.exact == -1) {
@@ -864,7 +936,8 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           }
         }
     } else if (kreal[0]) {
-      float* out = bc.glo_parts + ((((int64_t)bh * bc.nsplit + split) * p.G + lj) * 2) * M;
+      const int rec_ = bc.glo_from_dq ? bc.glo_nrec - 1 : split;       // (the dQ pass wrote records 0 .. glo_nrec-2)
+      float* out = bc.glo_parts + ((((int64_t)bh * bc.glo_nrec + rec_) * p.G + lj) * 2) * M;
 #pragma unroll
       for (int dt = 0; dt < MD; ++dt)
 #pragma unroll
@@ -888,7 +961,7 @@ __global__ __launch_bounds__(256) void k_mfma_reduce_glo(VilParams p, BwdCfg bc,
   const int b = bh / p.H, h = bh % p.H;
   if (tid < 2 * M) {
     float sk = 0.f;
-    for (int s = 0; s < bc.nsplit; ++s) sk += bc.glo_parts[((((int64_t)bh * bc.nsplit + s) * p.G + gk) * 2) * M + tid];
+    for (int s = 0; s < bc.glo_nrec; ++s) sk += bc.glo_parts[((((int64_t)bh * bc.glo_nrec + s) * p.G + gk) * 2) * M + tid];
     T* dst = tid < M ? (T*)p.dk + b * p.dk_sb + (int64_t)gk * p.dk_st + h * p.dk_sh + tid
                      : (T*)p.dv + b * p.dv_sb + (int64_t)gk * p.dv_st + h * p.dv_sh + (tid - M);
     *dst = (T)sk;
@@ -1010,13 +1083,14 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   memset(&bc, 0, sizeof(bc));
   VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
   bc.nch = g.mx * g.my;
-  bc.nsplit = d->G > 0 ? (bc.nch + 8) / 9 : 0;
+  bc.glo_from_dq = d->G > 0 && d->G <= 4;
+  bc.nsplit = d->G > 0 ? (bc.glo_from_dq ? 1 : (bc.nch + 8) / 9) : 0;
   bc.kv_KT = d->M >= 48 ? 2 : (d->M == 32 ? VIL_KV_KT32 : 4);
   bc.kv_HQ = (g.W + bc.kv_KT - 1) / bc.kv_KT;
   bc.kv_NWP = (g.W * bc.kv_HQ + 15) / 16;
   bc.units_kv_bh = bc.nch * bc.kv_NWP + bc.nsplit;
   // streamed query slots: an own-key unit sees <= nact query chunks, a global-key unit its share of all chunks
-  const int qch = d->G > 0 ? (bc.nch + bc.nsplit - 1) / bc.nsplit : 0;
+  const int qch = (d->G > 0 && !bc.glo_from_dq) ? (bc.nch + bc.nsplit - 1) / bc.nsplit : 0;
   bc.nqs = ((qch > g.nact ? qch : g.nact) * g.W2 + 31) & ~31;
   // slot tables + Q/dO tiles + the q / dO / out rows of the G global queries (vil_attn_bwd_full)
   const int kv_tiles = (VIL_KV_PIPE && d->M == 32 && bc.kv_KT == 2) ? 4 : 2;       // Q + dO tiles (pipelined kernel: two pairs)
@@ -1037,6 +1111,7 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   bc.dq_HQ = (g.W + bc.dq_QT - 1) / bc.dq_QT;
   bc.dq_NWP = (g.W * bc.dq_HQ + 15) / 16;
   bc.dq_units_bh = bc.nch * bc.dq_NWP;
+  bc.glo_nrec = bc.glo_from_dq ? bc.dq_units_bh + 1 : bc.nsplit;
   bc.dq_wpw = 4;
   while (bc.dq_wpw > 1 && (size_t)c.tabsize * 8 + (size_t)bc.dq_wpw * bc.dq_wave_lds > 160 * 1024) bc.dq_wpw >>= 1;
   {
@@ -1075,7 +1150,7 @@ static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& 
   off[1] = ((rows + 3) & ~(size_t)3) + 32 * VIL_NORM_SLOTS;      // + norm-maxima slots and the histogram scale
   off[2] = off[1] + (size_t)d->H * c.tabsize;
   off[3] = off[2] + (size_t)bc.dq_nwg * c.tabsize;
-  off[4] = off[3] + (size_t)d->B * d->H * bc.nsplit * d->G * 2 * d->M;
+  off[4] = off[3] + (size_t)d->B * d->H * bc.glo_nrec * d->G * 2 * d->M;
   off[5] = off[4] + (size_t)d->B * d->H * (bc.nch * bc.kv_NWP + 1) * d->G * (d->M + 4);
 }
 
