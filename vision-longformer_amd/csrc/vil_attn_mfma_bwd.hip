@@ -959,12 +959,45 @@ __global__ __launch_bounds__(256) void k_mfma_reduce_glo(VilParams p, BwdCfg bc,
   const int M = p.M, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int gk = blockIdx.x % p.G, bh = blockIdx.x / p.G;
   const int b = bh / p.H, h = bh % p.H;
-  if (tid < 2 * M) {
-    float sk = 0.f;
-    for (int s = 0; s < bc.glo_nrec; ++s) sk += bc.glo_parts[((((int64_t)bh * bc.glo_nrec + s) * p.G + gk) * 2) * M + tid];
-    T* dst = tid < M ? (T*)p.dk + b * p.dk_sb + (int64_t)gk * p.dk_st + h * p.dk_sh + tid
-                     : (T*)p.dv + b * p.dv_sb + (int64_t)gk * p.dv_st + h * p.dv_sh + (tid - M);
-    *dst = (T)sk;
+  {
+    // dk / dv rows of global key gk: sum of glo_nrec records of 2M floats (up to hundreds in by-product mode): the four
+    // waves take every fourth record, four loads in flight each, lanes = columns (2M <= 128: one or two per lane)
+    const float* rb = bc.glo_parts + (((int64_t)bh * bc.glo_nrec) * p.G + gk) * 2 * M;
+    const int64_t rstride = (int64_t)p.G * 2 * M;
+    const bool c2 = lane + 64 < 2 * M;
+    float b0 = 0.f, b1 = 0.f;
+    int s = wv;
+    for (; s + 12 < bc.glo_nrec; s += 16) {
+      float v0[4], v1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* r = rb + (s + 4 * u) * rstride;
+        v0[u] = lane < 2 * M ? r[lane] : 0.f;
+        v1[u] = c2 ? r[lane + 64] : 0.f;
+      }
+      b0 += (v0[0] + v0[1]) + (v0[2] + v0[3]);
+      b1 += (v1[0] + v1[1]) + (v1[2] + v1[3]);
+    }
+    for (; s < bc.glo_nrec; s += 4) {
+      const float* r = rb + s * rstride;
+      b0 += lane < 2 * M ? r[lane] : 0.f;
+      b1 += c2 ? r[lane + 64] : 0.f;
+    }
+    red[wv][0][lane] = b0; red[wv][1][lane] = b1;
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = lane + 64 * j;
+        if (col < 2 * M) {
+          const float sk = red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane];
+          T* dst = col < M ? (T*)p.dk + b * p.dk_sb + (int64_t)gk * p.dk_st + h * p.dk_sh + col
+                           : (T*)p.dv + b * p.dv_sb + (int64_t)gk * p.dv_st + h * p.dv_sh + (col - M);
+          *dst = (T)sk;
+        }
+      }
+    }
+    __syncthreads();
   }
   if (!p.glo_rows) return;
   const int RS = M + 4;
