@@ -49,7 +49,7 @@ def test_scalar_bf16_vs_oracle(c, dev):
     compare("scalar/bf16 " + cid(c), got, ref, BF16_TOL)
 
 
-# >= 32 chunks at head_dim <= 32: the global keys' dK/dV come out of the dQ pass (by-product mode of the MFMA backward)
+# >= 32 chunks at head_dim <= 32 (also the shapes of the backward's optional by-product mode, -DVIL_GLO_FROM_DQ=1)
 MANY_CHUNKS = [case(2, 16, 2, 12, 13, 2), case(1, 32, 3, 18, 20, 4), case(2, 32, 2, 16, 16, 1, exact=-1),
                case(2, 32, 3, 19, 18, 3, mode=5), case(2, 16, 2, 12, 12, 2, only_glo=True), case(3, 32, 4, 24, 23, 1, exact=1, B=1)]
 MFMA_CASES = [c for c in SMALL if c["M"] in (16, 32, 48, 64)] + MANY_CHUNKS      # incl. cyclic padding (exact=-1) and only_glo
@@ -122,7 +122,7 @@ def _fuzz_full_cases(n=24, seed=777):
         G = rng.choice([1, 1, 2, 3, 4])
         mode = rng.choice([0, 0, -1, 1, 3, 6, 8])
         cases.append(case(H, M, W, nx, ny, G, mode=mode, exact=0, rpe=rng.random() < 0.8, B=rng.choice([1, 2])))
-    # >= 32 chunks, head_dim <= 32: by-product mode of the backward together with the global QUERY rows
+    # >= 32 chunks, head_dim <= 32, with the global QUERY rows (also the shapes of -DVIL_GLO_FROM_DQ=1)
     cases += [case(2, 32, 2, 14, 13, 1, B=2), case(1, 16, 3, 18, 19, 3, mode=3, B=1), case(2, 32, 3, 20, 18, 4, B=1)]
     return cases
 

@@ -1116,10 +1116,16 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   memset(&bc, 0, sizeof(bc));
   VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
   bc.nch = g.mx * g.my;
-  // By-product mode only where it is a net win (A/B, one box): the dQ pass pays ~1.4 us per unit for it (twice that at
-  // head_dim 64), the dK/dV pass saves its owner units -- 11 % of its time at 8x8 chunks (ViL-Small stage 1: dK/dV
-  // 404 -> 364 us, dQ 380 -> 412), 5 % at 4x4 and nothing for the one-chunk stages, where dQ's extra cost dominates.
-  bc.glo_from_dq = d->G > 0 && d->G <= 4 && d->M <= 32 && bc.nch >= 32;
+  // By-product mode (dK/dV of the global keys out of the dQ pass): a measured alternative, OFF by default.  In-step, one
+  // box: ViL-Small stage 1 dK/dV 399 -> 366 us but dQ 350 -> 374 and the record reduce 13 -> 16: whole backward 861 -> 855 us
+  // (-0.7 %); ViL-Medium-Deep stage 1 dK/dV 314 -> 295, dQ 274 -> 302: 682 -> 696 us (+2 %); 4x4-chunk and one-chunk stages
+  // lose outright (the dQ pass pays ~1.4 us per unit, twice that at head_dim 64).  It moves work between the passes
+  // without reducing it: the per-unit VALU reduction over the 16 query columns costs what the owner units' idle MFMA
+  // columns cost.  -DVIL_GLO_FROM_DQ=1 enables it for head_dim <= 32 and >= 32 chunks (tests cover both settings).
+#ifndef VIL_GLO_FROM_DQ
+#define VIL_GLO_FROM_DQ 0
+#endif
+  bc.glo_from_dq = VIL_GLO_FROM_DQ && d->G > 0 && d->G <= 4 && d->M <= 32 && bc.nch >= 32;
   bc.nsplit = d->G > 0 ? (bc.glo_from_dq ? 1 : (bc.nch + 8) / 9) : 0;
   bc.kv_KT = d->M >= 48 ? 2 : (d->M == 32 ? VIL_KV_KT32 : 4);
   bc.kv_HQ = (g.W + bc.kv_KT - 1) / bc.kv_KT;
