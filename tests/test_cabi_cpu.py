@@ -188,3 +188,28 @@ def test_product_package_never_imports_the_oracle():
     for fn in ("__init__.py",):
         src = open(os.path.join(ROOT, "vision_longformer_amd", fn)).read()
         assert "oracle" not in src
+
+
+def test_round2_entry_points_validate_before_launching():
+    """Operator-level entry points (vil_sc2d_*), vil_gemm_tune and the fp16 dtype: argument errors come back as
+    VIL_E_* codes without touching a device."""
+    L = _lib.lib()
+    vp = ctypes.c_void_p
+    a16 = vp(4096)
+    F32, F64, BF16, F16 = _lib.DTYPE_F32, _lib.DTYPE_F64, _lib.DTYPE_BF16, _lib.DTYPE_F16
+    assert L.vil_sc2d_qk(None, a16, a16, 2, 4, 2, 2, 4, 0, F32, None) == -1
+    assert L.vil_sc2d_qk(a16, a16, a16, 2, 4, 2, 2, 4, 0, BF16, None) == -7        # operator surface: fp32 / fp64 only
+    assert L.vil_sc2d_av(a16, a16, a16, 2, 4, 2, 2, 4, 9, F64, None) == -5         # mode out of range
+    assert L.vil_sc2d_agrad(a16, a16, a16, 0, 4, 2, 2, 4, 0, F32, None) == -2
+    assert L.vil_sc2d_mask(a16, 2, 2, 2, 0, 0, 4, 1, 3, F32, None, None) == -6     # exact=1 with mode != 0: the reference's ValueError
+    assert L.vil_sc2d_mask(a16, 2, 2, 2, 0, 0, 4, 2, 0, F32, None, None) == -6
+    assert L.vil_sc2d_mask(a16, 2, 2, 2, 4, 0, 4, 0, 0, F32, None, None) == -2     # padding must be < W
+    assert L.vil_gemm_tune(0, None, a16, None, a16, 8, 8, 8, 8, 8, a16, 1 << 20, None) == -1
+    assert L.vil_gemm_tune(0, a16, a16, None, a16, 8, 12, 8, 16, 8, a16, 1 << 20, None) == -8
+    # fp16 I/O is a supported dtype of both kernel families (the reference's AMP dtype)
+    assert L.vil_attn_check(ctypes.byref(_desc(dtype=F16))) == 0
+    assert L.vil_attn_check(ctypes.byref(_desc(dtype=F16, backend=_lib.BACKEND_MFMA, M=32))) == 0
+    assert L.vil_attn_check(ctypes.byref(_desc(dtype=F64))) == -7                  # fp64: operator-level entry points only
+    # cyclic padding and only_glo no longer fall back to the scalar family
+    assert L.vil_attn_check(ctypes.byref(_desc(dtype=BF16, backend=_lib.BACKEND_MFMA, M=32, exact=-1))) == 0
+    assert L.vil_attn_check(ctypes.byref(_desc(dtype=BF16, backend=_lib.BACKEND_MFMA, M=32, only_glo=1))) == 0

@@ -7,7 +7,8 @@ Layout
   _lib.py          ctypes binding of the C ABI (fails loudly when the library is missing)
   ops.py           torch.autograd.Function around vil_attn_fwd / vil_attn_bwd
   longformer2d.py  drop-in Long2DSCSelfAttention module (same ctor, state-dict keys, mode RNG)
+  slidingchunk_2d.py  the reference's operator-level functions (slidingchunk_2d, mask_invalid_locations) on HIP kernels
   msvit.py         host model (MsViT) assembled from stock PyTorch-ROCm blocks + the module above
   engine.py        one-process-per-GPU data-parallel training step (RCCL all-reduce via DDP)
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"
