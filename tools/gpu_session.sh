@@ -35,6 +35,11 @@ for STEP in "$@"; do
       VIL_SHARE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 \
         bench.py --gpus 2 --steps 5 --warmup 2 > "$OUT/bench2.json" 2> "$OUT/bench2.err"
       tail -c 600 "$OUT/bench2.err"; python -c "import json; d=json.loads(open('$OUT/bench2.json').read().strip().splitlines()[-1]); print('2 ranks on 1 GPU:', d['value'], d['ms_per_step'], d['config']['launch'], d['comm'], d['secondary']['value'])" ;;
+    configs)      # the other BASELINE configurations (parity-test cases, not bench lines): one short run each
+      for CFG in vil_tiny_224 vil_medium_deep_384_f8f12 vil_base_deep_384_rs; do
+        timeout 600 python bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_$CFG.json" 2> "$OUT/bench_$CFG.err"
+        python -c "import json; d=json.load(open('$OUT/bench_$CFG.json')); print('$CFG', d['value'], d['ms_per_step'], d['hot_path_ms_per_step'], d['roofline'] and (d['roofline']['shape'], d['roofline']['frac']))"
+      done ;;
     meddeep)
       timeout 600 python bench.py --config vil_medium_deep_384 --no-cpu-baseline > "$OUT/bench_meddeep.json" 2> "$OUT/bench_meddeep.err"
       tail -c 1500 "$OUT/bench_meddeep.json" ;;
