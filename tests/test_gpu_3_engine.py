@@ -202,9 +202,9 @@ def test_graphed_step_two_processes_one_gpu(dev, tmp_path):
 
 def test_graphed_step_observes_lr_schedule(dev):
     """A captured optimizer step must follow a per-iteration learning-rate schedule (the reference's warm-up + cosine,
-    src/engine.py): with capturable=True the lr is a device tensor that engine.set_lr updates in place.  Graphed and
-    eager steps under the same schedule must agree, and the schedule must matter."""
-    from vision_longformer_amd.engine import MasterWeightAdamW, train_step, GraphedTrainStep, set_lr
+    src/engine.py): with capturable=True the lr is a device tensor that engine.set_lr updates in place.  fp32 step (no
+    bf16 noise): graphed and eager under the same schedule must agree closely, and the schedule must matter."""
+    from vision_longformer_amd.engine import make_optimizer, train_step, GraphedTrainStep, set_lr
     from vision_longformer_amd.msvit import MsViT
     arch = "l1,h1,d32,n1,s1,g1,p4,f4,a0_l2,h2,d64,n1,s1,g1,p2,f4,a0_l3,h2,d64,n1,s0,g1,p2,f7,a0"
     g = torch.Generator().manual_seed(7)
@@ -215,30 +215,27 @@ def test_graphed_step_observes_lr_schedule(dev):
     def run(graphed, schedule):
         torch.manual_seed(0)
         m = MsViT(arch, img_size=64, num_classes=10, drop_path_rate=0.0, norm_embed=True, sharew=True).to(dev).train()
-        opt = MasterWeightAdamW(m, lr=lrs[0], capturable=graphed)
+        opt = make_optimizer(m, lr=lrs[0], capturable=graphed)
         if graphed:
             sd = {k: v.clone() for k, v in m.state_dict().items()}
-            msd = [mm.clone() for mm in opt.master]
-            gs = GraphedTrainStep(m, opt, xs[0], ts[0], warmup=2)
+            gs = GraphedTrainStep(m, opt, xs[0], ts[0], warmup=2, amp_dtype=None)
             with torch.no_grad():
                 for k, v in m.state_dict().items():
                     v.copy_(sd[k])
-                for mm, v in zip(opt.master, msd):
-                    mm.copy_(v)
-            for st in opt.opt.state.values():
+            for st in opt.state.values():
                 for v in st.values():
                     if torch.is_tensor(v):
                         v.zero_()
         for i, (x, t) in enumerate(zip(xs, ts)):
             if schedule:
                 set_lr(opt, lrs[i])
-            gs(x, t) if graphed else train_step(m, opt, x, t)
+            gs(x, t) if graphed else train_step(m, opt, x, t, amp_dtype=None)
         torch.cuda.synchronize()
         return torch.cat([p.detach().float().reshape(-1) for p in m.parameters()]).cpu()
 
     pe, pg, pg_const = run(False, True), run(True, True), run(True, False)
     d_sched = float((pe - pg).abs().max())
     d_const = float((pg - pg_const).abs().max())
-    report(f"     lr schedule under hipGraph: |graph - eager| {d_sched:.3e}; |scheduled - constant lr| {d_const:.3e}")
-    assert d_sched < 2e-2
-    assert d_const > 5 * d_sched and d_const > 1e-2          # the captured step really read the new lr
+    report(f"     lr schedule under hipGraph (fp32 step): |graph - eager| {d_sched:.3e}; |scheduled - constant lr| {d_const:.3e}")
+    assert d_sched < 2e-3
+    assert d_const > 1e-2 and d_const > 5 * d_sched          # the captured step really read the new lr
