@@ -74,7 +74,7 @@ __global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out) {
 #endif
 constexpr int fwd_waves(int MD) { return MD <= 2 ? VIL_FWD_WAVES : 2; }
 template <typename T, int MD>
-__global__ __launch_bounds__(512, fwd_waves(MD)) void k_mfma_fwd(VilParams p, MfmaCfg c) {
+__global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, MfmaCfg c) {
   typedef typename V16<T>::x8 X8;
   typedef typename V16<T>::x4 X4;
   constexpr int M = 16 * MD;
@@ -381,7 +381,8 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   c.NSP = (c.NS + 31) & ~31;
   c.units_bh = g.mx * g.my * c.NWP;
   c.wave_lds = ((c.NSP * 8 + ((VIL_FWD_PIPE && d->M <= 32) ? 2 : 1) * 32 * d->M * 2 + 15) / 16) * 16;   // slot tables + V tile(s) (PIPE: two)
-  c.wpw = vil_pick_wpw((size_t)c.tabsize * 4, c.wave_lds, c.units_bh, d->M <= 32 ? VIL_FWD_WAVES : 2);
+  c.wpw = 4;
+  while (c.wpw > 1 && (size_t)c.tabsize * 8 + (size_t)c.wpw * c.wave_lds > 160 * 1024) c.wpw >>= 1;
   const int groups = (c.units_bh + c.wpw - 1) / c.wpw;
 #ifndef VIL_FWD_WGS
 #define VIL_FWD_WGS 8192   // target workgroup count: a workgroup walks gpw groups of chunks one after the other.

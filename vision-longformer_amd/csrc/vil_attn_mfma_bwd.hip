@@ -61,7 +61,7 @@ struct BwdCfg {
 #endif
 constexpr int dq_waves(int MD) { return MD == 2 ? VIL_DQ_WAVES : 2; }
 template <typename T, int MD, int QT>
-__global__ __launch_bounds__(512, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, BwdCfg bc) {
+__global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, MfmaCfg c, BwdCfg bc) {
   typedef typename V16<T>::x8 X8;
   typedef typename V16<T>::x4 X4;
   constexpr int M = 16 * MD;
@@ -499,7 +499,7 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
                            // 64 no step loop, 128 no global-row part, 256 no lse / delta gathers in the slot-table build
 constexpr int kv_waves(int MD) { return MD == 2 ? VIL_KV_WAVES : 2; }
 template <typename T, int MD, int KT>
-__global__ __launch_bounds__(512, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
+__global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
   typedef typename V16<T>::x8 X8;
   typedef typename V16<T>::x4 X4;
   constexpr int M = 16 * MD;
@@ -1137,7 +1137,8 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   // slot tables + Q/dO tiles + the q / dO / out rows of the G global queries (vil_attn_bwd_full)
   const int kv_tiles = (VIL_KV_PIPE && d->M == 32 && bc.kv_KT == 2) ? 4 : 2;       // Q + dO tiles (pipelined kernel: two pairs)
   bc.kv_wave_lds = ((bc.nqs * 16 + kv_tiles * 32 * d->M * 2 + d->G * 3 * d->M * 2 + 15) / 16) * 16;
-  bc.kv_wpw = vil_pick_wpw((size_t)c.tabsize * 4, bc.kv_wave_lds, bc.units_kv_bh, d->M == 32 ? VIL_KV_WAVES : 2);
+  bc.kv_wpw = 4;
+  while (bc.kv_wpw > 1 && (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
   const int groups = (bc.units_kv_bh + bc.kv_wpw - 1) / bc.kv_wpw;
 #ifndef VIL_KV_WGS
 #define VIL_KV_WGS 8192
@@ -1153,7 +1154,8 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   bc.dq_NWP = (g.W * bc.dq_HQ + 15) / 16;
   bc.dq_units_bh = bc.nch * bc.dq_NWP;
   bc.glo_nrec = bc.glo_from_dq ? bc.dq_units_bh + 1 : bc.nsplit;
-  bc.dq_wpw = vil_pick_wpw((size_t)c.tabsize * 8, bc.dq_wave_lds, bc.dq_units_bh, d->M == 32 ? VIL_DQ_WAVES : 2);
+  bc.dq_wpw = 4;
+  while (bc.dq_wpw > 1 && (size_t)c.tabsize * 8 + (size_t)bc.dq_wpw * bc.dq_wave_lds > 160 * 1024) bc.dq_wpw >>= 1;
   {
     const int dgroups = (bc.dq_units_bh + bc.dq_wpw - 1) / bc.dq_wpw;
 #ifndef VIL_DQ_WGS

@@ -195,28 +195,6 @@ __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg
   return __builtin_amdgcn_readfirstlane(padded);
 }
 
-// host: waves per workgroup.  A workgroup shares one LDS bias-table image; with a large image (the one-chunk stages at
-// 24x24: 28 KB, twice that with the dQ histogram) four-wave workgroups fit once per CU and leave ONE wave per SIMD.
-// Pick the size in 4..8 that keeps the most waves resident (LDS and the kernel's register budget) times the
-// fraction of waves that get a unit; ties go to the smaller workgroup.
-static inline int vil_pick_wpw(size_t fixed_bytes, size_t wave_bytes, int units, int reg_waves_per_simd) {
-  int best = 0;
-  double best_score = -1.0;
-  for (int w = 4; w <= 8; ++w) {
-    const size_t lds = fixed_bytes + (size_t)w * wave_bytes;
-    if (lds > 160 * 1024) break;
-    int resident = (int)((160 * 1024) / lds) * w;
-    if (resident > 4 * reg_waves_per_simd) resident = 4 * reg_waves_per_simd;
-    const int groups = (units + w - 1) / w;
-    const double score = resident * ((double)units / ((double)groups * w));
-    if (score > best_score * 1.05) { best_score = score; best = w; }
-  }
-  if (best) return best;
-  int w = 4;
-  while (w > 1 && fixed_bytes + (size_t)w * wave_bytes > 160 * 1024) w >>= 1;
-  return w;
-}
-
 // host: fills the launch configuration for a descriptor
 bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c);
 // device prologue kernel: builds every head's bias table in the workspace
