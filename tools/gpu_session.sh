@@ -73,6 +73,19 @@ for STEP in "$@"; do
       done ;;
     opbench)
       timeout 900 python tools/op_benchmark.py > "$OUT/op_benchmark.jsonl" 2> "$OUT/op_benchmark.err"; cat "$OUT/op_benchmark.jsonl" ;;
+    wgradprobe)   # per-shape vil_linear_wgrad timings at the planner's workgroup targets in WGRAD_TARGETS
+      for W in ${WGRAD_TARGETS:-512 768 1024}; do
+        VIL_WGRAD_WGS=$W timeout 300 python tools/wgrad_probe2.py >> "$OUT/wgrad_probe.txt" 2>&1
+      done
+      cat "$OUT/wgrad_probe.txt" ;;
+    kvtiming)     # per-segment cycle budget of the dK/dV waves (diagnostics build, tools/kv_timing.py)
+      for SH in ${KVT_SHAPES:-small_s1 small_s3_dense}; do
+        for LIB in tools/ab/off/libvilattn_kvtiming*.so; do
+          echo "== $LIB" >> "$OUT/kv_timing.txt"
+          VIL_ATTN_LIB=$PWD/$LIB timeout 300 python tools/kv_timing.py $SH >> "$OUT/kv_timing.txt" 2>&1
+        done
+      done
+      cat "$OUT/kv_timing.txt" ;;
     smoke)
       python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" ;;
     *) echo "unknown step $STEP" ;;

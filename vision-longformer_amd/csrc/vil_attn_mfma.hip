@@ -143,15 +143,13 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
       vtr_off[hf][dt] = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
   }
   const int lgo = lg * 16;
-  int adr1, adc1;
-  shift_neighbour(p, adr1, adc1);
 
   for (int gi = 0; gi < c.gpw; ++gi) {
     const int unit = (wgi * c.gpw + gi) * c.wpw + wave;
     if (unit >= c.units_bh) break;
     const int wp = unit % c.NWP, ch = unit / c.NWP;
     const int cn = ch % g.my, cm = ch / g.my;
-    const int nslots = build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey, adr1, adc1);
+    const int nslots = load_key_slots(c, ch, lane, s_koff, s_akey);
 
     // ---- query slots of this lane: column j of q-tile qt is query (x, y = 4*hq + qt)
     const int jj = wp * 16 + lj;
@@ -357,6 +355,21 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   }
 }
 
+// One 64-thread workgroup per query chunk: its key-slot table (see load_key_slots in vil_mfma_common.h)
+__global__ __launch_bounds__(64) void k_key_slots(VilParams p, MfmaCfg c, int row_stride_b) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ch = blockIdx.x, lane = threadIdx.x;
+  const int cn = ch % p.g.my, cm = ch / p.g.my;
+  int* s_koff = (int*)smem;
+  int* s_akey = s_koff + c.NSP;
+  int adr1, adc1;
+  shift_neighbour(p, adr1, adc1);
+  const int nslots = build_key_slots(p, c, cm, cn, lane, row_stride_b, s_koff, s_akey, adr1, adc1);
+  int2* out = c.key_slots + (int64_t)ch * c.NSP;
+  for (int s = lane; s < nslots; s += 64) out[s] = make_int2(s_koff[s], s_akey[s]);
+  if (lane == 0) c.key_nslots[ch] = nslots;
+}
+
 // ===================================================================== host side
 bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   memset(&c, 0, sizeof(c));
@@ -422,7 +435,8 @@ int vil_mfma_supported(const VilAttnDesc* d, int pass) {
 size_t vil_mfma_workspace(const VilAttnDesc* d, int pass) {
   if (pass != 0) return vil_mfma_bwd_workspace(d);
   MfmaCfg c; vil_mfma_make_cfg(d, c);
-  return (size_t)d->H * c.tabsize * sizeof(float);
+  VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
+  return ((size_t)d->H * c.tabsize + vil_key_slots_floats(c, g.mx * g.my)) * sizeof(float);
 }
 
 int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
@@ -432,8 +446,13 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)tabws) & 15) return VIL_E_ALIGN;
   if ((uintptr_t)p.o & 7) return VIL_E_ALIGN;
   const VilWork w(d);
+  const int nch = p.g.mx * p.g.my;
+  c.key_slots = (int2*)(tabws + (size_t)p.H * c.tabsize);           // (tabsize is a multiple of 4 floats)
+  c.key_nslots = (int*)(c.key_slots + (size_t)nch * c.NSP);
   vil_prof_begin(VIL_K_TABLE, s, 0, 0);
   k_mfma_table<<<dim3((c.tabsize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
+  if (int he = vil_ensure_dyn_lds((const void*)k_key_slots, (size_t)c.NSP * 8)) return he;
+  k_key_slots<<<dim3((unsigned)nch), dim3(64), (size_t)c.NSP * 8, s>>>(p, c, (int)p.k_st * 2);
   vil_prof_end(s);
   int e = (int)hipGetLastError();
   if (e) return e;

@@ -43,6 +43,8 @@ struct BwdCfg {
   int hist_nmax;      // upper bound of contributions one histogram bin can receive in one workgroup
   unsigned* norm2;    // VIL_NORM_SLOTS x 32 words; slot k: [0] max ||dO_q||^2, [1] max ||v_k||^2 as float bits
                       // (partial maxima written by k_mfma_delta); word 2 of slot 0: the histogram scale lfx
+  int2* kv_slots;     // (nch + nsplit, nqs): streamed-query slot tables of the dK/dV pass (k_kv_slots)
+  int* kv_nchunks;    // (nch + nsplit)
 };
 
 // ===================================================================== dQ pass
@@ -153,15 +155,13 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
       krow_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ (SWZ * (((row2 >> 2) & 1) << 5)));
   }
   const int lgo = lg * 16;
-  int adr1, adc1;
-  shift_neighbour(p, adr1, adc1);
 
   for (int gi = 0; gi < bc.dq_gpw; ++gi) {
     const int unit = (wgi * bc.dq_gpw + gi) * bc.dq_wpw + wave;
     if (unit < bc.dq_units_bh) {
       const int wp = unit % bc.dq_NWP, ch = unit / bc.dq_NWP;
       const int cn = ch % g.my, cm = ch / g.my;
-      const int nslots = build_key_slots(p, c, cm, cn, lane, kstride_b, s_koff, s_akey, adr1, adc1);
+      const int nslots = load_key_slots(c, ch, lane, s_koff, s_akey);
       const int jj = wp * 16 + lj;
       const int qx = jj / bc.dq_HQ, qhq = jj % bc.dq_HQ;
       const unsigned aq0b = tab_lds + (min(qx, W - 1) * c.P + QT * qhq) * 4;
@@ -497,6 +497,101 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
 #define VIL_KV_ABL 0       // ablation bits for TIMING diagnostics only (results are wrong when non-zero): 1 no bias gather,
 #endif                     // 2 no exp, 4 no dV/dK MFMAs + transpose reads, 8 no S/dP MFMAs, 16 no global loads, 32 no LDS tiles,
                            // 64 no step loop, 128 no global-row part, 256 no lse / delta gathers in the slot-table build
+// Streamed-query slot tables of the dK/dV pass.  Which query rows a key chunk is attended by, and the bias-table address
+// term of each, depend on the chunk position only -- not on the (image, head) -- so one 64-thread workgroup per key
+// chunk (and per global-key split) builds the table ONCE per call; the dK/dV waves used to rebuild it per (image, head,
+// chunk): ~800 instructions, a fifth of a wave's lifetime at ViL-Small stage 1 (tools/kv_timing.py).
+//   kv_slots[t][s] = (token, 4 * bias address term)   token = -1: padding slot;   kv_nchunks[t] = query chunks streamed
+__global__ __launch_bounds__(64) void k_kv_slots(VilParams p, MfmaCfg c, BwdCfg bc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const VilGeom& g = p.g;
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const bool glo = t >= bc.nch;
+  const int split = t - bc.nch, ch = glo ? 0 : t;
+  const int kn = ch % g.my, km = ch / g.my;
+  const int W = g.W, W2 = g.W2;
+  int* s_tok = (int*)smem;
+  int* s_aq = s_tok + bc.nqs;
+  int adr1, adc1;
+  shift_neighbour(p, adr1, adc1);
+  for (int s = lane; s < bc.nqs; s += 64) { s_tok[s] = -1; s_aq[s] = glo ? 0 : c.aconst * 4; }
+  __syncthreads();
+  int nchunks;
+  if (glo) {
+    nchunks = bc.glo_from_dq ? 0 : (bc.nch - split + bc.nsplit - 1) / bc.nsplit;
+  } else if (p.only_glo) {
+    nchunks = 0;                                   // local keys are attended by nobody
+  } else if (g.exact == -1) {
+    nchunks = g.nact;                              // cyclic: every neighbour offset reaches a chunk (by wrap-around)
+  } else {
+    nchunks = 0;
+    for (int a = 0; a < g.nact; ++a) {
+      const int ar = g.nact == 2 ? (a == 0 ? 0 : adr1) : g.adr[a], ac = g.nact == 2 ? (a == 0 ? 0 : adc1) : g.adc[a];
+      const int m_ = km - ar, n_ = kn - ac;
+      nchunks += (m_ >= 0 && m_ < g.mx && n_ >= 0 && n_ < g.my);
+    }
+  }
+  for (int rid = lane; rid < nchunks * W; rid += 64) {      // one neighbourhood row per lane
+    const int ci = fdiv(rid, c.magicW), xl = rid - ci * W;
+    int qm = -1, qn = -1, dr = 0, dc = 0;
+    if (glo) {
+      const int qch = split + ci * bc.nsplit;
+      qm = qch / g.my; qn = qch - qm * g.my;
+    } else {
+      int cnt = 0;
+      for (int a = 0; a < g.nact; ++a) {
+        const int a3 = (a * 11) >> 5;
+        const int ar = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : adr1);
+        const int ac = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : adc1);
+        int m_ = km - ar, n_ = kn - ac;
+        bool ok = m_ >= 0 && m_ < g.mx && n_ >= 0 && n_ < g.my;
+        if (g.exact == -1) {                     // cyclic: the query chunk that reaches this key chunk through (ar, ac)
+          m_ = m_ < 0 ? m_ + g.mx : (m_ >= g.mx ? m_ - g.mx : m_);
+          n_ = n_ < 0 ? n_ + g.my : (n_ >= g.my ? n_ - g.my : n_);
+          ok = true;
+        }
+        if (ok && cnt == ci) { qm = m_; qn = n_; dr = ar; dc = ac; }
+        cnt += ok;
+      }
+    }
+    const int qr = qm * W + xl;
+    if (qm >= 0 && qr < g.nx) {
+      const int qc0 = qn * W;
+      const int nvalid = min(W, g.ny - qc0);
+      int tok = qr * g.ny + qc0;
+      int aq = glo ? 0 : ((xl - dr * W) * c.P - dc * W + c.aconst) * 4;
+      int s = ci * W2 + xl * W;
+      for (int yl = 0; yl < nvalid; ++yl) {
+        s_tok[s] = tok; s_aq[s] = aq;
+        ++s; ++tok; aq += glo ? 0 : 4;
+      }
+    }
+  }
+  __syncthreads();
+  int2* out = bc.kv_slots + (int64_t)t * bc.nqs;
+  for (int s = lane; s < bc.nqs; s += 64) out[s] = make_int2(s_tok[s], s_aq[s]);
+  if (lane == 0) bc.kv_nchunks[t] = nchunks;
+}
+
+#ifndef VIL_KV_TIMING
+#define VIL_KV_TIMING 0     // diagnostics build only: per-segment s_memtime sums of the dK/dV waves (tools/kv_timing.py)
+#endif
+#if VIL_KV_TIMING
+__device__ unsigned long long vil_kv_timing[16];
+#ifndef VIL_KV_TIMING_EVERY
+#define VIL_KV_TIMING_EVERY 64     // only the waves of every 64th workgroup take stamps: s_memtime at full density slows the kernel 6x
+#endif
+#define KV_STAMP(v) __builtin_amdgcn_sched_barrier(0); unsigned v = 0; if (tme) v = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define KV_ADD(i, a, b) tacc[i] += (b) - (a)
+extern "C" int vil_debug_kv_timing(unsigned long long* host16, int reset) {
+  if (host16 && hipMemcpyFromSymbol(host16, HIP_SYMBOL(vil_kv_timing), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(vil_kv_timing), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define KV_STAMP(v)
+#define KV_ADD(i, a, b)
+#endif
 constexpr int kv_waves(int MD) { return MD == 2 ? VIL_KV_WAVES : 2; }
 template <typename T, int MD, int KT>
 __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
@@ -520,6 +615,11 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   const int wgi = rem_ / p.H, h = rem_ - wgi * p.H;
   const int bh = b * p.H + h;
   const unsigned tab_lds = lds_addr(smem);
+#if VIL_KV_TIMING
+  unsigned tacc[16] = {};
+  const bool tme = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % VIL_KV_TIMING_EVERY)) == 0;
+#endif
+  KV_STAMP(tk0);
 
   float* tab = (float*)smem;
   {
@@ -527,6 +627,8 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
   }
   __syncthreads();
+  KV_STAMP(tk1);
+  KV_ADD(11, tk0, tk1);
 
   char* wbase = smem + (size_t)c.tabsize * 4 + (size_t)wave * bc.kv_wave_lds;
   int* s_tok = (int*)wbase;                       // [nqs] token index of each streamed query slot (Q / dO row)
@@ -570,8 +672,6 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       row_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ (SWZ * (((row2 >> 2) & 1) << 5)));
   }
 
-  int adr1, adc1;
-  shift_neighbour(p, adr1, adc1);
   for (int gi = 0; gi < bc.kv_gpw; ++gi) {
     const int unit = (wgi * bc.kv_gpw + gi) * bc.kv_wpw + wave;
     if (unit >= bc.units_kv_bh) break;
@@ -580,10 +680,10 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     const int wp = glo ? 0 : unit % bc.kv_NWP, ch = glo ? 0 : unit / bc.kv_NWP;
     const int kn = ch % g.my, km = ch / g.my;
 
-    // ---- streamed query slot table: defaults (padding), then one neighbourhood row per lane
-    for (int s = lane; s < bc.nqs; s += 64) {
-      s_tok[s] = 0; s_aq[s] = glo ? 0 : c.aconst * 4; s_lse[s] = LSE_PAD; s_dlt[s] = 0.f;
-    }
+    KV_STAMP(t0);
+    // ---- streamed query slot table: the (token, bias address) columns come from k_kv_slots (one table per key chunk /
+    // global-key split, built once per call); this wave adds the lse / delta of ITS (image, head).  256 slots per
+    // round: table loads, then all gathers, then the LDS stores -- nothing waits on a single round trip.
     if (p.glo_rows) {       // staged now so that the unit's tail does not wait on HBM with one wave per SIMD
       for (int i = lane; i < p.G * 3 * (M / 8); i += 64) {
         const int c8 = i % (M / 8), wh = (i / (M / 8)) % 3, gq = i / (3 * (M / 8));
@@ -593,61 +693,38 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
         *(X8*)(s_gq + i * 16) = *(const X8*)(src + c8 * 8);
       }
     }
-    wave_lds_fence();
-    int nchunks;
-    if (glo) {
-      nchunks = bc.glo_from_dq ? 0 : (bc.nch - split + bc.nsplit - 1) / bc.nsplit;
-    } else if (p.only_glo) {
-      nchunks = 0;                                   // local keys are attended by nobody
-    } else if (g.exact == -1) {
-      nchunks = g.nact;                              // cyclic: every neighbour offset reaches a chunk (by wrap-around)
-    } else {
-      nchunks = 0;
-      for (int a = 0; a < g.nact; ++a) {
-        const int ar = g.nact == 2 ? (a == 0 ? 0 : adr1) : g.adr[a], ac = g.nact == 2 ? (a == 0 ? 0 : adc1) : g.adc[a];
-        const int m_ = km - ar, n_ = kn - ac;
-        nchunks += (m_ >= 0 && m_ < g.mx && n_ >= 0 && n_ < g.my);
-      }
-    }
-    for (int rid = lane; rid < nchunks * W; rid += 64) {
-      const int ci = fdiv(rid, c.magicW), xl = rid - ci * W;
-      int qm = -1, qn = -1, dr = 0, dc = 0;
-      if (glo) {
-        const int qch = split + ci * bc.nsplit;
-        qm = qch / g.my; qn = qch - qm * g.my;
-      } else {
-        int cnt = 0;
-        for (int a = 0; a < g.nact; ++a) {
-          const int a3 = (a * 11) >> 5;
-          const int ar = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : adr1);
-          const int ac = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : adc1);
-          int m_ = km - ar, n_ = kn - ac;
-          bool ok = m_ >= 0 && m_ < g.mx && n_ >= 0 && n_ < g.my;
-          if (g.exact == -1) {                     // cyclic: the query chunk that reaches this key chunk through (ar, ac)
-            m_ = m_ < 0 ? m_ + g.mx : (m_ >= g.mx ? m_ - g.mx : m_);
-            n_ = n_ < 0 ? n_ + g.my : (n_ >= g.my ? n_ - g.my : n_);
-            ok = true;
-          }
-          if (ok && cnt == ci) { qm = m_; qn = n_; dr = ar; dc = ac; }
-          cnt += ok;
+    const int tix = glo ? bc.nch + split : ch;
+    const int nchunks = __builtin_amdgcn_readfirstlane(bc.kv_nchunks[tix]);
+    {
+      const int2* slots = bc.kv_slots + (int64_t)tix * bc.nqs;
+      for (int s0 = 0; s0 < bc.nqs; s0 += 256) {
+        int2 e[4];
+        float l4[4], d4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int sl = s0 + u * 64 + lane;
+          e[u] = slots[min(sl, bc.nqs - 1)];
         }
-      }
-      const int qr = qm * W + xl;
-      if (qm >= 0 && qr < g.nx) {
-        const int qc0 = qn * W;
-        const int nvalid = min(W, g.ny - qc0);
-        int tok = qr * g.ny + qc0;
-        int aq = glo ? 0 : ((xl - dr * W) * c.P - dc * W + c.aconst) * 4;
-        int s = ci * W2 + xl * W;
-        for (int yl = 0; yl < nvalid; ++yl) {
-          s_tok[s] = tok; s_aq[s] = aq;
-          if (VIL_KV_ABL & 256) { s_lse[s] = 1.0f; s_dlt[s] = 0.f; }
-          else { s_lse[s] = lse_bh[tok] * LOG2E; s_dlt[s] = dlt_bh[tok]; }
-          ++s; ++tok; aq += glo ? 0 : 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = max(e[u].x, 0);
+          if (VIL_KV_ABL & 256) { l4[u] = 1.0f; d4[u] = 0.f; }
+          else { l4[u] = lse_bh[t]; d4[u] = dlt_bh[t]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int sl = s0 + u * 64 + lane;
+          if (sl < bc.nqs) {
+            const bool real = e[u].x >= 0;
+            s_tok[sl] = max(e[u].x, 0); s_aq[sl] = e[u].y;
+            s_lse[sl] = real ? l4[u] * LOG2E : LSE_PAD; s_dlt[sl] = real ? d4[u] : 0.f;
+          }
         }
       }
     }
     const int nsteps = (VIL_KV_ABL & 64) ? 0 : (nchunks * W2 + 31) >> 5;
+    KV_STAMP(t1);
+    KV_ADD(0, t0, t1);
 
     // ---- this lane's key slots: column j of key-tile kt is key (x, y = KT*hq + KT-1 - kt)
     const int jj = wp * 16 + lj;
@@ -708,14 +785,19 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       constexpr int sl = decltype(slot_)::value;
       char* sq = s_q + (PIPE ? (st & 1) * 2 * TILE : 0);
       char* sd = sq + TILE;
+      KV_STAMP(ta);
 #pragma unroll
       for (int it = 0; it < MD; ++it) {
         if ((VIL_KV_ABL & 32) && st > 0) break;
         *(u32x4*)(sq + st_off[it]) = qr_[sl][it];
         *(u32x4*)(sd + st_off[it]) = dr_[sl][it];
       }
+      KV_STAMP(ta2);
+      KV_ADD(2, ta, ta2);
       if (st + PF < nsteps) load_step(slot_, st + PF);
       wave_lds_fence();
+      KV_STAMP(tb);
+      KV_ADD(3, ta2, tb);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         X8 qa[MK], da[MK];
@@ -744,12 +826,15 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           sacc[hf][kt] = acc; dpacc[hf][kt] = dp;
         }
       }
+      KV_STAMP(tc);
+      KV_ADD(4, tb, tc);
     };
     // P = exp2(S c - lse), dS = P o (dP - delta);  dV^T += dO^T P ; dK^T += Q^T dS
     auto finish = [&](int st, const f32x4 (&sacc)[2][KT], const f32x4 (&dpacc)[2][KT]) {
       const char* sq = s_q + (PIPE ? (st & 1) * 2 * TILE : 0);
       const char* sd = sq + TILE;
       X8 pb[KT], dsb[KT];
+      KV_STAMP(td);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int sb = st * 32 + hf * 16 + lg * 4;
@@ -764,6 +849,11 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
             dsb[kt][hf * 4 + r] = (T)(pr * dpacc[hf][kt][r]);
           }
       }
+#if VIL_KV_TIMING
+      asm volatile("" :: "v"(pb[0]), "v"(dsb[KT - 1]));
+#endif
+      KV_STAMP(te);
+      KV_ADD(5, td, te);
 #pragma unroll
       for (int dt = 0; dt < MD; ++dt) {
         if (VIL_KV_ABL & 4) {
@@ -787,10 +877,14 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           dk[dt][kt] = mfma16(qt_, dsb[kt], dk[dt][kt]);
         }
       }
+      KV_STAMP(tf);
+      KV_ADD(6, te, tf);
     };
 
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, PF - 1> S1;
+    KV_STAMP(t2);
+    KV_ADD(1, t1, t2);
     if (nsteps > 0) load_step(S0{}, 0);
     if constexpr (PF == 2) { if (nsteps > 1) load_step(S1{}, 1); }
     if constexpr (PIPE) {
@@ -818,6 +912,8 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       }
     }
 
+    KV_STAMP(t3);
+    KV_ADD(7, t2, t3);
     // ---- global-token QUERY rows (vil_attn_bwd_full): G extra queries that attend every key.  The unit's
     // K / V fragments are still in registers: scores by VALU dot products (G is 1..4, no MFMA tile to
     // fill), dK/dV added straight into the accumulators, the unit's share of dq_g / d(bias) to a partial
@@ -918,6 +1014,8 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       }
     }
 
+    KV_STAMP(t4);
+    KV_ADD(8, t3, t4);
     // ---- epilogue
     if (!glo) {
 #pragma unroll
@@ -947,7 +1045,22 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
         }
     }
     wave_lds_fence();
+    KV_STAMP(t5);
+    KV_ADD(9, t4, t5);
+    KV_ADD(10, t0, t5);
+#if VIL_KV_TIMING
+    tacc[12] += 1; tacc[13] += nsteps;
+#endif
   }
+#if VIL_KV_TIMING
+  {
+    KV_STAMP(t6);
+    KV_ADD(14, tk0, t6);
+    tacc[15] = 1;
+    if (lane == 0 && tme)
+      for (int i = 0; i < 16; ++i) atomicAdd(&vil_kv_timing[i], (unsigned long long)tacc[i]);
+  }
+#endif
 }
 
 // One workgroup per (image, head, global token gk):
@@ -1185,28 +1298,31 @@ int vil_mfma_bwd_supported(const VilAttnDesc* d) {
   return VIL_OK;
 }
 
-// floats: [delta | table copies | hist partials | global-key partials]
-static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& bc, size_t off[6]) {
+// floats: [delta | table copies | hist partials | global-key partials | global-query partials | dK/dV slot tables | counts]
+static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& bc, size_t off[9]) {
   const size_t rows = (size_t)d->B * d->H * d->nx * d->ny;
   off[0] = 0;
   off[1] = ((rows + 3) & ~(size_t)3) + 32 * VIL_NORM_SLOTS;      // + norm-maxima slots and the histogram scale
   off[2] = off[1] + (size_t)d->H * c.tabsize;
   off[3] = off[2] + (size_t)bc.dq_nwg * c.tabsize;
   off[4] = off[3] + (size_t)d->B * d->H * bc.glo_nrec * d->G * 2 * d->M;
-  off[5] = off[4] + (size_t)d->B * d->H * (bc.nch * bc.kv_NWP + 1) * d->G * (d->M + 4);
+  off[5] = (off[4] + (size_t)d->B * d->H * (bc.nch * bc.kv_NWP + 1) * d->G * (d->M + 4) + 3) & ~(size_t)3;
+  off[6] = off[5] + (size_t)(bc.nch + bc.nsplit) * bc.nqs * 2;                    // dK/dV slot tables (int2)
+  off[7] = off[6] + (((size_t)(bc.nch + bc.nsplit) + 3) & ~(size_t)3);             // their chunk counts
+  off[8] = off[7] + vil_key_slots_floats(c, bc.nch);                               // key-slot tables of the dQ pass
 }
 
 size_t vil_mfma_bwd_workspace(const VilAttnDesc* d) {
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   BwdCfg bc; bwd_cfg(d, c, bc);
-  size_t off[6]; bwd_ws_layout(d, c, bc, off);
-  return off[5] * sizeof(float) + 64;
+  size_t off[9]; bwd_ws_layout(d, c, bc, off);
+  return off[8] * sizeof(float) + 64;
 }
 
 int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   BwdCfg bc; bwd_cfg(d, c, bc);
-  size_t off[6]; bwd_ws_layout(d, c, bc, off);
+  size_t off[9]; bwd_ws_layout(d, c, bc, off);
   float* ws = (float*)p.delta;
   if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.dout | (uintptr_t)p.out | (uintptr_t)ws) & 15)
     return VIL_E_ALIGN;
@@ -1217,11 +1333,14 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   bc.hist_parts = ws + off[2];
   bc.glo_parts = ws + off[3];
   bc.gq_parts = ws + off[4];
+  bc.kv_slots = (int2*)(ws + off[5]);
+  bc.kv_nchunks = (int*)(ws + off[6]);
+  c.key_slots = (int2*)(ws + off[7]);
+  c.key_nslots = (int*)(c.key_slots + (size_t)bc.nch * c.NSP);
   bc.do_hist = (p.dtable != nullptr) || (p.dg2l != nullptr);
   bc.norm2 = (unsigned*)(ws + off[1] - 32 * VIL_NORM_SLOTS);
   bc.hist_nmax = p.g.W2 * bc.dq_gpw * bc.dq_wpw;
   const VilWork w(d);
-  const int64_t rows = (int64_t)p.B * p.H * p.g.nx * p.g.ny;
   int e;
 #define BWD_SWITCH_T(T_, ...)                    \
   switch (d->M) {                                \
@@ -1237,6 +1356,11 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   vil_prof_begin(VIL_K_TABLE, s, 0, 0);
   k_mfma_table<<<dim3((c.tabsize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
   vil_prof_end(s);
+  if ((e = (int)hipGetLastError())) return e;
+  if (int he = vil_ensure_dyn_lds((const void*)k_key_slots, (size_t)c.NSP * 8)) return he;
+  if (int he = vil_ensure_dyn_lds((const void*)k_kv_slots, (size_t)bc.nqs * 8)) return he;
+  k_key_slots<<<dim3((unsigned)bc.nch), dim3(64), (size_t)c.NSP * 8, s>>>(p, c, (int)p.k_st * 2);
+  k_kv_slots<<<dim3((unsigned)(bc.nch + bc.nsplit)), dim3(64), (size_t)bc.nqs * 8, s>>>(p, c, bc);
   if ((e = (int)hipGetLastError())) return e;
   {
     const int na = 32 * VIL_NORM_SLOTS, nb = p.dg2l ? p.H * p.G : 0;

@@ -52,6 +52,8 @@ struct MfmaCfg {
   int wpw;           // waves per workgroup (4, or fewer when the per-wave LDS is large)
   int wave_lds;      // bytes of private LDS per wave (forward / dQ pass)
   const float* tabws;  // (H, tabsize) prepared bias tables
+  int2* key_slots;     // (mx*my, NSP): key-slot table of every query chunk (k_key_slots), .x = K/V row byte offset, .y = bias term
+  int* key_nslots;     // (mx*my): padded slot count of each
 };
 
 __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned magic) { return __umulhi(n, magic); }
@@ -193,6 +195,32 @@ __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg
   for (int s = total + lane; s < padded; s += 64) { s_koff[s] = own_off; s_akey[s] = -c.guard0 * 4; }
   wave_lds_fence();
   return __builtin_amdgcn_readfirstlane(padded);
+}
+
+// The key-slot table depends on the chunk position only, not on the (image, head): k_key_slots builds the table of every
+// chunk once per call (one 64-thread workgroup each, build_key_slots into LDS, copied out), and a forward / dQ wave
+// fetches its chunk's table with a few independent 8-byte loads.  Each wave used to run build_key_slots itself:
+// ~800 instructions and a wave prefix sum per (image, head, chunk) -- 10-20 % of a wave's lifetime (tools/kv_timing.py).
+__device__ __forceinline__ int load_key_slots(const MfmaCfg& c, int ch, int lane, int* s_koff, int* s_akey) {
+  const int nslots = __builtin_amdgcn_readfirstlane(c.key_nslots[ch]);
+  const int2* src = c.key_slots + (int64_t)ch * c.NSP;
+  for (int s0 = 0; s0 < nslots; s0 += 512) {
+    int2 e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) e[u] = src[min(s0 + u * 64 + lane, nslots - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u * 64 + lane;
+      if (s < nslots) { s_koff[s] = e[u].x; s_akey[s] = e[u].y; }
+    }
+  }
+  wave_lds_fence();
+  return nslots;
+}
+__global__ void k_key_slots(VilParams p, MfmaCfg c, int row_stride_b);
+// floats of workspace behind the bias tables for the key-slot tables (16-byte multiple)
+static inline size_t vil_key_slots_floats(const MfmaCfg& c, int nch) {
+  return (size_t)nch * c.NSP * 2 + (((size_t)nch + 3) & ~(size_t)3);
 }
 
 // host: fills the launch configuration for a descriptor
