@@ -19,6 +19,7 @@
 // Reference semantics: SlidingChunk2D.backward (src/models/layers/slidingchunk_2d.py:234-246)
 // plus the autograd of bias gather / mask / softmax in longformer2d.py:152-200.
 #include "vil_mfma_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 #define LSE_PAD 1.0e30f
@@ -333,20 +334,26 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
       // dS^T = P^T o (dP^T - delta) (+ the bias-gradient histogram), then dQ^T += K^T dS^T
       auto finish = [&](int st, const f32x4 (&sacc)[2][QT], const f32x4 (&dpacc)[2][QT], const unsigned (&i0)[2][4]) {
         const char* sk = s_k + (PIPE ? (st & 1) * (32 * M * 2) : 0);
-        X8 dsb[QT];
+        u32x4 dsw[QT];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-          for (int qt = 0; qt < QT; ++qt)
+          for (int qt = 0; qt < QT; ++qt) {
+            float ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][qt][r], c1, -lse2[qt]));
-              const float ds = pr * dpacc[hf][qt][r];
-              dsb[qt][hf * 4 + r] = (T)ds;
+              ds[r] = pr * dpacc[hf][qt][r];
               if (bc.do_hist)
-                __hip_atomic_fetch_add(lds_i32(i0[hf][r] + hist_off) + qt, __float2int_rn(FOLD ? ds : ds * hscale),
+                __hip_atomic_fetch_add(lds_i32(i0[hf][r] + hist_off) + qt, __float2int_rn(FOLD ? ds[r] : ds[r] * hscale),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            dsw[qt][hf * 2] = pack2<T>((f32x2){ds[0], ds[1]});
+            dsw[qt][hf * 2 + 1] = pack2<T>((f32x2){ds[2], ds[3]});
+          }
+        X8 dsb[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) dsb[qt] = __builtin_bit_cast(X8, dsw[qt]);
 #pragma unroll
         for (int dt = 0; dt < MD; ++dt) {
           X8 kt_;
@@ -833,24 +840,33 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     auto finish = [&](int st, const f32x4 (&sacc)[2][KT], const f32x4 (&dpacc)[2][KT]) {
       const char* sq = s_q + (PIPE ? (st & 1) * 2 * TILE : 0);
       const char* sd = sq + TILE;
-      X8 pb[KT], dsb[KT];
+      u32x4 pbw[KT], dsw[KT];       // the 8 packed 16-bit operand values of each key tile, as dwords (2 per query half)
       KV_STAMP(td);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int sb = st * 32 + hf * 16 + lg * 4;
         const f32x4 ls4 = *(const f32x4*)(s_lse + sb);
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int kt = 0; kt < KT; ++kt) {
+          float pr[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pr = (VIL_KV_ABL & 2) ? __builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r])
-                                              : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r]));
-            pb[kt][hf * 4 + r] = (T)pr;
-            dsb[kt][hf * 4 + r] = (T)(pr * dpacc[hf][kt][r]);
+          for (int r = 0; r < 4; ++r)
+            pr[r] = (VIL_KV_ABL & 2) ? __builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r])
+                                     : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r]));
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const f32x2 p2 = {pr[2 * h2], pr[2 * h2 + 1]};
+            const f32x2 d2 = {dpacc[hf][kt][2 * h2], dpacc[hf][kt][2 * h2 + 1]};
+            pbw[kt][hf * 2 + h2] = pack2<T>(p2);
+            dsw[kt][hf * 2 + h2] = pack2<T>(p2 * d2);
           }
+        }
       }
+      X8 pb[KT], dsb[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) { pb[kt] = __builtin_bit_cast(X8, pbw[kt]); dsb[kt] = __builtin_bit_cast(X8, dsw[kt]); }
 #if VIL_KV_TIMING
-      asm volatile("" :: "v"(pb[0]), "v"(dsb[KT - 1]));
+      asm volatile("" :: "v"(pbw[0]), "v"(pbw[KT - 1]), "v"(dsw[0]), "v"(dsw[KT - 1]));
 #endif
       KV_STAMP(te);
       KV_ADD(5, td, te);
@@ -1388,7 +1404,9 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     if ((e = (int)hipGetLastError())) return e;
   }
   {
-    const size_t lds = kv_lds(c, bc);
+    // (diagnostics: VIL_DEBUG_KV_LDS_PAD=<bytes> of unused LDS per workgroup lowers the resident waves per SIMD)
+    static const size_t pad = [] { const char* e_ = getenv("VIL_DEBUG_KV_LDS_PAD"); return e_ ? (size_t)atol(e_) : (size_t)0; }();
+    const size_t lds = kv_lds(c, bc) + pad;
     const unsigned grid = (unsigned)(p.B * p.H * bc.kv_wg_per_bh);
     vil_prof_begin(VIL_K_MFMA_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
     BWD_SWITCH({

@@ -14,7 +14,15 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct V16 {
   typedef T x8 __attribute__((ext_vector_type(8)));
   typedef T x4 __attribute__((ext_vector_type(4)));
+  typedef T x2 __attribute__((ext_vector_type(2)));
 };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> one dword of two 16-bit values (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32): written as a vector conversion so
+// that the pairing is fixed in the source (left to the SLP vectoriser, scalar conversions next to packed multiplies
+// came out paired across the operand dwords and were re-assembled with v_alignbit / v_perm)
+template <typename T> __device__ __forceinline__ unsigned pack2(f32x2 v) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, typename V16<T>::x2));
+}
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
