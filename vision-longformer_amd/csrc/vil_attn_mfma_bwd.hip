@@ -53,6 +53,9 @@ struct BwdCfg {
 // SIMD instead of one; same reasoning as KT of the dK/dV pass)
 // Tuning switches (see vil_attn_mfma.hip).  ViL-Small stage 1, round-1 kernel 407 us: ring 1 / 3 waves 367 us (default);
 // ring 2 / 3 waves 398; ring 1 / 4 waves (128 VGPRs, 36 B scratch) 389; software pipeline (219 VGPRs, 2 waves) 460.
+#ifndef VIL_DQ_ABL
+#define VIL_DQ_ABL 0       // ablation bits for TIMING diagnostics only (wrong results): 1 no histogram atomics in the step loop
+#endif
 #ifndef VIL_DQ_PIPE
 #define VIL_DQ_PIPE 0      // software pipeline over steps at head_dim 32
 #endif
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
             for (int r = 0; r < 4; ++r) {
               const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][qt][r], c1, -lse2[qt]));
               ds[r] = pr * dpacc[hf][qt][r];
-              if (bc.do_hist)
+              if (bc.do_hist && !(VIL_DQ_ABL & 1))
                 __hip_atomic_fetch_add(lds_i32(i0[hf][r] + hist_off) + qt, __float2int_rn(FOLD ? ds[r] : ds[r] * hscale),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -580,6 +583,9 @@ __global__ __launch_bounds__(64) void k_kv_slots(VilParams p, MfmaCfg c, BwdCfg 
   if (lane == 0) bc.kv_nchunks[t] = nchunks;
 }
 
+#ifndef VIL_KV_PKFMA
+#define VIL_KV_PKFMA 0      // exponent arguments by v_pk_fma_f32 (two scores per instruction)
+#endif
 #ifndef VIL_KV_TIMING
 #define VIL_KV_TIMING 0     // diagnostics build only: per-segment s_memtime sums of the dK/dV waves (tools/kv_timing.py)
 #endif
@@ -849,10 +855,21 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
           float pr[4];
+#if VIL_KV_PKFMA
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const f32x2 s2 = {sacc[hf][kt][2 * h2], sacc[hf][kt][2 * h2 + 1]};
+            const f32x2 l2 = {ls4[2 * h2], ls4[2 * h2 + 1]};
+            const f32x2 t2 = __builtin_elementwise_fma(s2, (f32x2){c1, c1}, -l2);
+            pr[2 * h2] = (VIL_KV_ABL & 2) ? t2[0] : __builtin_amdgcn_exp2f(t2[0]);
+            pr[2 * h2 + 1] = (VIL_KV_ABL & 2) ? t2[1] : __builtin_amdgcn_exp2f(t2[1]);
+          }
+#else
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             pr[r] = (VIL_KV_ABL & 2) ? __builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r])
                                      : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r]));
+#endif
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
             const f32x2 p2 = {pr[2 * h2], pr[2 * h2 + 1]};
