@@ -22,7 +22,10 @@
  * (a hipStream_t passed as void*), never allocate device memory and never
  * synchronise -- the two documented exceptions synchronise by design:
  * vil_gemm_tune and vil_attn_profile_end.  Process-global state: the
- * profiling sink and the GEMM plan cache (both described at their entry points).  Return value: 0 = success, negative = argument error
+ * profiling sink, the GEMM plan cache (both described at their entry points) and the record of which kernels
+ * already had their dynamic-LDS limit raised.  Two environment variables are read once, for measurements only:
+ * VIL_WGRAD_WGS (workgroup target of vil_linear_wgrad's planner) and VIL_DEBUG_KV_LDS_PAD (unused LDS bytes added
+ * to the dK/dV launch to lower its residency).  Return value: 0 = success, negative = argument error
  * (VIL_E_*), positive = hipError_t of the failing launch.
  *
  * Tensor layout: q is addressed as q[b*q_sb + i*q_st + h*q_sh + d] with

@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   // back to back on one XCD, so both 64-byte halves (two heads) of every K / V cache line are consumed while the
   // line is L2-resident, and the in-flight K/V footprint of an XCD is H times smaller than with (image, head, ...)
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = logical / (c.wg_per_bh * p.H), rem_ = logical - b * (c.wg_per_bh * p.H);
-  const int wgi = rem_ / p.H, h = rem_ - wgi * p.H;
+  const int b = fdiv(logical, c.m_wgbh), rem_ = logical - b * (c.wg_per_bh * p.H);
+  const int wgi = fdiv(rem_, c.m_H), h = rem_ - wgi * p.H;
   const int bh = b * p.H + h;
 
   float* tab = (float*)smem;
@@ -147,13 +147,13 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   for (int gi = 0; gi < c.gpw; ++gi) {
     const int unit = (wgi * c.gpw + gi) * c.wpw + wave;
     if (unit >= c.units_bh) break;
-    const int wp = unit % c.NWP, ch = unit / c.NWP;
-    const int cn = ch % g.my, cm = ch / g.my;
+    const int ch = fdiv(unit, c.m_NWP), wp = unit - ch * c.NWP;
+    const int cm = fdiv(ch, c.m_my), cn = ch - cm * g.my;
     const int nslots = load_key_slots(c, ch, lane, s_koff, s_akey);
 
     // ---- query slots of this lane: column j of q-tile qt is query (x, y = 4*hq + qt)
     const int jj = wp * 16 + lj;
-    const int qx = jj / c.HQ, qhq = jj % c.HQ;
+    const int qx = fdiv(jj, c.m_HQ), qhq = jj - qx * c.HQ;
     const unsigned aq0b = tab_lds + (min(qx, W - 1) * c.P + 4 * qhq) * 4;   // LDS byte address; + 4*qt per q-tile
     int qtok[4];
     bool qreal[4];
@@ -388,8 +388,8 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   c.glo0 = c.guard0 + c.gsz;
   c.tabsize = ((c.glo0 + d->G * c.gsz + 4 + 3) / 4) * 4;
   c.aconst = c.tcen * (P + 1) + VIL_CPAD;
-  c.magicW = (unsigned)(0x100000000ull / (unsigned)W) + 1;
-  c.magicW2 = (unsigned)(0x100000000ull / (unsigned)(W * W)) + 1;
+  c.magicW = vil_magic((unsigned)W);
+  c.magicW2 = vil_magic((unsigned)(W * W));
   c.NS = d->G + g.nact * g.W2;
   c.NSP = (c.NS + 31) & ~31;
   c.units_bh = g.mx * g.my * c.NWP;
@@ -407,6 +407,8 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   if (gpw > groups) gpw = groups;
   c.gpw = gpw;
   c.wg_per_bh = (groups + gpw - 1) / gpw;
+  c.m_wgbh = vil_magic((unsigned)(c.wg_per_bh * d->H)); c.m_H = vil_magic((unsigned)d->H);
+  c.m_NWP = vil_magic((unsigned)c.NWP); c.m_my = vil_magic((unsigned)g.my); c.m_HQ = vil_magic((unsigned)c.HQ);
   return true;
 }
 
@@ -429,6 +431,8 @@ int vil_mfma_supported(const VilAttnDesc* d, int pass) {
     return VIL_E_BACKEND;
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   if (mfma_lds_bytes(c) > 160 * 1024) return VIL_E_BACKEND;
+  // the workgroup index is decoded with magic-number divisions, exact for index * divisor < 2^32 (fdiv)
+  if ((uint64_t)d->B * d->H * c.wg_per_bh * ((uint64_t)c.wg_per_bh * d->H) >= (1ull << 32)) return VIL_E_BACKEND;
   return pass == 0 ? VIL_OK : vil_mfma_bwd_supported(d);
 }
 

@@ -44,6 +44,7 @@ struct BwdCfg {
   int hist_nmax;      // upper bound of contributions one histogram bin can receive in one workgroup
   unsigned* norm2;    // VIL_NORM_SLOTS x 32 words; slot k: [0] max ||dO_q||^2, [1] max ||v_k||^2 as float bits
                       // (partial maxima written by k_mfma_delta); word 2 of slot 0: the histogram scale lfx
+  unsigned m_dq_wgbh, m_dq_NWP, m_dq_HQ, m_kv_wgbh, m_kv_NWP, m_kv_HQ;   // magic reciprocals (vil_magic, fdiv)
   int2* kv_slots;     // (nch + nsplit, nqs): streamed-query slot tables of the dK/dV pass (k_kv_slots)
   int* kv_nchunks;    // (nch + nsplit)
 };
@@ -84,8 +85,8 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
 
   // (image, workgroup-of-chunks, head) order: see k_mfma_fwd
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = logical / (bc.dq_wg_per_bh * p.H), rem_ = logical - b * (bc.dq_wg_per_bh * p.H);
-  const int wgi = rem_ / p.H, h = rem_ - wgi * p.H;
+  const int b = fdiv(logical, bc.m_dq_wgbh), rem_ = logical - b * (bc.dq_wg_per_bh * p.H);
+  const int wgi = fdiv(rem_, c.m_H), h = rem_ - wgi * p.H;
   const int bh = b * p.H + h;
 
   float* tab = (float*)smem;
@@ -163,11 +164,11 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
   for (int gi = 0; gi < bc.dq_gpw; ++gi) {
     const int unit = (wgi * bc.dq_gpw + gi) * bc.dq_wpw + wave;
     if (unit < bc.dq_units_bh) {
-      const int wp = unit % bc.dq_NWP, ch = unit / bc.dq_NWP;
-      const int cn = ch % g.my, cm = ch / g.my;
+      const int ch = fdiv(unit, bc.m_dq_NWP), wp = unit - ch * bc.dq_NWP;
+      const int cm = fdiv(ch, c.m_my), cn = ch - cm * g.my;
       const int nslots = load_key_slots(c, ch, lane, s_koff, s_akey);
       const int jj = wp * 16 + lj;
-      const int qx = jj / bc.dq_HQ, qhq = jj % bc.dq_HQ;
+      const int qx = fdiv(jj, bc.m_dq_HQ), qhq = jj - qx * bc.dq_HQ;
       const unsigned aq0b = tab_lds + (min(qx, W - 1) * c.P + QT * qhq) * 4;
       int qtok[QT];
       bool qreal[QT];
@@ -624,8 +625,8 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
 
   // (image, workgroup-of-chunks, head) order: see k_mfma_fwd
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = logical / (bc.kv_wg_per_bh * p.H), rem_ = logical - b * (bc.kv_wg_per_bh * p.H);
-  const int wgi = rem_ / p.H, h = rem_ - wgi * p.H;
+  const int b = fdiv(logical, bc.m_kv_wgbh), rem_ = logical - b * (bc.kv_wg_per_bh * p.H);
+  const int wgi = fdiv(rem_, c.m_H), h = rem_ - wgi * p.H;
   const int bh = b * p.H + h;
   const unsigned tab_lds = lds_addr(smem);
 #if VIL_KV_TIMING
@@ -690,8 +691,8 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     if (unit >= bc.units_kv_bh) break;
     const bool glo = unit >= nown;                 // global-key owner unit
     const int split = unit - nown;
-    const int wp = glo ? 0 : unit % bc.kv_NWP, ch = glo ? 0 : unit / bc.kv_NWP;
-    const int kn = ch % g.my, km = ch / g.my;
+    const int ch = glo ? 0 : fdiv(unit, bc.m_kv_NWP), wp = glo ? 0 : unit - ch * bc.kv_NWP;
+    const int km = fdiv(ch, c.m_my), kn = ch - km * g.my;
 
     KV_STAMP(t0);
     // ---- streamed query slot table: the (token, bias address) columns come from k_kv_slots (one table per key chunk /
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
 
     // ---- this lane's key slots: column j of key-tile kt is key (x, y = KT*hq + KT-1 - kt)
     const int jj = wp * 16 + lj;
-    const int kx = jj / bc.kv_HQ, khq = jj % bc.kv_HQ;
+    const int kx = fdiv(jj, bc.m_kv_HQ), khq = jj - kx * bc.kv_HQ;
     const unsigned akl = (unsigned)(glo ? -(c.glo0 + min(lj, max(p.G - 1, 0)) * c.gsz) * 4
                                         : (min(kx, W - 1) * c.P + KT * khq + KT - 1) * 4) - tab_lds;
     int ktok[KT];
@@ -1314,6 +1315,10 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
     bc.dq_wg_per_bh = (dgroups + dgpw - 1) / dgpw;
   }
   bc.dq_nwg = d->B * d->H * bc.dq_wg_per_bh;
+  bc.m_dq_wgbh = vil_magic((unsigned)(bc.dq_wg_per_bh * d->H)); bc.m_dq_NWP = vil_magic((unsigned)bc.dq_NWP);
+  bc.m_dq_HQ = vil_magic((unsigned)bc.dq_HQ);
+  bc.m_kv_wgbh = vil_magic((unsigned)(bc.kv_wg_per_bh * d->H)); bc.m_kv_NWP = vil_magic((unsigned)bc.kv_NWP);
+  bc.m_kv_HQ = vil_magic((unsigned)bc.kv_HQ);
 }
 
 static size_t dq_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.tabsize * 8 + (size_t)bc.dq_wpw * bc.dq_wave_lds; }
@@ -1328,6 +1333,8 @@ int vil_mfma_bwd_supported(const VilAttnDesc* d) {
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   BwdCfg bc; bwd_cfg(d, c, bc);
   if (dq_lds(c, bc) > 160 * 1024 || kv_lds(c, bc) > 160 * 1024) return VIL_E_BACKEND;
+  for (uint64_t w : {(uint64_t)bc.dq_wg_per_bh, (uint64_t)bc.kv_wg_per_bh})      // fdiv exactness, see vil_mfma_supported
+    if ((uint64_t)d->B * d->H * w * (w * d->H) >= (1ull << 32)) return VIL_E_BACKEND;
   return VIL_OK;
 }
 

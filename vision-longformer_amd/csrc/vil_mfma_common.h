@@ -51,6 +51,7 @@ struct MfmaCfg {
   int gsz;           // size of one such region (>= Aq range)
   int aconst;
   unsigned magicW, magicW2;
+  unsigned m_wgbh, m_H, m_NWP, m_my, m_HQ;   // magic reciprocals (vil_magic) of wg_per_bh*H, H, NWP, my, HQ
   int HQ;            // query quads per chunk row = ceil(W/4)
   int NWP;           // waves per chunk = ceil(W*HQ/16)
   int NS;            // real key slots = G + nact*W2
@@ -64,7 +65,11 @@ struct MfmaCfg {
   int* key_nslots;     // (mx*my): padded slot count of each
 };
 
-__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned magic) { return __umulhi(n, magic); }
+// n / d for a run-time divisor without the ~25-instruction integer division sequence: magic = floor(2^32 / d) + 1
+// (host: vil_magic), exact for n * d < 2^32 (the host checks the largest n of every use); magic 0 encodes d == 1.
+// The kernels decode (image, head, chunk, row, column) from the workgroup index with six such divisions per wave.
+__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
+static inline unsigned vil_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / d) + 1u; }
 
 // LDS byte address of a __shared__ object as a plain integer, and a dword read at such an address.  The bias
 // gather of the MFMA kernels is `table[Aq - Ak + qt]` for 4 keys (r) x 4 queries (qt) per lane: written through
