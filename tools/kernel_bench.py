@@ -35,7 +35,6 @@ def main():
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--backend", default="auto")
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--no-bias-grad", action="store_true", help="bias table / g2l without gradient: the dQ pass runs without its histogram")
     a = ap.parse_args()
     H, M, W, nx, ny, G, mode, B = SHAPES[a.shape]
     B = a.batch or B
@@ -44,8 +43,8 @@ def main():
     C = H * M
     q = (torch.randn(B, nx * ny, C, generator=g) ).to(dev, torch.bfloat16).requires_grad_(not a.fwd_only)
     kv = torch.randn(B, G + nx * ny, 2 * C, generator=g).to(dev, torch.bfloat16).requires_grad_(not a.fwd_only)
-    table = (torch.randn((4 * W - 1) ** 2, H, generator=g) * 0.02).to(dev).requires_grad_(not a.fwd_only and not a.no_bias_grad)
-    g2l = (torch.randn(H, G, generator=g) * 0.02).to(dev).requires_grad_(not a.fwd_only and not a.no_bias_grad)
+    table = (torch.randn((4 * W - 1) ** 2, H, generator=g) * 0.02).to(dev).requires_grad_(not a.fwd_only)
+    g2l = (torch.randn(H, G, generator=g) * 0.02).to(dev).requires_grad_(not a.fwd_only)
     dout = torch.randn(B, nx * ny, C, generator=g).to(dev, torch.bfloat16)
     kw = dict(nx=nx, ny=ny, w=W, nglo=G, num_heads=H, mode=mode, backend=a.backend)
     dense = a.shape.endswith("_dense")
