@@ -24,8 +24,7 @@ s0, s1 = idx[-1 - nsteps * per], idx[-1]
 t0, t1 = int(rows[s0]["Start_Timestamp"]), int(rows[s1]["Start_Timestamp"])
 def classify(n):
     if n.startswith("Cijk"): return "gemm(hipblaslt)"
-    if ("k_mfma" in n or "k_delta" in n or "k_reduce" in n or "k_scalar" in n or "k_glo_" in n or "k_key_slots" in n
-            or "k_kv_slots" in n): return "vil hot path"
+    if "k_mfma" in n or "k_delta" in n or "k_reduce" in n or "k_scalar" in n or "k_glo_" in n: return "vil hot path"
     if "k_ln_" in n: return "vil layernorm"
     if "layer_norm" in n or "cuCompute" in n: return "torch layernorm"
     if "attn_fwd" in n or "bwd_kernel" in n or "attn_bwd" in n: return "sdpa (dense attn)"

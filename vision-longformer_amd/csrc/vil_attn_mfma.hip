@@ -29,30 +29,16 @@
 #include "vil_mfma_common.h"
 #include <type_traits>
 
-// ------------------------------------------------------------------ table prologue
-__global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out) {
-  const int h = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= c.tabsize) return;
-  const int tbl = c.trows, W = p.g.W;
-  const float inv = 1.0f / p.scale;
-  float v = 0.f;
-  if (e < tbl * c.P) {
-    const int row = e / c.P, col = e % c.P - VIL_CPAD;
-    if (col >= 0 && col < tbl) {
-      const int dx = row - c.tcen, dy = col - c.tcen;
-      const int o = p.bias_off, S = p.bias_S;      // the caller's table covers |dx|,|dy| <= o
-      if (p.has_bias && dx >= -o && dx <= o && dy >= -o && dy <= o)
-        v = p.table[(int64_t)((dx + o) * S + (dy + o)) * p.H + h] * inv;
-      if (p.g.exact == 1 && (dx > W || dx < -W || dy > W || dy < -W)) v = VIL_MASK_VAL;
-    }
-  } else if (e < c.glo0) {
-    v = VIL_MASK_VAL;
-  } else {
-    const int g = (e - c.glo0) / c.gsz;
-    if (g < p.G && p.has_g2l) v = p.g2l[h * p.G + g] * inv;
+// ------------------------------------------------------------------ prologue (tables: see vil_mfma_common.h)
+__global__ __launch_bounds__(256) void k_mfma_prep(VilParams p, MfmaCfg c, int row_stride_b, int ntx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int blk = blockIdx.x, ntab = ntx * p.H;
+  if (blk < ntab) {
+    const int h = blk / ntx, bx = blk - h * ntx;
+    table_element(p, c, (float*)c.tabws, h, bx * 256 + threadIdx.x);
+  } else if (threadIdx.x < 64) {
+    key_slots_block(p, c, blk - ntab, threadIdx.x, row_stride_b, smem);
   }
-  out[(int64_t)h * c.tabsize + e] = v;
 }
 
 // ------------------------------------------------------------------ forward
@@ -355,21 +341,6 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   }
 }
 
-// One 64-thread workgroup per query chunk: its key-slot table (see load_key_slots in vil_mfma_common.h)
-__global__ __launch_bounds__(64) void k_key_slots(VilParams p, MfmaCfg c, int row_stride_b) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int ch = blockIdx.x, lane = threadIdx.x;
-  const int cn = ch % p.g.my, cm = ch / p.g.my;
-  int* s_koff = (int*)smem;
-  int* s_akey = s_koff + c.NSP;
-  int adr1, adc1;
-  shift_neighbour(p, adr1, adc1);
-  const int nslots = build_key_slots(p, c, cm, cn, lane, row_stride_b, s_koff, s_akey, adr1, adc1);
-  int2* out = c.key_slots + (int64_t)ch * c.NSP;
-  for (int s = lane; s < nslots; s += 64) out[s] = make_int2(s_koff[s], s_akey[s]);
-  if (lane == 0) c.key_nslots[ch] = nslots;
-}
-
 // ===================================================================== host side
 bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   memset(&c, 0, sizeof(c));
@@ -454,9 +425,11 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   c.key_slots = (int2*)(tabws + (size_t)p.H * c.tabsize);           // (tabsize is a multiple of 4 floats)
   c.key_nslots = (int*)(c.key_slots + (size_t)nch * c.NSP);
   vil_prof_begin(VIL_K_TABLE, s, 0, 0);
-  k_mfma_table<<<dim3((c.tabsize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
-  if (int he = vil_ensure_dyn_lds((const void*)k_key_slots, (size_t)c.NSP * 8)) return he;
-  k_key_slots<<<dim3((unsigned)nch), dim3(64), (size_t)c.NSP * 8, s>>>(p, c, (int)p.k_st * 2);
+  {
+    const int ntx = (c.tabsize + 255) / 256;
+    if (int he = vil_ensure_dyn_lds((const void*)k_mfma_prep, (size_t)c.NSP * 8)) return he;
+    k_mfma_prep<<<dim3((unsigned)(ntx * p.H + nch)), dim3(256), (size_t)c.NSP * 8, s>>>(p, c, (int)p.k_st * 2, ntx);
+  }
   vil_prof_end(s);
   int e = (int)hipGetLastError();
   if (e) return e;

@@ -45,7 +45,7 @@ struct BwdCfg {
   unsigned* norm2;    // VIL_NORM_SLOTS x 32 words; slot k: [0] max ||dO_q||^2, [1] max ||v_k||^2 as float bits
                       // (partial maxima written by k_mfma_delta); word 2 of slot 0: the histogram scale lfx
   unsigned m_dq_wgbh, m_dq_NWP, m_dq_HQ, m_kv_wgbh, m_kv_NWP, m_kv_HQ;   // magic reciprocals (vil_magic, fdiv)
-  int2* kv_slots;     // (nch + nsplit, nqs): streamed-query slot tables of the dK/dV pass (k_kv_slots)
+  int2* kv_slots;     // (nch + nsplit, nqs): streamed-query slot tables of the dK/dV pass (kv_slots_block)
   int* kv_nchunks;    // (nch + nsplit)
 };
 
@@ -509,14 +509,13 @@ __global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
 #endif                     // 2 no exp, 4 no dV/dK MFMAs + transpose reads, 8 no S/dP MFMAs, 16 no global loads, 32 no LDS tiles,
                            // 64 no step loop, 128 no global-row part, 256 no lse / delta gathers in the slot-table build
 // Streamed-query slot tables of the dK/dV pass.  Which query rows a key chunk is attended by, and the bias-table address
-// term of each, depend on the chunk position only -- not on the (image, head) -- so one 64-thread workgroup per key
-// chunk (and per global-key split) builds the table ONCE per call; the dK/dV waves used to rebuild it per (image, head,
+// term of each, depend on the chunk position only -- not on the (image, head) -- so one wave per key
+// chunk (and per global-key split) builds the table ONCE per call (a role of k_mfma_prep_bwd); the dK/dV waves used to rebuild it per (image, head,
 // chunk): ~800 instructions, a fifth of a wave's lifetime at ViL-Small stage 1 (tools/kv_timing.py).
 //   kv_slots[t][s] = (token, 4 * bias address term)   token = -1: padding slot;   kv_nchunks[t] = query chunks streamed
-__global__ __launch_bounds__(64) void k_kv_slots(VilParams p, MfmaCfg c, BwdCfg bc) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void kv_slots_block(const VilParams& p, const MfmaCfg& c, const BwdCfg& bc, int t, int lane,
+                                               char* smem) {
   const VilGeom& g = p.g;
-  const int t = blockIdx.x, lane = threadIdx.x;
   const bool glo = t >= bc.nch;
   const int split = t - bc.nch, ch = glo ? 0 : t;
   const int kn = ch % g.my, km = ch / g.my;
@@ -526,7 +525,7 @@ __global__ __launch_bounds__(64) void k_kv_slots(VilParams p, MfmaCfg c, BwdCfg 
   int adr1, adc1;
   shift_neighbour(p, adr1, adc1);
   for (int s = lane; s < bc.nqs; s += 64) { s_tok[s] = -1; s_aq[s] = glo ? 0 : c.aconst * 4; }
-  __syncthreads();
+  wave_lds_fence();
   int nchunks;
   if (glo) {
     nchunks = bc.glo_from_dq ? 0 : (bc.nch - split + bc.nsplit - 1) / bc.nsplit;
@@ -578,10 +577,41 @@ __global__ __launch_bounds__(64) void k_kv_slots(VilParams p, MfmaCfg c, BwdCfg 
       }
     }
   }
-  __syncthreads();
+  wave_lds_fence();
   int2* out = bc.kv_slots + (int64_t)t * bc.nqs;
   for (int s = lane; s < bc.nqs; s += 64) out[s] = make_int2(s_tok[s], s_aq[s]);
   if (lane == 0) bc.kv_nchunks[t] = nchunks;
+}
+
+// Backward prologue, ONE launch of 256-thread workgroups with four roles (see k_mfma_prep): bias-table images, key-slot
+// tables (dQ pass), streamed-query slot tables (dK/dV pass), and the words that must be zero before the passes run.
+// (Kernels instead of hipMemsetAsync for the zeroing: memset nodes captured into a hipGraph were observed to run out of
+// order with their neighbouring kernel nodes on replay, tools/graph_op_check.py.)
+struct PrepZero { unsigned* a; int na; unsigned* b; int nb; unsigned* z; int nz; };
+__global__ __launch_bounds__(256) void k_mfma_prep_bwd(VilParams p, MfmaCfg c, BwdCfg bc, int row_stride_b, int ntx, PrepZero zr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntab = ntx * p.H, nkv = bc.nch + bc.nsplit;
+  int blk = blockIdx.x;
+  if (blk < ntab) {
+    const int h = blk / ntx, bx = blk - h * ntx;
+    table_element(p, c, (float*)c.tabws, h, bx * 256 + threadIdx.x);
+    return;
+  }
+  blk -= ntab;
+  if (blk < bc.nch) {
+    if (threadIdx.x < 64) key_slots_block(p, c, blk, threadIdx.x, row_stride_b, smem);
+    return;
+  }
+  blk -= bc.nch;
+  if (blk < nkv) {
+    if (threadIdx.x < 64) kv_slots_block(p, c, bc, blk, threadIdx.x, smem);
+    return;
+  }
+  blk -= nkv;
+  const int i = blk * 256 + threadIdx.x;
+  if (i < zr.na) zr.a[i] = 0u;
+  else if (i - zr.na < zr.nb) zr.b[i - zr.na] = 0u;
+  else if (i - zr.na - zr.nb < zr.nz) zr.z[i - zr.na - zr.nb] = 0u;
 }
 
 #ifndef VIL_KV_PKFMA
@@ -695,7 +725,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     const int km = fdiv(ch, c.m_my), kn = ch - km * g.my;
 
     KV_STAMP(t0);
-    // ---- streamed query slot table: the (token, bias address) columns come from k_kv_slots (one table per key chunk /
+    // ---- streamed query slot table: the (token, bias address) columns come from the prologue kernel (kv_slots_block: one table per key chunk /
     // global-key split, built once per call); this wave adds the lse / delta of ITS (image, head).  256 slots per
     // round: table loads, then all gathers, then the LDS stores -- nothing waits on a single round trip.
     if (p.glo_rows) {       // staged now so that the unit's tail does not wait on HBM with one wave per SIMD
@@ -1249,15 +1279,6 @@ __global__ void k_mfma_delta(VilParams p, unsigned* norm2) {
   }
 }
 
-// Zeroing is a KERNEL, not hipMemsetAsync: memset nodes of a captured hipGraph were observed (ROCm 7.2, gfx950)
-// to run out of order with their neighbouring kernel nodes on replay (tools/graph_op_check.py: maxima zeroed
-// after k_mfma_delta had written them -> garbage histogram scale).
-__global__ void k_zero_words(unsigned* a, int na, unsigned* b, int nb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < na) a[i] = 0u;
-  else if (i - na < nb) b[i - na] = 0u;
-}
-
 // ===================================================================== host side
 static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   memset(&bc, 0, sizeof(bc));
@@ -1393,24 +1414,20 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
 #define BWD_SWITCH(...)                                                   \
   if (d->dtype == VIL_DTYPE_F16) { BWD_SWITCH_T(_Float16, __VA_ARGS__) }  \
   else { BWD_SWITCH_T(__bf16, __VA_ARGS__) }
-  vil_prof_begin(VIL_K_TABLE, s, 0, 0);
-  k_mfma_table<<<dim3((c.tabsize + 255) / 256, p.H), dim3(256), 0, s>>>(p, c, tabws);
-  vil_prof_end(s);
-  if ((e = (int)hipGetLastError())) return e;
-  if (int he = vil_ensure_dyn_lds((const void*)k_key_slots, (size_t)c.NSP * 8)) return he;
-  if (int he = vil_ensure_dyn_lds((const void*)k_kv_slots, (size_t)bc.nqs * 8)) return he;
-  k_key_slots<<<dim3((unsigned)bc.nch), dim3(64), (size_t)c.NSP * 8, s>>>(p, c, (int)p.k_st * 2);
-  k_kv_slots<<<dim3((unsigned)(bc.nch + bc.nsplit)), dim3(64), (size_t)bc.nqs * 8, s>>>(p, c, bc);
-  if ((e = (int)hipGetLastError())) return e;
   {
-    const int na = 32 * VIL_NORM_SLOTS, nb = p.dg2l ? p.H * p.G : 0;
-    k_zero_words<<<dim3((na + nb + 255) / 256), dim3(256), 0, s>>>(bc.norm2, na, (unsigned*)p.dg2l, nb);
+    PrepZero zr;
+    zr.a = bc.norm2; zr.na = 32 * VIL_NORM_SLOTS;
+    zr.b = (unsigned*)p.dg2l; zr.nb = p.dg2l ? p.H * p.G : 0;
+    // the LDS image covers only part of the caller's table: the rest of d(table) is 0
+    zr.z = (unsigned*)p.dtable; zr.nz = (p.dtable && c.trows < p.bias_S) ? p.bias_S * p.bias_S * p.H : 0;
+    const int ntx = (c.tabsize + 255) / 256, nzb = (zr.na + zr.nb + zr.nz + 255) / 256;
+    const size_t lds = (size_t)(c.NSP > bc.nqs ? c.NSP : bc.nqs) * 8;
+    if (int he = vil_ensure_dyn_lds((const void*)k_mfma_prep_bwd, lds)) return he;
+    vil_prof_begin(VIL_K_TABLE, s, 0, 0);
+    k_mfma_prep_bwd<<<dim3((unsigned)(ntx * p.H + bc.nch + bc.nch + bc.nsplit + nzb)), dim3(256), lds, s>>>(
+        p, c, bc, (int)p.k_st * 2, ntx, zr);
+    vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
-    if (p.dtable && c.trows < p.bias_S) {       // the LDS image covers only part of the caller's table: rest is 0
-      const int nt = p.bias_S * p.bias_S * p.H;
-      k_zero_words<<<dim3((nt + 255) / 256), dim3(256), 0, s>>>((unsigned*)p.dtable, nt, nullptr, 0);
-      if ((e = (int)hipGetLastError())) return e;
-    }
   }
   vil_prof_begin(VIL_K_DELTA, s, w.delta_bytes(), 0);
   BWD_SWITCH((k_mfma_delta<TT_, MD_><<<dim3((unsigned)((p.g.nx * p.g.ny * (MD_ == 4 ? 8 : (MD_ == 2 ? 4 : 2)) + 255) / 256), p.B * p.H), dim3(256), 0, s>>>(

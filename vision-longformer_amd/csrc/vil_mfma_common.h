@@ -61,7 +61,7 @@ struct MfmaCfg {
   int wpw;           // waves per workgroup (4, or fewer when the per-wave LDS is large)
   int wave_lds;      // bytes of private LDS per wave (forward / dQ pass)
   const float* tabws;  // (H, tabsize) prepared bias tables
-  int2* key_slots;     // (mx*my, NSP): key-slot table of every query chunk (k_key_slots), .x = K/V row byte offset, .y = bias term
+  int2* key_slots;     // (mx*my, NSP): key-slot table of every query chunk (key_slots_block), .x = K/V row byte offset, .y = bias term
   int* key_nslots;     // (mx*my): padded slot count of each
 };
 
@@ -210,8 +210,8 @@ __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg
   return __builtin_amdgcn_readfirstlane(padded);
 }
 
-// The key-slot table depends on the chunk position only, not on the (image, head): k_key_slots builds the table of every
-// chunk once per call (one 64-thread workgroup each, build_key_slots into LDS, copied out), and a forward / dQ wave
+// The key-slot table depends on the chunk position only, not on the (image, head): the prologue kernel builds the table
+// of every chunk once per call (key_slots_block: one wave each, build_key_slots into LDS, copied out), and a forward / dQ wave
 // fetches its chunk's table with a few independent 8-byte loads.  Each wave used to run build_key_slots itself:
 // ~800 instructions and a wave prefix sum per (image, head, chunk) -- 10-20 % of a wave's lifetime (tools/kv_timing.py).
 __device__ __forceinline__ int load_key_slots(const MfmaCfg& c, int ch, int lane, int* s_koff, int* s_akey) {
@@ -230,7 +230,47 @@ __device__ __forceinline__ int load_key_slots(const MfmaCfg& c, int ch, int lane
   wave_lds_fence();
   return nslots;
 }
-__global__ void k_key_slots(VilParams p, MfmaCfg c, int row_stride_b);
+// One element e of head h's LDS-image bias table (bias / scale so that one multiply by scale*log2e serves scores and
+// bias alike; masks and the exact window as VIL_MASK_VAL; one constant region per global token)
+__device__ __forceinline__ void table_element(const VilParams& p, const MfmaCfg& c, float* out, int h, int e) {
+  if (e >= c.tabsize) return;
+  const int tbl = c.trows, W = p.g.W;
+  const float inv = 1.0f / p.scale;
+  float v = 0.f;
+  if (e < tbl * c.P) {
+    const int row = e / c.P, col = e % c.P - VIL_CPAD;
+    if (col >= 0 && col < tbl) {
+      const int dx = row - c.tcen, dy = col - c.tcen;
+      const int o = p.bias_off, S = p.bias_S;      // the caller's table covers |dx|,|dy| <= o
+      if (p.has_bias && dx >= -o && dx <= o && dy >= -o && dy <= o)
+        v = p.table[(int64_t)((dx + o) * S + (dy + o)) * p.H + h] * inv;
+      if (p.g.exact == 1 && (dx > W || dx < -W || dy > W || dy < -W)) v = VIL_MASK_VAL;
+    }
+  } else if (e < c.glo0) {
+    v = VIL_MASK_VAL;
+  } else {
+    const int g = (e - c.glo0) / c.gsz;
+    if (g < p.G && p.has_g2l) v = p.g2l[h * p.G + g] * inv;
+  }
+  out[(int64_t)h * c.tabsize + e] = v;
+}
+// Key-slot table of query chunk ch, built by ONE wave in `smem` (NSP * 8 bytes) and copied to c.key_slots
+__device__ __forceinline__ void key_slots_block(const VilParams& p, const MfmaCfg& c, int ch, int lane, int row_stride_b,
+                                                char* smem) {
+  const int cn = ch % p.g.my, cm = ch / p.g.my;
+  int* s_koff = (int*)smem;
+  int* s_akey = s_koff + c.NSP;
+  int adr1, adc1;
+  shift_neighbour(p, adr1, adc1);
+  const int nslots = build_key_slots(p, c, cm, cn, lane, row_stride_b, s_koff, s_akey, adr1, adc1);
+  int2* out = c.key_slots + (int64_t)ch * c.NSP;
+  for (int s = lane; s < nslots; s += 64) out[s] = make_int2(s_koff[s], s_akey[s]);
+  if (lane == 0) c.key_nslots[ch] = nslots;
+}
+// Forward prologue, ONE launch of 256-thread workgroups with two roles: [0, ntx*H) bias-table images, then one
+// workgroup (its first wave) per query chunk for the key-slot tables.  (Separate launches cost ~4 us each under
+// hipGraph replay, 24 attention calls per ViL-Small step.)
+__global__ void k_mfma_prep(VilParams p, MfmaCfg c, int row_stride_b, int ntx);
 // floats of workspace behind the bias tables for the key-slot tables (16-byte multiple)
 static inline size_t vil_key_slots_floats(const MfmaCfg& c, int nch) {
   return (size_t)nch * c.NSP * 2 + (((size_t)nch + 3) & ~(size_t)3);
@@ -238,5 +278,4 @@ static inline size_t vil_key_slots_floats(const MfmaCfg& c, int nch) {
 
 // host: fills the launch configuration for a descriptor
 bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c);
-// device prologue kernel: builds every head's bias table in the workspace
-__global__ void k_mfma_table(VilParams p, MfmaCfg c, float* out);
+
