@@ -141,7 +141,8 @@ int vil_glo_attn_bwd(const VilAttnDesc* d, const void* q_g, const void* k, const
  * strides; g2l / dg2l are the reference's (2,H,G) g2l_relative_position_bias ([0]: global query ->
  * local keys, [1]: local query -> global keys), g2g / dg2g (H,G,G).  The global rows' backward
  * (autograd of longformer2d.py:210-227) is computed inside the dK/dV pass from the K / V fragments it
- * already holds, so dk / dv are written once.  dg2l and dg2g must be zero on entry.  Workspace:
+ * already holds, so dk / dv are written once.  dg2l and dg2g are overwritten (the call zeroes them in its
+ * prologue launch before accumulating).  Workspace:
  * vil_attn_workspace_bytes(d, 1).  1 <= G <= 4. */
 int vil_attn_bwd_full(const VilAttnDesc* d, const void* q_all, const void* k, const void* v,
                       const void* out_all, const void* dout_all, const float* lse, const float* lse_g,

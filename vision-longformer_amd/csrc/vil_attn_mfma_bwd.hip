@@ -587,7 +587,7 @@ __device__ __forceinline__ void kv_slots_block(const VilParams& p, const MfmaCfg
 // tables (dQ pass), streamed-query slot tables (dK/dV pass), and the words that must be zero before the passes run.
 // (Kernels instead of hipMemsetAsync for the zeroing: memset nodes captured into a hipGraph were observed to run out of
 // order with their neighbouring kernel nodes on replay, tools/graph_op_check.py.)
-struct PrepZero { unsigned* a; int na; unsigned* b; int nb; unsigned* z; int nz; };
+struct PrepZero { unsigned* ptr[5]; int n[5]; int total; };
 __global__ __launch_bounds__(256) void k_mfma_prep_bwd(VilParams p, MfmaCfg c, BwdCfg bc, int row_stride_b, int ntx, PrepZero zr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntab = ntx * p.H, nkv = bc.nch + bc.nsplit;
@@ -608,10 +608,12 @@ __global__ __launch_bounds__(256) void k_mfma_prep_bwd(VilParams p, MfmaCfg c, B
     return;
   }
   blk -= nkv;
-  const int i = blk * 256 + threadIdx.x;
-  if (i < zr.na) zr.a[i] = 0u;
-  else if (i - zr.na < zr.nb) zr.b[i - zr.na] = 0u;
-  else if (i - zr.na - zr.nb < zr.nz) zr.z[i - zr.na - zr.nb] = 0u;
+  int i = blk * 256 + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    if (i < zr.n[r]) { zr.ptr[r][i] = 0u; return; }
+    i -= zr.n[r];
+  }
 }
 
 #ifndef VIL_KV_PKFMA
@@ -1416,11 +1418,15 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   else { BWD_SWITCH_T(__bf16, __VA_ARGS__) }
   {
     PrepZero zr;
-    zr.a = bc.norm2; zr.na = 32 * VIL_NORM_SLOTS;
-    zr.b = (unsigned*)p.dg2l; zr.nb = p.dg2l ? p.H * p.G : 0;
+    zr.ptr[0] = bc.norm2; zr.n[0] = 32 * VIL_NORM_SLOTS;
+    zr.ptr[1] = (unsigned*)p.dg2l; zr.n[1] = p.dg2l ? p.H * p.G : 0;
     // the LDS image covers only part of the caller's table: the rest of d(table) is 0
-    zr.z = (unsigned*)p.dtable; zr.nz = (p.dtable && c.trows < p.bias_S) ? p.bias_S * p.bias_S * p.H : 0;
-    const int ntx = (c.tabsize + 255) / 256, nzb = (zr.na + zr.nb + zr.nz + 255) / 256;
+    zr.ptr[2] = (unsigned*)p.dtable; zr.n[2] = (p.dtable && c.trows < p.bias_S) ? p.bias_S * p.bias_S * p.H : 0;
+    // whole-layer backward: the global QUERY rows' bias gradients are accumulated with atomics
+    zr.ptr[3] = (unsigned*)p.dg2l0; zr.n[3] = (p.glo_rows && p.dg2l0) ? p.H * p.G : 0;
+    zr.ptr[4] = (unsigned*)p.dg2g; zr.n[4] = (p.glo_rows && p.dg2g) ? p.H * p.G * p.G : 0;
+    zr.total = zr.n[0] + zr.n[1] + zr.n[2] + zr.n[3] + zr.n[4];
+    const int ntx = (c.tabsize + 255) / 256, nzb = (zr.total + 255) / 256;
     const size_t lds = (size_t)(c.NSP > bc.nqs ? c.NSP : bc.nqs) * 8;
     if (int he = vil_ensure_dyn_lds((const void*)k_mfma_prep_bwd, lds)) return he;
     vil_prof_begin(VIL_K_TABLE, s, 0, 0);

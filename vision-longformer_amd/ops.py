@@ -193,8 +193,9 @@ def _full_bwd(q_all, k, v, out_all, dout_all, lse, lse_g, tab, g2l_f, g2g_f, dq_
     G, H = cfg["G"], cfg["H"]
     M = C // H
     dtab = torch.empty_like(tab) if tab is not None else None
-    dg2l = torch.zeros_like(g2l_f) if g2l_f is not None else None
-    dg2g = torch.zeros_like(g2g_f) if g2g_f is not None else None
+    # (vil_attn_bwd_full zeroes dg2l / dg2g in its own prologue launch; the two-call fallback below needs them zero)
+    dg2l = torch.empty_like(g2l_f) if g2l_f is not None else None
+    dg2g = torch.empty_like(g2g_f) if g2g_f is not None else None
     q_loc, out_loc, do_loc, dq_loc = q_all[:, G:], out_all[:, G:], dout_all[:, G:], dq_all[:, G:]
     d = _make_desc(q_loc, k, v, out_loc, cfg, backend)
     d.do_sb, d.do_st, d.do_sh = _strides(do_loc, M)
@@ -213,6 +214,9 @@ def _full_bwd(q_all, k, v, out_all, dout_all, lse, lse_g, tab, g2l_f, g2g_f, dq_
                 return dtab, dg2l, dg2g
             if rc != _lib.VIL_E_BACKEND:
                 _lib.check(rc)
+        for t in (dg2l, dg2g):
+            if t is not None:
+                t.zero_()
         _lib.check(L.vil_attn_bwd(ctypes.byref(d), _ptr(q_loc), _ptr(k), _ptr(v), _ptr(out_loc), _ptr(do_loc),
                                   _ptr(lse), _ptr(tab), _ptr(g2l_f[1]) if g2l_f is not None else None,
                                   _ptr(dq_loc), _ptr(dk), _ptr(dv), _ptr(dtab),
