@@ -164,6 +164,20 @@ int vil_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
                       float* dgamma, float* dbeta, void* workspace, int64_t rows, int C,
                       int64_t dy_row_stride, int64_t x_row_stride, int64_t dx_row_stride, void* stream);
 
+/* LayerNorm of the patch embedding written straight into / differentiated straight out of the stage's token tensor
+ * (B, gap_rows + rows_per_sample, C) contiguous: row r of the normalised side lives at token row
+ * r + (r / rows_per_sample + 1) * gap_rows, i.e. behind the gap_rows global tokens of its sample -- replaces the copy of
+ * `torch.cat((cls_tokens, x), dim=1)` (reference src/models/msvit.py:204-206) and of its backward.  The global-token
+ * rows are not touched.  rows % rows_per_sample == 0. */
+int vil_layernorm_fwd_tokens(const void* x, int x_dtype, const float* gamma, const float* beta,
+                             void* y_tokens, int y_dtype, float* mean, float* rstd, int64_t rows, int C,
+                             int64_t x_row_stride, float eps, int64_t rows_per_sample, int64_t gap_rows, void* stream);
+int vil_layernorm_bwd_tokens(const void* dy_tokens, int dy_dtype, const void* x, int x_dtype, const float* gamma,
+                             const float* mean, const float* rstd, void* dx, int dx_dtype,
+                             float* dgamma, float* dbeta, void* workspace, int64_t rows, int C,
+                             int64_t x_row_stride, int64_t dx_row_stride, int64_t rows_per_sample, int64_t gap_rows,
+                             void* stream);
+
 /* ---- the reference's OPERATOR-level surface (compatibility / parity; the hot path is vil_attn_fwd/_bwd, which never
  * builds the score tensor).  Chunked layouts of the reference: images (BH, M, mx, my, W^2), scores
  * (BH, mx, my, W^2, kv), kv = 9 W^2 (mode 0) | W^2 (mode -1) | 2 W^2 (mode 1..8: [own chunk | neighbour]); neighbours

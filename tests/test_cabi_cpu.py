@@ -213,3 +213,22 @@ def test_round2_entry_points_validate_before_launching():
     # cyclic padding and only_glo no longer fall back to the scalar family
     assert L.vil_attn_check(ctypes.byref(_desc(dtype=BF16, backend=_lib.BACKEND_MFMA, M=32, exact=-1))) == 0
     assert L.vil_attn_check(ctypes.byref(_desc(dtype=BF16, backend=_lib.BACKEND_MFMA, M=32, only_glo=1))) == 0
+
+
+def test_token_layernorm_entry_points_validate_before_launching():
+    """vil_layernorm_fwd_tokens / _bwd_tokens (LayerNorm written behind the global-token rows of the token tensor):
+    argument errors without touching a device."""
+    L = _lib.lib()
+    vp = ctypes.c_void_p
+    a16 = vp(4096)
+    F32, BF16 = _lib.DTYPE_F32, _lib.DTYPE_BF16
+    f = L.vil_layernorm_fwd_tokens
+    assert f(None, BF16, a16, a16, a16, F32, a16, a16, 64, 96, 96, 1e-5, 16, 1, None) == -1
+    assert f(a16, BF16, a16, a16, a16, F32, a16, a16, 64, 100, 100, 1e-5, 16, 1, None) == -3       # C % 8 (VIL_E_HEAD_DIM)
+    assert f(a16, BF16, a16, a16, a16, F32, a16, a16, 64, 96, 96, 1e-5, 0, 1, None) == -2           # rows per sample
+    assert f(a16, BF16, a16, a16, a16, F32, a16, a16, 64, 96, 96, 1e-5, 24, 1, None) == -2          # 64 % 24 != 0
+    assert f(a16, BF16, a16, a16, a16, F32, a16, a16, 64, 96, 96, 1e-5, 16, -1, None) == -2
+    b = L.vil_layernorm_bwd_tokens
+    assert b(a16, F32, a16, BF16, a16, a16, a16, a16, BF16, a16, a16, None, 64, 96, 96, 96, 16, 1, None) == -1
+    assert b(a16, F32, a16, BF16, a16, a16, a16, a16, F32, a16, a16, a16, 64, 96, 96, 96, 16, 1, None) == -7   # dx dtype = x dtype
+    assert b(a16, F32, a16, BF16, a16, a16, a16, a16, BF16, a16, a16, a16, 60, 96, 96, 96, 16, 1, None) == -2

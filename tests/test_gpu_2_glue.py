@@ -140,6 +140,40 @@ def test_residual_layernorm_fused(dev, B, N, C, bdt):
     torch.testing.assert_close(ln.bias.grad.double().cpu(), b_r.grad, atol=2e-3 * float(b_r.grad.abs().max()), rtol=2e-3)
 
 
+@pytest.mark.parametrize("B,N,C,G,xdt", [(4, 196, 384, 1, torch.bfloat16), (3, 784, 192, 1, torch.bfloat16),
+                                          (2, 3136, 96, 1, torch.bfloat16), (5, 49, 768, 2, torch.float32)])
+def test_tokens_layernorm_fused(dev, B, N, C, G, xdt):
+    """vil_layernorm_fwd_tokens / _bwd_tokens: cat((cls.expand(B), LayerNorm(x)), dim=1) and every gradient (x, cls,
+    gamma, beta) against the fp64 concatenation (reference PatchEmbed, msvit.py:204-206)."""
+    from vision_longformer_amd.layernorm import VilLayerNorm, tokens_layernorm, tokens_layernorm_ok
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, N, C, generator=g).to(xdt).float()
+    cls = 0.5 * torch.randn(1, G, C, generator=g)
+    ln = VilLayerNorm(C, eps=1e-6, cast_output=False).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * torch.randn(C, generator=g)); ln.bias.copy_(0.1 * torch.randn(C, generator=g))
+    gout = torch.randn(B, G + N, C, generator=g)
+    xr, cr = x.double().requires_grad_(True), cls.double().requires_grad_(True)
+    wr, b_r = ln.weight.detach().double().cpu().requires_grad_(True), ln.bias.detach().double().cpu().requires_grad_(True)
+    out_r = torch.cat((cr.expand(B, -1, -1), torch.nn.functional.layer_norm(xr, (C,), wr, b_r, 1e-6)), dim=1)
+    (out_r * gout.double()).sum().backward()
+    xd = x.to(dev, xdt).requires_grad_(True)
+    cd = cls.to(dev).requires_grad_(True)
+    assert tokens_layernorm_ok(xd, cd, ln)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=xdt == torch.bfloat16):
+        out = tokens_layernorm(xd, cd, ln)
+    assert out.dtype == torch.float32 and out.shape == (B, G + N, C) and out.is_contiguous()
+    (out * gout.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.detach().double().cpu(), out_r.detach(), atol=1e-4, rtol=1e-4)
+    tolx = dict(atol=2e-2, rtol=1e-2) if xdt == torch.bfloat16 else dict(atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(xd.grad.double().cpu(), xr.grad, **tolx)
+    torch.testing.assert_close(cd.grad.double().cpu(), cr.grad, atol=1e-4 * float(cr.grad.abs().max()) + 1e-5, rtol=1e-4)
+    gs = float(wr.grad.abs().max())
+    torch.testing.assert_close(ln.weight.grad.double().cpu(), wr.grad, atol=2e-3 * gs, rtol=2e-3)
+    torch.testing.assert_close(ln.bias.grad.double().cpu(), b_r.grad, atol=2e-3 * float(b_r.grad.abs().max()), rtol=2e-3)
+
+
 @pytest.mark.parametrize("T,K,N", [(25216, 384, 1536), (25216, 1536, 384), (6400, 768, 3072), (100480, 192, 576),
                                     (4000, 96, 288), (197, 768, 1000), (8, 48, 96)])
 def test_library_gemm_selected_algorithm(dev, T, K, N):

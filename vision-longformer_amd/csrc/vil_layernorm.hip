@@ -68,7 +68,16 @@ struct LNParams {
   float* xout; int64_t xout_rs;
   const float* gres; int64_t gres_rs;
   void* gbranch; int gb_bf16; int64_t gb_rs;
+  // token layout of the normalised side (vil_layernorm_*_tokens): the forward's y / the backward's dy hold tok_gap
+  // extra rows (the global tokens) in front of every sample's tok_rps rows: row r lives at r + (r / tok_rps + 1) * tok_gap
+  int64_t tok_rps, tok_gap;
+  unsigned tok_magic;
 };
+__device__ __forceinline__ int64_t ln_tok_row(const LNParams& p, int64_t row) {
+  if (!p.tok_gap) return row;
+  const int64_t q = p.tok_magic ? (int64_t)__umulhi((unsigned)row, p.tok_magic) : row / p.tok_rps;
+  return row + (q + 1) * p.tok_gap;
+}
 
 template <typename TI, typename TO, int LPR, int NIT>
 __global__ __launch_bounds__(256) void k_ln_fwd(LNParams p) {
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(LNParams p) {
       LNIO<float>::ld8(p.beta + e0, bt);
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = fmaf((v[it][i] - mean) * rstd, gm[i], bt[i]);
-      LNIO<TO>::st8((TO*)p.y + row * p.y_rs + e0, o);
+      LNIO<TO>::st8((TO*)p.y + ln_tok_row(p, row) * p.y_rs + e0, o);
     }
   }
   if (sub == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(LNParams p) {
       float xv[8], dyv[8];
       if (rok && e0 < p.C) {
         LNIO<TI>::ld8((const TI*)p.x + row * p.x_rs + e0, xv);
-        LNIO<TG>::ld8((const TG*)p.dy + row * p.dy_rs + e0, dyv);
+        LNIO<TG>::ld8((const TG*)p.dy + ln_tok_row(p, row) * p.dy_rs + e0, dyv);
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { xv[i] = mean; dyv[i] = 0.f; }
@@ -267,6 +276,7 @@ extern "C" size_t vil_layernorm_workspace_bytes(int64_t rows, int C) {
 
 static int ln_fwd_launch(LNParams& p, int x_dtype, int y_dtype, hipStream_t s);
 static int ln_bwd_launch(LNParams& p, int x_dtype, int dy_dtype, hipStream_t s);
+static unsigned ln_rps_magic(int64_t rows, int64_t rps);
 
 extern "C" int vil_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
                                  void* y, int y_dtype, float* mean, float* rstd, int64_t rows, int C,
@@ -331,6 +341,44 @@ static int ln_bwd_launch(LNParams& p, int x_dtype, int dy_dtype, hipStream_t s) 
   if (e) return e;
   k_ln_reduce<<<dim3((2 * C + 63) / 64), dim3(1024), 0, s>>>(p);
   return (int)hipGetLastError();
+}
+
+// ---- LayerNorm of the patch embedding written straight into the stage's token tensor (B, G + N, C): the forward's
+// output rows / the backward's dy rows skip the G global-token rows in front of every sample (the reference
+// concatenates: torch.cat((cls_tokens, x), dim=1), msvit.py:204-206 -- a full copy each way)
+extern "C" int vil_layernorm_fwd_tokens(const void* x, int x_dtype, const float* gamma, const float* beta,
+                                        void* y_tokens, int y_dtype, float* mean, float* rstd, int64_t rows, int C,
+                                        int64_t x_row_stride, float eps, int64_t rows_per_sample, int64_t gap_rows,
+                                        void* stream) {
+  if (!x || !gamma || !beta || !y_tokens || !mean || !rstd) return VIL_E_NULL;
+  int e = ln_check(rows, C, x_row_stride, C);
+  if (e) return e;
+  if (rows_per_sample <= 0 || gap_rows < 0 || rows % rows_per_sample) return VIL_E_SHAPE;
+  if (((uintptr_t)x | (uintptr_t)y_tokens | (uintptr_t)gamma | (uintptr_t)beta) & 15) return VIL_E_ALIGN;
+  LNParams p; memset(&p, 0, sizeof(p));
+  p.x = x; p.y = y_tokens; p.gamma = gamma; p.beta = beta; p.mean = mean; p.rstd = rstd;
+  p.rows = rows; p.C = C; p.x_rs = x_row_stride; p.y_rs = C; p.eps = eps;
+  p.tok_rps = rows_per_sample; p.tok_gap = gap_rows; p.tok_magic = ln_rps_magic(rows, rows_per_sample);
+  return ln_fwd_launch(p, x_dtype, y_dtype, (hipStream_t)stream);
+}
+
+extern "C" int vil_layernorm_bwd_tokens(const void* dy_tokens, int dy_dtype, const void* x, int x_dtype, const float* gamma,
+                                        const float* mean, const float* rstd, void* dx, int dx_dtype,
+                                        float* dgamma, float* dbeta, void* workspace, int64_t rows, int C,
+                                        int64_t x_row_stride, int64_t dx_row_stride, int64_t rows_per_sample,
+                                        int64_t gap_rows, void* stream) {
+  if (!dy_tokens || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return VIL_E_NULL;
+  int e = ln_check(rows, C, x_row_stride, dx_row_stride);
+  if (e) return e;
+  if (rows_per_sample <= 0 || gap_rows < 0 || rows % rows_per_sample) return VIL_E_SHAPE;
+  if (((uintptr_t)x | (uintptr_t)dy_tokens | (uintptr_t)dx | (uintptr_t)gamma) & 15) return VIL_E_ALIGN;
+  if (dx_dtype != x_dtype) return VIL_E_DTYPE;
+  LNParams p; memset(&p, 0, sizeof(p));
+  p.dy = dy_tokens; p.x = x; p.gamma = gamma; p.mean = (float*)mean; p.rstd = (float*)rstd; p.dx = dx;
+  p.dgamma = dgamma; p.dbeta = dbeta; p.parts = (float*)workspace;
+  p.rows = rows; p.C = C; p.dy_rs = C; p.x_rs = x_row_stride; p.dx_rs = dx_row_stride;
+  p.tok_rps = rows_per_sample; p.tok_gap = gap_rows; p.tok_magic = ln_rps_magic(rows, rows_per_sample);
+  return ln_bwd_launch(p, x_dtype, dy_dtype, (hipStream_t)stream);
 }
 
 // 64-bit division per row and lane is ~50 VALU instructions; one multiply-high when exact for the call's row range

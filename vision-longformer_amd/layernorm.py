@@ -6,6 +6,7 @@ in bf16 -- numerically identical to PyTorch's fp32 LayerNorm followed by autocas
 Linear, without the cast kernels and with half the write traffic.  CPU tensors fall through to
 `nn.LayerNorm.forward` (this layer is glue, not the hot path; the CPU baseline model uses it that way)."""
 import ctypes
+import os
 
 import torch
 from torch import nn
@@ -62,6 +63,81 @@ class _FusedLN(torch.autograd.Function):
                                            _p(dx), _DT[dx.dtype], _p(dgamma), _p(dbeta), _p(ws), rows, C,
                                            dy2.stride(0), x2.stride(0), dx.stride(0), stream))
         return dx.view(ctx.x_shape), dgamma.to(ctx.wdtype), dbeta.to(ctx.wdtype), None, None
+
+
+class _TokensLN(torch.autograd.Function):
+    """out[:, :G] = cls (broadcast over the batch);  out[:, G:] = LayerNorm(x)   for x (B, N, C), cls (1, G, C):
+    `torch.cat((cls_tokens, norm(x)), dim=1)` of the reference's PatchEmbed (msvit.py:204-206) with the LayerNorm
+    writing straight into the token tensor (vil_layernorm_fwd_tokens) and its backward reading straight out of the
+    token tensor's gradient (vil_layernorm_bwd_tokens): no concatenation copy in either direction."""
+
+    @staticmethod
+    def forward(ctx, x, cls, weight, bias, eps, out_dtype):
+        L = _lib.lib()
+        B, N, C = x.shape
+        G = cls.shape[1]
+        x2 = x.reshape(-1, C)
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        w = weight.detach().float().contiguous()
+        b = bias.detach().float().contiguous()
+        out = torch.empty(B, G + N, C, dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        with torch.cuda.device(x.device):
+            _lib.check(L.vil_layernorm_fwd_tokens(_p(x2), _DT[x2.dtype], _p(w), _p(b), _p(out), _DT[out_dtype], _p(mean),
+                                                  _p(rstd), rows, C, x2.stride(0), float(eps), N, G, stream))
+        out[:, :G] = cls.to(out_dtype)
+        ctx.save_for_backward(x2, w, mean, rstd)
+        ctx.x_shape, ctx.G, ctx.wdtype, ctx.cdtype, ctx.cshape = x.shape, G, weight.dtype, cls.dtype, cls.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .linear import _colsum
+        x2, w, mean, rstd = ctx.saved_tensors
+        L = _lib.lib()
+        rows, C = x2.shape
+        B, N, _ = ctx.x_shape
+        G = ctx.G
+        if not g.is_contiguous():
+            g = g.contiguous()
+        if g.dtype not in _DT:
+            g = g.float()
+        dx = torch.empty(rows, C, dtype=x2.dtype, device=x2.device)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x2.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x2.device)
+        ws = torch.empty(L.vil_layernorm_workspace_bytes(rows, C) // 4, dtype=torch.float32, device=x2.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream)
+        with torch.cuda.device(x2.device):
+            _lib.check(L.vil_layernorm_bwd_tokens(_p(g), _DT[g.dtype], _p(x2), _DT[x2.dtype], _p(w), _p(mean), _p(rstd),
+                                                  _p(dx), _DT[dx.dtype], _p(dgamma), _p(dbeta), _p(ws), rows, C,
+                                                  x2.stride(0), dx.stride(0), N, G, stream))
+        dcls = None
+        if ctx.needs_input_grad[1]:
+            # the batch sum of the global-token rows: a column sum of the (B, G*C) leading block of every sample
+            dcls = _colsum(g.view(B, (G + N) * C)[:, :G * C]).view(ctx.cshape).to(ctx.cdtype)
+        return dx.view(ctx.x_shape), dcls, dgamma.to(ctx.wdtype), dbeta.to(ctx.wdtype), None, None
+
+
+def tokens_layernorm_ok(x, cls, norm):
+    C = x.shape[-1]
+    if os.environ.get("VIL_UNFUSED_STAGE_ENTRY"):      # A/B switch for measurements: the concatenating path
+        return False
+    return (isinstance(norm, VilLayerNorm) and x.is_cuda and x.dim() == 3 and x.dtype in _DT and cls is not None
+            and cls.shape[1] >= 1 and C % 8 == 0 and C <= 1024 and norm.elementwise_affine and norm.bias is not None
+            and hasattr(_lib.lib(), "vil_layernorm_fwd_tokens"))
+
+
+def tokens_layernorm(x, cls, norm):
+    """cat((cls.expand(B), norm(x)), dim=1) in one LayerNorm kernel each way; output dtype as VilLayerNorm.forward."""
+    out_dtype = x.dtype
+    if torch.is_autocast_enabled("cuda"):
+        ac = torch.get_autocast_dtype("cuda")
+        out_dtype = ac if (norm.cast_output and ac in _DT) else torch.float32
+    return _TokensLN.apply(x, cls, norm.weight, norm.bias, norm.eps, out_dtype)
 
 
 class _ResLN(torch.autograd.Function):

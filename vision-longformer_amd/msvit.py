@@ -19,7 +19,7 @@ from torch import nn
 
 from .longformer2d import Long2DSCSelfAttention, _trunc_normal_
 from .ops import vil_dense_attention, FULL_MAX_G
-from .layernorm import VilLayerNorm, res_layernorm, res_layernorm_ok
+from .layernorm import VilLayerNorm, res_layernorm, res_layernorm_ok, tokens_layernorm, tokens_layernorm_ok
 from .linear import VilLinear, vil_linear, expand_rows
 
 
@@ -231,10 +231,15 @@ class PatchEmbed(nn.Module):
             x, nx, ny = self._embed(xtuple[0])
         B = x.shape[0]
         assert nx == self.nx and ny == self.ny, "Fix input size!"
-        if self.norm_embed is not None:
-            x = self.norm_embed(x)
-        if self.cls_token is not None:
-            x = torch.cat((expand_rows(self.cls_token, B).to(x.dtype), x), dim=1)
+        if (self.norm_embed is not None and self.cls_token is not None
+                and tokens_layernorm_ok(x, self.cls_token, self.norm_embed)):
+            # the LayerNorm writes behind the global-token rows of the stage's token tensor: no concatenation copy
+            x = tokens_layernorm(x, self.cls_token, self.norm_embed)
+        else:
+            if self.norm_embed is not None:
+                x = self.norm_embed(x)
+            if self.cls_token is not None:
+                x = torch.cat((expand_rows(self.cls_token, B).to(x.dtype), x), dim=1)
         if self.ape:
             grid = torch.cat([self.x_pos_embed.unsqueeze(2).expand(-1, -1, ny, -1),
                               self.y_pos_embed.unsqueeze(1).expand(-1, nx, -1, -1)], dim=-1).flatten(1, 2)
