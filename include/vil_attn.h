@@ -178,6 +178,18 @@ int vil_layernorm_bwd_tokens(const void* dy_tokens, int dy_dtype, const void* x,
                              int64_t x_row_stride, int64_t dx_row_stride, int64_t rows_per_sample, int64_t gap_rows,
                              void* stream);
 
+/* ---- stage transition: `x[:, G:].transpose(-2,-1).reshape(B,-1,nx,ny)` + the strided Conv2d of
+ * PatchEmbed (reference src/models/msvit.py:500-507, 166-203) as ONE row gather in front of a GEMM:
+ *   patches[(b, i', j'), (py, px, c)] = x[b, G + (i' ph + py) ny + (j' pw + px), c] (+ rscale[b] * res[same]),
+ * x fp32 (B, G + nx*ny, C) contiguous, res (the pending `drop_path(branch)` of the stage's last block, or NULL) fp32 /
+ * bf16 of the same shape, rscale (B) fp32 or NULL, patches (B * nx/ph * ny/pw, ph*pw*C) fp32 / bf16.  C % 8 == 0.
+ * _bwd: dx (B, G + nx*ny, C) fp32 = the scattered patch gradient (global-token rows 0) and, when gbranch != NULL,
+ * gbranch = rscale[b] * dx in gb_dtype (the pending branch's gradient). */
+int vil_patchify_fwd(const float* x, const void* res, int res_dtype, const float* rscale, void* patches, int out_dtype,
+                     int B, int G, int nx, int ny, int C, int ph, int pw, void* stream);
+int vil_patchify_bwd(const void* dpatches, int dp_dtype, const float* rscale, float* dx, void* gbranch, int gb_dtype,
+                     int B, int G, int nx, int ny, int C, int ph, int pw, void* stream);
+
 /* ---- the reference's OPERATOR-level surface (compatibility / parity; the hot path is vil_attn_fwd/_bwd, which never
  * builds the score tensor).  Chunked layouts of the reference: images (BH, M, mx, my, W^2), scores
  * (BH, mx, my, W^2, kv), kv = 9 W^2 (mode 0) | W^2 (mode -1) | 2 W^2 (mode 1..8: [own chunk | neighbour]); neighbours

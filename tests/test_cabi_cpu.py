@@ -232,3 +232,21 @@ def test_token_layernorm_entry_points_validate_before_launching():
     assert b(a16, F32, a16, BF16, a16, a16, a16, a16, BF16, a16, a16, None, 64, 96, 96, 96, 16, 1, None) == -1
     assert b(a16, F32, a16, BF16, a16, a16, a16, a16, F32, a16, a16, a16, 64, 96, 96, 96, 16, 1, None) == -7   # dx dtype = x dtype
     assert b(a16, F32, a16, BF16, a16, a16, a16, a16, BF16, a16, a16, a16, 60, 96, 96, 96, 16, 1, None) == -2
+
+
+def test_patchify_entry_points_validate_before_launching():
+    """vil_patchify_fwd / _bwd (stage transition as one row gather): argument errors without touching a device."""
+    L = _lib.lib()
+    vp = ctypes.c_void_p
+    a16 = vp(4096)
+    F32, BF16, F16 = _lib.DTYPE_F32, _lib.DTYPE_BF16, _lib.DTYPE_F16
+    f, b = L.vil_patchify_fwd, L.vil_patchify_bwd
+    assert f(None, a16, BF16, a16, a16, BF16, 2, 1, 8, 8, 96, 2, 2, None) == -1
+    assert f(a16, a16, F16, a16, a16, BF16, 2, 1, 8, 8, 96, 2, 2, None) == -7           # branch dtype
+    assert f(a16, None, 0, None, a16, F16, 2, 1, 8, 8, 96, 2, 2, None) == -7             # output dtype
+    assert f(a16, None, 0, None, a16, BF16, 2, 1, 9, 8, 96, 2, 2, None) == -2            # nx % ph
+    assert f(a16, None, 0, None, a16, BF16, 2, 1, 8, 8, 100, 2, 2, None) == -8           # C % 8
+    assert f(a16, None, 0, None, vp(4100), BF16, 2, 1, 8, 8, 96, 2, 2, None) == -8       # alignment
+    assert b(a16, BF16, a16, None, a16, BF16, 2, 1, 8, 8, 96, 2, 2, None) == -1
+    assert b(a16, BF16, a16, a16, a16, F16, 2, 1, 8, 8, 96, 2, 2, None) == -7
+    assert b(a16, BF16, a16, a16, None, 0, 0, 1, 8, 8, 96, 2, 2, None) == -2

@@ -140,6 +140,43 @@ def test_residual_layernorm_fused(dev, B, N, C, bdt):
     torch.testing.assert_close(ln.bias.grad.double().cpu(), b_r.grad, atol=2e-3 * float(b_r.grad.abs().max()), rtol=2e-3)
 
 
+@pytest.mark.parametrize("B,G,nx,ny,C,ph,pw,bdt,odt", [(3, 1, 56, 56, 96, 2, 2, torch.bfloat16, torch.bfloat16),
+                                                       (2, 1, 28, 28, 192, 2, 2, torch.bfloat16, torch.bfloat16),
+                                                       (2, 2, 12, 8, 48, 2, 4, torch.float32, torch.float32),
+                                                       (4, 0, 14, 14, 384, 2, 2, None, torch.bfloat16),
+                                                       (2, 1, 6, 9, 64, 3, 3, torch.bfloat16, torch.float32)])
+def test_patchify_stage_transition(dev, B, G, nx, ny, C, ph, pw, bdt, odt):
+    """vil_patchify_fwd / _bwd against the reference's op sequence in fp64: x + s*branch, x[:, G:], the image view and
+    the (py, px, c) patch vectors a strided Conv2d consumes (msvit.py:500-507, 166-203), and both gradients."""
+    from vision_longformer_amd.msvit import _Patchify
+    g = torch.Generator().manual_seed(9)
+    N = nx * ny
+    x = torch.randn(B, G + N, C, generator=g)
+    br = torch.randn(B, G + N, C, generator=g).to(bdt).float() if bdt is not None else None
+    sc = torch.tensor([0.0, 1.25, 1.0, 1.25][:B]) if bdt is not None else None
+    nxp, nyp = nx // ph, ny // pw
+    gout = torch.randn(B * nxp * nyp, ph * pw * C, generator=g).to(odt).float()
+    xr = x.double().requires_grad_(True)
+    brr = br.double().requires_grad_(True) if br is not None else None
+    xs = xr + sc.double().view(B, 1, 1) * brr if br is not None else xr
+    ref = xs[:, G:].reshape(B, nxp, ph, nyp, pw, C).permute(0, 1, 3, 2, 4, 5).reshape(B * nxp * nyp, ph * pw * C)
+    (ref * gout.double()).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    brd = br.to(dev, bdt).requires_grad_(True) if br is not None else None
+    out = _Patchify.apply(xd, brd, sc.to(dev) if sc is not None else None, G, nx, ny, ph, pw, odt)
+    assert out.dtype == odt and out.shape == ref.shape
+    (out.float() * gout.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    tol = dict(atol=2e-2, rtol=1e-2) if odt == torch.bfloat16 else dict(atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(out.detach().double().cpu(), ref.detach(), **tol)
+    torch.testing.assert_close(xd.grad.double().cpu(), xr.grad, atol=1e-6, rtol=1e-6)
+    if G:
+        assert float(xd.grad[:, :G].abs().max()) == 0.0
+    if br is not None:
+        tolb = dict(atol=2e-2, rtol=1e-2) if bdt == torch.bfloat16 else dict(atol=1e-6, rtol=1e-6)
+        torch.testing.assert_close(brd.grad.double().cpu(), brr.grad, **tolb)
+
+
 @pytest.mark.parametrize("B,N,C,G,xdt", [(4, 196, 384, 1, torch.bfloat16), (3, 784, 192, 1, torch.bfloat16),
                                           (2, 3136, 96, 1, torch.bfloat16), (5, 49, 768, 2, torch.float32)])
 def test_tokens_layernorm_fused(dev, B, N, C, G, xdt):

@@ -23,7 +23,7 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_attn_fwd", "vil_attn_bwd", "vil_geom_mask", "vil_geom_bias_index",
            "vil_attn_profile_begin", "vil_attn_profile_end", "vil_attn_profile_end2", "vil_attn_kernel_name",
            "vil_layernorm_workspace_bytes", "vil_layernorm_fwd", "vil_layernorm_bwd",
-           "vil_layernorm_fwd_tokens", "vil_layernorm_bwd_tokens",
+           "vil_layernorm_fwd_tokens", "vil_layernorm_bwd_tokens", "vil_patchify_fwd", "vil_patchify_bwd",
            "vil_glo_attn_fwd", "vil_glo_attn_bwd", "vil_attn_bwd_full",
            "vil_colsum_workspace_bytes", "vil_colsum_bf16", "vil_colsum_f32",
            "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad",
@@ -140,6 +140,12 @@ def lib():
             L.vil_layernorm_bwd_tokens.restype = ctypes.c_int
             L.vil_layernorm_bwd_tokens.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp,
                                                    vp, i64, ctypes.c_int, i64, i64, i64, i64, vp]
+        if hasattr(L, "vil_patchify_fwd"):
+            ci_ = ctypes.c_int
+            L.vil_patchify_fwd.restype = ci_
+            L.vil_patchify_fwd.argtypes = [vp, vp, ci_, vp, vp, ci_] + [ci_] * 7 + [vp]
+            L.vil_patchify_bwd.restype = ci_
+            L.vil_patchify_bwd.argtypes = [vp, ci_, vp, vp, vp, ci_] + [ci_] * 7 + [vp]
         if L.vil_attn_abi_version() != ABI_VERSION:
             raise RuntimeError("libvilattn.so ABI version mismatch; rebuild it")
         _lib = L

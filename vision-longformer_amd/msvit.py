@@ -54,6 +54,56 @@ class _DropPathAdd(torch.autograd.Function):
         return g, (g * mask).to(ctx.ydtype), None
 
 
+class _Patchify(torch.autograd.Function):
+    """Stage transition as one row gather each way (vil_patchify_fwd / _bwd): the pending `x + drop_path(branch)` of the
+    stage's last block, `x[:, G:]`, the regrouping of every ph x pw patch's tokens into one (py, px, c) vector and the cast
+    to the GEMM dtype; the backward scatters the patch gradient home (global-token rows zero) and emits the branch's
+    gradient.  Reference msvit.py:500-507 + the strided Conv2d of PatchEmbed (:166-203)."""
+
+    @staticmethod
+    def forward(ctx, x, branch, rscale, G, nx, ny, ph, pw, out_dtype):
+        from . import _lib
+        import ctypes
+        L = _lib.lib()
+        B, _, C = x.shape
+        x = x.contiguous()
+        if branch is not None:
+            branch = branch.contiguous()
+        patches = torch.empty(B * (nx // ph) * (ny // pw), ph * pw * C, dtype=out_dtype, device=x.device)
+        vp = ctypes.c_void_p
+        dt = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16}
+        with torch.cuda.device(x.device):
+            _lib.check(L.vil_patchify_fwd(vp(x.data_ptr()), vp(branch.data_ptr()) if branch is not None else None,
+                                          dt[branch.dtype] if branch is not None else 0,
+                                          vp(rscale.data_ptr()) if rscale is not None else None, vp(patches.data_ptr()),
+                                          dt[out_dtype], B, G, nx, ny, C, ph, pw,
+                                          vp(torch.cuda.current_stream(x.device).cuda_stream)))
+        ctx.save_for_backward(rscale)
+        ctx.cfg = (B, G, nx, ny, C, ph, pw, x.shape, branch.dtype if branch is not None else None)
+        return patches
+
+    @staticmethod
+    def backward(ctx, dp):
+        from . import _lib
+        import ctypes
+        L = _lib.lib()
+        (rscale,) = ctx.saved_tensors
+        B, G, nx, ny, C, ph, pw, xshape, bdtype = ctx.cfg
+        dt = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16}
+        dp = dp.contiguous()
+        if dp.dtype not in dt:
+            dp = dp.float()
+        dx = torch.empty(xshape, dtype=torch.float32, device=dp.device)
+        gb = torch.empty(xshape, dtype=bdtype, device=dp.device) if bdtype is not None else None
+        vp = ctypes.c_void_p
+        with torch.cuda.device(dp.device):
+            _lib.check(L.vil_patchify_bwd(vp(dp.data_ptr()), dt[dp.dtype], vp(rscale.data_ptr()) if rscale is not None else None,
+                                          vp(dx.data_ptr()), vp(gb.data_ptr()) if gb is not None else None,
+                                          dt[bdtype] if bdtype is not None else 0, B, G, nx, ny, C, ph, pw,
+                                          vp(torch.cuda.current_stream(dp.device).cuda_stream)))
+        return dx, gb, None, None, None, None, None, None, None
+
+
 def residual_drop_path(x, y, drop_prob, training):
     """x + drop_path(y): stochastic depth per sample (reference msvit.py:313-316,336-340 with timm's DropPath)."""
     if drop_prob == 0.0 or not training:
@@ -224,8 +274,19 @@ class PatchEmbed(nn.Module):
         return (xt.is_cuda and pnx % ph == 0 and pny % pw == 0 and (xt.shape[-1] * ph * pw) % 8 == 0
                 and self.proj.out_channels % 8 == 0)
 
+    def _embed_patches(self, patches, pnx, pny):
+        """Projection of ready-made (py, px, c) patch vectors (B * nx * ny, ph * pw * Cin) -- MsViT's fused stage transition"""
+        ph, pw = self.patch_size
+        nx, ny = pnx // ph, pny // pw
+        Cin = patches.shape[1] // (ph * pw)
+        w = self.proj.weight.permute(0, 2, 3, 1).reshape(self.proj.out_channels, ph * pw * Cin)
+        y = vil_linear(patches, w, self.proj.bias)
+        return y.view(-1, nx * ny, self.proj.out_channels), nx, ny
+
     def forward(self, xtuple, tokens=False):
-        if tokens:
+        if tokens == "patches":
+            x, nx, ny = self._embed_patches(*xtuple)
+        elif tokens:
             x, nx, ny = self._embed_tokens(*xtuple)
         else:
             x, nx, ny = self._embed(xtuple[0])
@@ -393,6 +454,20 @@ class MsViT(nn.Module):
         self._dp_scales = (u < keep).to(torch.float32) / keep
 
     @staticmethod
+    def _fused_transition_ok(x, pend, embed, nx, ny):
+        import os
+        from . import _lib
+        if os.environ.get("VIL_UNFUSED_STAGE_ENTRY") or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
+            return False
+        ph, pw = embed.patch_size
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        if dt not in (torch.float32, torch.bfloat16) or not embed.tokens_ok(x, nx, ny) or x.shape[-1] % 8:
+            return False
+        if pend is not None and (pend[0].shape != x.shape or pend[0].dtype not in (torch.float32, torch.bfloat16)):
+            return False
+        return hasattr(_lib.lib(), "vil_patchify_fwd")
+
+    @staticmethod
     def _settle(x, pend):
         """materialise a deferred `x + drop_path(branch)`"""
         if pend is None:
@@ -430,7 +505,16 @@ class MsViT(nn.Module):
         for i in range(self.num_layers):
             layer = getattr(self, "layer%d" % (i + 1))
             tokens = False
-            if i > 0:   # drop the previous stage's global tokens, back to an image
+            if i > 0 and self._fused_transition_ok(x, pend, layer[0], nx, ny):
+                # one row gather: pending residual add + drop the global tokens + (py, px, c) patch vectors + cast
+                ph, pw = layer[0].patch_size
+                dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+                br, sc = pend if pend is not None else (None, None)
+                x = _Patchify.apply(x, br, sc, self.Nglos[i - 1], nx, ny, ph, pw, dt)
+                if getattr(self, "_seg_points", None) is not None:
+                    self._seg_points[i] = x          # activation entering stage i: a backward-segment cut (engine.GraphedTrainStep)
+                tokens = "patches"
+            elif i > 0:   # drop the previous stage's global tokens, back to an image
                 x = self._settle(x, pend)
                 if getattr(self, "_seg_points", None) is not None:
                     self._seg_points[i] = x          # activation entering stage i: a backward-segment cut (engine.GraphedTrainStep)
