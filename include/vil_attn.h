@@ -258,7 +258,8 @@ int vil_linear_wgrad(const void* dy, const void* x, int64_t T, int CO, int CI, i
  * `x = x + drop_path(branch)` of one block fused with `norm(x)` of the next).  Contiguous (rows, C) tensors.
  *   forward : x_out = x + rscale[row / rows_per_sample] * res  (rscale NULL: 1);  y = LN(x_out)
  *   backward: dx = gres (NULL: 0) + LNbwd(dy);  gbranch = rscale[...] * dx in the branch's dtype
- * (dx is the gradient of x AND of x_out's producer; gbranch the gradient of res). */
+ * (dx is the gradient of x AND of x_out's producer; gbranch the gradient of res; gbranch NULL: no branch was added --
+ * the first block of a stage, where x feeds the norm and the residual stream: dx = gres + LNbwd(dy) in one pass). */
 int vil_resln_fwd(const float* x, const void* res, int res_dtype, const float* rscale, int64_t rows_per_sample,
                   const float* gamma, const float* beta, float* x_out, void* y, int y_dtype,
                   float* mean, float* rstd, int64_t rows, int C, float eps, void* stream);

@@ -81,7 +81,7 @@ def test_glue_entry_points_validate_before_launching():
     assert L.vil_gemm_workspace_bytes() >= 1 << 20
     assert L.vil_resln_fwd(None, a16, 1, None, 1, a16, a16, a16, a16, 1, a16, a16, 8, 8, 1e-6, None) == -1
     assert L.vil_resln_fwd(a16, a16, 1, None, 0, a16, a16, a16, a16, 1, a16, a16, 8, 8, 1e-6, None) == -2
-    assert L.vil_resln_bwd(a16, 1, None, a16, a16, a16, a16, None, 1, a16, None, 1, a16, a16, a16, 8, 8, None) == -1
+    assert L.vil_resln_bwd(a16, 1, None, a16, a16, a16, a16, None, 1, None, None, 1, a16, a16, a16, 8, 8, None) == -1   # dx (gbranch may be NULL)
     d = _desc(mode=3, dtype=_lib.DTYPE_BF16)
     d.mode_dev = 4096
     assert L.vil_attn_check(ctypes.byref(d)) in (0, -10)        # accepted (MFMA) or backend-declined, never a crash

@@ -413,7 +413,8 @@ extern "C" int vil_resln_bwd(const void* dy, int dy_dtype, const float* gres, co
                              const float* mean, const float* rstd, const float* rscale, int64_t rows_per_sample,
                              float* dx, void* gbranch, int gb_dtype, float* dgamma, float* dbeta, void* workspace,
                              int64_t rows, int C, void* stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !gbranch || !dgamma || !dbeta || !workspace) return VIL_E_NULL;
+  // gbranch == NULL: no branch was added in the forward (the first block of a stage): dx = gres + LNbwd(dy) only
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return VIL_E_NULL;
   int e = ln_check(rows, C, C, C);
   if (e) return e;
   if (rows_per_sample <= 0) return VIL_E_SHAPE;

@@ -201,6 +201,75 @@ class _ResLN(torch.autograd.Function):
         return (dx.view(ctx.shape), gb.view(ctx.shape), None, dgamma.to(ctx.wdtype), dbeta.to(ctx.wdtype), None, None)
 
 
+class _PassLN(torch.autograd.Function):
+    """(x, LayerNorm(x)) for the FIRST block of a stage, where x feeds both the norm and the residual stream: the
+    backward adds the two gradients inside the LayerNorm-backward kernel (vil_resln_bwd with no branch) instead of an
+    autograd accumulation pass over the fp32 stream."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        L = _lib.lib()
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        rows = x2.shape[0]
+        w = weight.detach().float().contiguous()
+        b = bias.detach().float().contiguous()
+        y = torch.empty(rows, C, dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        with torch.cuda.device(x.device):
+            _lib.check(L.vil_layernorm_fwd(_p(x2), _DT[x2.dtype], _p(w), _p(b), _p(y), _DT[out_dtype], _p(mean), _p(rstd),
+                                           rows, C, x2.stride(0), y.stride(0), float(eps), stream))
+        ctx.save_for_backward(x2, w, mean, rstd)
+        ctx.shape, ctx.wdtype = x.shape, weight.dtype
+        return x.view_as(x), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g_x, g_y):
+        x2, w, mean, rstd = ctx.saved_tensors
+        L = _lib.lib()
+        rows, C = x2.shape
+        if g_y is None:
+            g_y = torch.zeros(rows, C, dtype=torch.bfloat16, device=x2.device)
+        dy2 = g_y.reshape(rows, C)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        if dy2.dtype not in _DT:
+            dy2 = dy2.float()
+        gres = None
+        if g_x is not None:
+            gres = g_x.reshape(rows, C)
+            if gres.dtype != torch.float32 or not gres.is_contiguous():
+                gres = gres.float().contiguous()
+        dx = torch.empty(rows, C, dtype=torch.float32, device=x2.device)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x2.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x2.device)
+        ws = torch.empty(L.vil_layernorm_workspace_bytes(rows, C) // 4, dtype=torch.float32, device=x2.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream)
+        with torch.cuda.device(x2.device):
+            _lib.check(L.vil_resln_bwd(_p(dy2), _DT[dy2.dtype], _p(gres) if gres is not None else None, _p(x2), _p(w),
+                                       _p(mean), _p(rstd), None, rows, _p(dx), None, _DT[torch.float32], _p(dgamma),
+                                       _p(dbeta), _p(ws), rows, C, stream))
+        return dx.view(ctx.shape), dgamma.to(ctx.wdtype), dbeta.to(ctx.wdtype), None, None
+
+
+def pass_layernorm_ok(x, norm):
+    C = x.shape[-1]
+    return (isinstance(norm, VilLayerNorm) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+            and C % 8 == 0 and C <= 1024 and norm.elementwise_affine and norm.bias is not None
+            and not os.environ.get("VIL_UNFUSED_STAGE_ENTRY"))
+
+
+def pass_layernorm(x, norm):
+    """(x, norm(x)) with the gradient of both uses of x summed inside the LayerNorm backward; see _PassLN"""
+    out_dtype = x.dtype
+    if torch.is_autocast_enabled("cuda"):
+        ac = torch.get_autocast_dtype("cuda")
+        out_dtype = ac if (norm.cast_output and ac in _DT) else torch.float32
+    return _PassLN.apply(x, norm.weight, norm.bias, norm.eps, out_dtype)
+
+
 def res_layernorm_ok(x, branch, norm):
     C = x.shape[-1]
     return (isinstance(norm, VilLayerNorm) and x.is_cuda and x.dtype == torch.float32 and branch.dtype in _DT

@@ -19,7 +19,8 @@ from torch import nn
 
 from .longformer2d import Long2DSCSelfAttention, _trunc_normal_
 from .ops import vil_dense_attention, FULL_MAX_G
-from .layernorm import VilLayerNorm, res_layernorm, res_layernorm_ok, tokens_layernorm, tokens_layernorm_ok
+from .layernorm import (VilLayerNorm, res_layernorm, res_layernorm_ok, tokens_layernorm, tokens_layernorm_ok,
+                        pass_layernorm, pass_layernorm_ok)
 from .linear import VilLinear, vil_linear, expand_rows
 
 
@@ -490,6 +491,8 @@ class MsViT(nn.Module):
                 continue
             if pend is not None and res_layernorm_ok(x, pend[0], blk.norm):
                 x, y = res_layernorm(x, pend[0], pend[1], blk.norm)
+            elif pend is None and torch.is_grad_enabled() and x.requires_grad and pass_layernorm_ok(x, blk.norm):
+                x, y = pass_layernorm(x, blk.norm)      # first block of a stage: x feeds the norm AND the residual stream
             else:
                 x = self._settle(x, pend)
                 y = blk.norm(x)
