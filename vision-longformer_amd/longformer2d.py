@@ -18,8 +18,8 @@ import random
 import torch
 from torch import nn
 
-from .ops import vil_local_attention, vil_full_attention, vil_global_attention, FULL_MAX_G
-from .linear import VilLinear
+from .ops import vil_local_attention, vil_full_attention, vil_full_attention_qkv, vil_global_attention, FULL_MAX_G
+from .linear import VilLinear, vil_linear
 
 
 def _trunc_normal_(t, std):
@@ -107,6 +107,12 @@ class Long2DSCSelfAttention(nn.Module):
         return (1 <= G <= FULL_MAX_G and self.query_global is self.query and self.kv_global is self.kv
                 and self.proj_global is self.proj and not self.only_glo and M in (8, 16, 32, 48, 64))
 
+    def _packed_projection_ok(self, x):
+        import os
+        q, kv = self.query, self.kv
+        return (x.is_cuda and isinstance(q, VilLinear) and isinstance(kv, VilLinear) and q.weight.dtype == kv.weight.dtype
+                and (q.bias is None) == (kv.bias is None) and not os.environ.get("VIL_UNPACKED_QKV"))
+
     def forward(self, x, nx, ny):
         B, N, C = x.shape
         G, H, M = self.Nglo, self.num_heads, self.head_dim
@@ -127,10 +133,16 @@ class Long2DSCSelfAttention(nn.Module):
             # shared weights (every published ViL): ONE query / kv / proj GEMM over all N tokens and one
             # fused op for local + global rows -- no token slicing, no concatenation, and the two
             # gradient contributions to kv are summed inside the kernels
-            out = vil_full_attention(self.query(x), self.kv(x), table, g2l, g2g,
-                                     nx=nx, ny=ny, w=self.attention_window, nglo=G, num_heads=H,
-                                     mode=(1 if rs_dev else mode), exact=self.exact, scale=self.scale,
-                                     backend=self.backend, mode_dev=self.mode_dev if rs_dev else None)
+            kw = dict(nx=nx, ny=ny, w=self.attention_window, nglo=G, num_heads=H, mode=(1 if rs_dev else mode),
+                      exact=self.exact, scale=self.scale, backend=self.backend, mode_dev=self.mode_dev if rs_dev else None)
+            if self._packed_projection_ok(x):
+                # query and kv as ONE (3C, C) GEMM over the shared input: x is read once, and the backward is one input-
+                # gradient GEMM and one weight-gradient kernel instead of two of each plus an accumulation pass
+                wq, wkv = self.query.weight, self.kv.weight
+                bias = torch.cat([self.query.bias, self.kv.bias]) if self.query.bias is not None else None
+                out = vil_full_attention_qkv(vil_linear(x, torch.cat([wq, wkv], dim=0), bias), table, g2l, g2g, **kw)
+            else:
+                out = vil_full_attention(self.query(x), self.kv(x), table, g2l, g2g, **kw)
             return self.proj_drop(self.proj(out))
 
         if rs_dev:

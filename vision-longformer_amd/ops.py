@@ -395,6 +395,21 @@ def vil_full_attention(q_all, kv, bias_table, g2l_bias, g2g_bias, *, nx, ny, w, 
     return _VilFullAttention.apply(q_all, kv, bias_table, g2l_bias, g2g_bias, cfg, backend or DEFAULT_BACKEND)
 
 
+def vil_full_attention_qkv(qkv, bias_table, g2l_bias, g2g_bias, *, nx, ny, w, nglo, num_heads, mode=0, exact=0,
+                           scale=None, backend=None, mode_dev=None):
+    """vil_full_attention on ONE packed (B, N, 3C) projection [q | k | v] (the layer's query and kv weights applied as a
+    single GEMM): q, k, v are strided views for the kernels and the gradient comes back as one (B, N, 3C) tensor, so the
+    input gradient of the projection is one GEMM instead of two plus an accumulation pass."""
+    if exact not in (0, 1, -1) or (exact == 1 and mode != 0):
+        raise ValueError("longsc exact should be in [0,1,-1]!")
+    assert 1 <= nglo <= FULL_MAX_G
+    cfg = _cfg(qkv.shape[-1] // 3, nx, ny, w, nglo, num_heads, mode, exact, scale)
+    if mode_dev is not None:
+        assert mode > 0 and mode_dev.dtype == torch.int32 and mode_dev.is_cuda
+        cfg["mode_dev"] = mode_dev.data_ptr()
+    return _VilQKVAttention.apply(qkv, bias_table, g2l_bias, g2g_bias, cfg, backend or DEFAULT_BACKEND)
+
+
 def vil_dense_attention(qkv, bias_table, g2l_bias, g2g_bias, *, nx, ny, nglo, num_heads, scale=None, backend=None):
     """Dense attention over an (nglo + nx*ny)-token sequence with the Swin-style relative position bias
     of the `s0` stages (reference msvit.py:37-120), expressed as the ONE-CHUNK case of the sliding-chunk
