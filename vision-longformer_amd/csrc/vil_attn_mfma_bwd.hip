@@ -423,18 +423,18 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
   }
   if (bc.do_hist) {
     __syncthreads();
-    int* out = (int*)bc.hist_parts + ((int64_t)bh * bc.dq_wg_per_bh + wgi) * c.tabsize;   // layout k_mfma_reduce_hist reads
+    int* out = (int*)bc.hist_parts + ((int64_t)bh * bc.dq_wg_per_bh + wgi) * c.tabsize;   // layout reduce_hist_block reads
     for (int i = tid; i < c.tabsize; i += blockDim.x) out[i] = hist[i];
     if (logical == 0 && tid == 0) ((int*)bc.norm2)[2] = lfx;      // the reduce needs the scale
   }
 }
 
 // d(table)[idx*H+h] and d(g2l)[h*G+g] from the per-workgroup histograms.
-// grid (ceil(tabsize/64), H), block 1024 = 64 bins x 16 partial groups (4 independent loads in flight each).
-__global__ void k_mfma_reduce_hist(VilParams p, MfmaCfg c, BwdCfg bc) {
+// One 1024-thread workgroup per (64 bins, head) = 64 bins x 16 partial groups (4 independent loads in flight each);
+// a role of k_mfma_post_bwd.
+__device__ __forceinline__ void reduce_hist_block(const VilParams& p, const MfmaCfg& c, const BwdCfg& bc, int bx, int h) {
   __shared__ long long red[16][64];
-  const int h = blockIdx.y;
-  const int bin = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  const int bin = bx * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
   long long si = 0;
   if (bin < c.tabsize) {
     // workgroups of head h: logical = (b*H + h)*wg_per_bh + w
@@ -1132,11 +1132,12 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
 // One workgroup per (image, head, global token gk):
 //   dk/dv rows of global KEY gk   = sum over the splits' fp32 partials (glo_parts)
 //   dq row of global QUERY gk     = scale * sum over the units' partials (gq_parts), and its d(g2l[0]) share
+// (the first 256 threads of a k_mfma_post_bwd workgroup)
 template <typename T>
-__global__ __launch_bounds__(256) void k_mfma_reduce_glo(VilParams p, BwdCfg bc, int nslots) {
+__device__ __forceinline__ void reduce_glo_block(const VilParams& p, const BwdCfg& bc, int nslots, int blk) {
   __shared__ float red[4][2][64];
   const int M = p.M, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int gk = blockIdx.x % p.G, bh = blockIdx.x / p.G;
+  const int gk = blk % p.G, bh = blk / p.G;
   const int b = bh / p.H, h = bh % p.H;
   {
     // dk / dv rows of global key gk: sum of glo_nrec records of 2M floats (up to hundreds in by-product mode): the four
@@ -1211,6 +1212,21 @@ __global__ __launch_bounds__(256) void k_mfma_reduce_glo(VilParams p, BwdCfg bc,
     const float bs = M == 64 ? a1 : a0;              // column M
     if (p.dg2l0 && lane == (M & 63)) atomicAdd(&p.dg2l0[h * p.G + gk], bs);
   }
+}
+
+// Backward epilogue, ONE launch with two roles (separate launches cost ~11 us each for a few microseconds of work):
+// [0, nglo) the global-token reductions (first 256 threads; the other waves of the workgroup end at once, and a
+// workgroup barrier only waits for waves that are still alive), then (64 bins, head) blocks of the histogram reduce.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_mfma_post_bwd(VilParams p, MfmaCfg c, BwdCfg bc, int nslots, int nglo, int nhx) {
+  const int blk = blockIdx.x;
+  if (blk < nglo) {
+    if (threadIdx.x < 256) reduce_glo_block<T>(p, bc, nslots, blk);
+    return;
+  }
+  const int hb = blk - nglo;
+  const int h = hb / nhx;
+  reduce_hist_block(p, c, bc, hb - h * nhx, h);
 }
 
 // rowsum(dO * O): LPR lanes per (image, head, token) row, each lane one (or three) 16-byte pieces of the
@@ -1463,17 +1479,17 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
   }
-  if (p.G > 0) {
-    vil_prof_begin(VIL_K_REDUCE_GLO, s, 0, 0);
-    if (d->dtype == VIL_DTYPE_F16) k_mfma_reduce_glo<_Float16><<<dim3((unsigned)(p.B * p.H * p.G)), dim3(256), 0, s>>>(p, bc, bc.nch * bc.kv_NWP + 1);
-    else k_mfma_reduce_glo<__bf16><<<dim3((unsigned)(p.B * p.H * p.G)), dim3(256), 0, s>>>(p, bc, bc.nch * bc.kv_NWP + 1);
-    vil_prof_end(s);
-    if ((e = (int)hipGetLastError())) return e;
-  }
-  if (bc.do_hist) {
-    vil_prof_begin(VIL_K_REDUCE_BIAS, s, 0, 0);
-    k_mfma_reduce_hist<<<dim3((unsigned)((c.tabsize + 63) / 64), p.H), dim3(1024), 0, s>>>(p, c, bc);
-    vil_prof_end(s);
+  {
+    const int nglo = p.G > 0 ? p.B * p.H * p.G : 0, nhx = (c.tabsize + 63) / 64;
+    const int nh = bc.do_hist ? nhx * p.H : 0;
+    if (nglo + nh > 0) {
+      vil_prof_begin(VIL_K_REDUCE_GLO, s, 0, 0);
+      if (d->dtype == VIL_DTYPE_F16)
+        k_mfma_post_bwd<_Float16><<<dim3((unsigned)(nglo + nh)), dim3(1024), 0, s>>>(p, c, bc, bc.nch * bc.kv_NWP + 1, nglo, nhx);
+      else
+        k_mfma_post_bwd<__bf16><<<dim3((unsigned)(nglo + nh)), dim3(1024), 0, s>>>(p, c, bc, bc.nch * bc.kv_NWP + 1, nglo, nhx);
+      vil_prof_end(s);
+    }
   }
   return (int)hipGetLastError();
 }
