@@ -208,7 +208,11 @@ static void wgrad_plan(int64_t T, int CO, int CI, int& tiles_co, int& tiles_ci, 
   tiles_co = (CO + WG_TILE - 1) / WG_TILE; tiles_ci = (CI + WG_TILE - 1) / WG_TILE;
   const int tiles = tiles_co * tiles_ci;
   static const int target = [] { const char* e = getenv("VIL_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
-  int64_t s = ((target + tiles - 1) / tiles + 7) / 8 * 8;        // ~2 workgroups per CU, whole XCD rounds (tuning hook: VIL_WGRAD_WGS)
+  // ~2 workgroups per CU, whole XCD rounds (tuning hook: VIL_WGRAD_WGS).  The HBM-bound shapes (>= 64 k tokens into >= 3
+  // output tiles: the fc / qkv layers of stages 1-2) run 8-12 % faster with 3 per CU (tools/wgrad_probe2.py); the
+  // MFMA-bound ones (stages 3-4) and the one- and two-tile outputs lose 10-25 % there
+  const int tgt = (getenv("VIL_WGRAD_WGS") == nullptr && T >= 65536 && tiles >= 3) ? 768 : target;
+  int64_t s = ((tgt + tiles - 1) / tiles + 7) / 8 * 8;
   const int64_t max_by_rows = (T + 4 * WG_ROWS - 1) / (4 * WG_ROWS);   // >= 4 steps per workgroup
   const int64_t max_by_ws = ((int64_t)96 << 20) / ((int64_t)CO * CI * 4);
   if (s > max_by_rows) s = max_by_rows;
