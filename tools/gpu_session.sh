@@ -80,7 +80,7 @@ for STEP in "$@"; do
       cat "$OUT/wgrad_probe.txt" ;;
     kvtiming)     # per-segment cycle budget of the dK/dV waves (diagnostics build, tools/kv_timing.py)
       for SH in ${KVT_SHAPES:-small_s1 small_s3_dense}; do
-        for LIB in tools/ab/off/libvilattn_kvtiming*.so; do
+        for LIB in tools/ab/libvilattn_kvtiming*.so; do
           echo "== $LIB" >> "$OUT/kv_timing.txt"
           VIL_ATTN_LIB=$PWD/$LIB timeout 300 python tools/kv_timing.py $SH >> "$OUT/kv_timing.txt" 2>&1
         done
