@@ -5,8 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W      (one rank per GPU, RCCL)
 
-One "step" = forward + backward + AdamW step of the named ViL on one synthetic
-ImageNet-shape batch already resident in HBM (bf16 autocast, fp32 master weights).
+One "step" = forward + backward + the optimizer step of the reference's recipe (AdamW for the 224 training recipe,
+QHM for the 384 fine-tuning recipe; the reference's update rules on the HIP multi-tensor kernel) of the named ViL on
+one synthetic ImageNet-shape batch already resident in HBM (bf16 autocast, fp32 master weights).
 W untimed warm-up steps, then exactly K steps bracketed by barrier +
 torch.cuda.synchronize(); the elapsed time is the MAX over ranks; rank 0 prints ONE
 JSON line.  `value` = images of all ranks / that time (weak scaling: fixed per-GPU batch).
@@ -51,9 +52,10 @@ F32_VALU_PEAK_TFLOPS = 157.3
 
 def cpu_baseline(config, seconds):
     """Bounded CPU sample: the same host model with every hot-path layer computed by the
-    oracle (fp32, B=2), fwd + bwd + AdamW, on this box's host cores."""
+    oracle (fp32, B=2), fwd + bwd + the reference optimizer (oracle restatement), on this box's host cores."""
     from oracle.cpu_model import build_cpu_baseline_model
-    from vision_longformer_amd.engine import CONFIGS, make_optimizer, SyntheticBatches, train_step
+    from oracle import optim_oracle
+    from vision_longformer_amd.engine import CONFIGS, make_optimizer, recipe_of, SyntheticBatches, train_step
     cores = len(os.sched_getaffinity(0))
     threads = min(cores, 32)          # measured: 64 threads across two sockets are slower than 8-32
     torch.set_num_threads(threads)
@@ -61,7 +63,7 @@ def cpu_baseline(config, seconds):
     img = CONFIGS[config][1]
     B = 2
     model = build_cpu_baseline_model(config).train()
-    opt = make_optimizer(model)
+    opt = make_optimizer(model, kind=recipe_of(config), optimizer_module=optim_oracle)     # the reference's update rule on CPU
     data = SyntheticBatches(B, img, torch.device("cpu"))
     train_step(model, opt, *data.next(), amp_dtype=None)           # warm-up
     n, t0 = 0, time.perf_counter()
@@ -80,7 +82,7 @@ def cpu_baseline(config, seconds):
     except OSError:
         pass
     return {"value": round(B * n / el, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{n} train steps (fwd+bwd+AdamW) of {config}, batch {B}, fp32, oracle hot path, "
+            "sample": f"{n} train steps (fwd+bwd+{recipe_of(config)}) of {config}, batch {B}, fp32, oracle hot path, "
                       f"{threads} threads of {cores} logical cores, {cpu}, {el:.1f} s"}
 
 
@@ -197,13 +199,15 @@ def measure(args, config, B, steps, warmup, rank, world, device):
     profiled eager replay.  Returns the result dict pieces (rank-0 meaningful)."""
     from vision_longformer_amd import _lib
     from vision_longformer_amd.engine import (CONFIGS, build_vil, make_optimizer, wrap_ddp, SyntheticBatches, train_step,
-                                             GraphedTrainStep, MasterWeightAdamW)
+                                             GraphedTrainStep, MasterWeightOptimizer, recipe_of)
+    kind = recipe_of(config)
     fam, img, cfg_batch, f1, f2, mode = CONFIGS[config]
     torch.manual_seed(0)
     model = build_vil(config).to(device).train()
     use_graph = args.graph in ("on", "auto")
     use_master = args.master_weights == "on"
-    opt = MasterWeightAdamW(model, capturable=use_graph) if use_master else make_optimizer(model, capturable=use_graph)
+    opt = (MasterWeightOptimizer(model, kind=kind, capturable=use_graph) if use_master
+           else make_optimizer(model, kind=kind, capturable=use_graph))
     data = SyntheticBatches(B, img, device, rank)
     if use_graph:
         def agree(ok):                   # every rank takes the same branch (a lone eager rank would dead-lock the others)
@@ -239,7 +243,7 @@ def measure(args, config, B, steps, warmup, rank, world, device):
             torch.cuda.synchronize()
             torch.manual_seed(0)
             model = build_vil(config).to(device).train()
-            opt = MasterWeightAdamW(model) if use_master else make_optimizer(model)
+            opt = MasterWeightOptimizer(model, kind=kind) if use_master else make_optimizer(model, kind=kind)
     if use_graph:
         step_fn = lambda xb, tb: gstep(xb, tb)
     else:
@@ -285,7 +289,7 @@ def measure(args, config, B, steps, warmup, rank, world, device):
     loss_val = float(loss.item())
     comm = gstep.comm_summary() if (use_graph and world > 1) else None
     del step_fn
-    return dict(elapsed=elapsed, recs=recs, nprof=nprof, loss=loss_val, use_graph=use_graph, use_master=use_master,
+    return dict(elapsed=elapsed, recs=recs, nprof=nprof, loss=loss_val, use_graph=use_graph, use_master=use_master, optimizer=kind,
                 fam=fam, img=img, f1=f1, f2=f2, mode=mode, comm=comm)
 
 
@@ -302,7 +306,7 @@ def main():
                     help="skip the ViL-Medium-Deep@384 leg (the second half of BASELINE's metric) of the default run")
     ap.add_argument("--backend", default="auto", choices=["auto", "scalar", "mfma"])
     ap.add_argument("--master-weights", default="on", choices=["on", "off"],
-                    help="bf16 working weights + fp32 master (engine.MasterWeightAdamW) instead of per-call autocast casts")
+                    help="bf16 working weights + fp32 master (engine.MasterWeightOptimizer) instead of per-call autocast casts")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="run the step as hipGraphs (auto = on; random-shift neighbours are device-side words refreshed per replay); "
                          "off = eager step under DDP (bucketed all-reduce overlapped with backward)")
@@ -329,14 +333,14 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(m_["elapsed"] / steps * 1e3, 3),
             "config": {"workload": f"{config}: ViL ({m_['fam']}) ATTN_TYPE=longformerhand rpe, {m_['img']}x{m_['img']}, "
-                                   f"windows f{m_['f1']}/f{m_['f2']}, train step fwd+bwd+AdamW, random-init weights",
+                                   f"windows f{m_['f1']}/f{m_['f2']}, train step fwd+bwd+{m_['optimizer']} (reference update rule), random-init weights",
                        "global_batch": B_ * world, "per_gpu_batch": B_, "parallelism": f"dp{world}",
                        "backend": args.backend, "random_shift_mode": m_["mode"],
-                       "precision": "bf16 compute, fp32 master weights + fp32 AdamW state"
-                                    + (" (bf16 working copy, foreach refresh)" if m_["use_master"] else " (autocast casts)"),
-                       "launch": ("hipGraph replay (fwd+bwd+AdamW)" if world == 1 else
+                       "precision": "bf16 compute, fp32 master weights + fp32 optimizer state"
+                                    + (" (bf16 working copy written by the optimizer kernel)" if m_["use_master"] else " (autocast casts)"),
+                       "launch": ("hipGraph replay (fwd+bwd+optimizer)" if world == 1 else
                                   "hipGraph replay per stage segment (fwd+bwd), flat-gradient RCCL all-reduce per segment on a side "
-                                  "stream overlapped with the next segment's replay, hipGraph replay (AdamW)")
+                                  "stream overlapped with the next segment's replay, hipGraph replay (optimizer)")
                                  if m_["use_graph"] else "eager (DDP bucketed all-reduce)"},
             "roofline": roofline_of(config, B_, shapes, tags),
             "roofline_by_shape": shapes,

@@ -284,6 +284,42 @@ int vil_gemm_bf16(int op, const void* in, const void* w, const void* bias, void*
 int vil_gemm_tune(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
                   int64_t in_row_stride, int64_t out_row_stride, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- the optimizer step of the training loop as ONE multi-tensor launch on fp32 master weights.
+ * Replaces torch.optim's per-recipe optimizers of the reference with its own update rules:
+ *   vil_optim_adamw_step   src/optim/optimization.py:111-193 (AdamW: denom = sqrt(v) + eps with eps OUTSIDE the bias
+ *                          correction, step_size = lr sqrt(1-b2^t)/(1-b1^t), decoupled decay p -= lr wd p AFTER the
+ *                          Adam update; the optimizer of config/msvit.yaml:32-47)
+ *   vil_optim_qhm_step     src/optim/qhm.py:55-130 (QHM: g += wd p; h = beta h + (1-beta) g; d = (1-nu) g + nu h;
+ *                          p -= lr d; the optimizer of config/msvit_384finetune.yaml:28-35)
+ * Each tensor is described by a VilOptimTensor: fp32 `param` (updated in place), its gradient in the dtype autograd
+ * produced it in, fp32 state tensors, and optionally the 16-bit working copy (`low`) of the parameter, refreshed in
+ * the same pass.  A PLAN (header + descriptors + a table of 4096-element blocks) is built on the host
+ * (vil_optim_plan_build into a caller buffer of vil_optim_plan_bytes bytes), uploaded by the caller to 16-byte
+ * aligned device memory and reused by every step while the tensor addresses are unchanged (hipGraph replay).
+ * `step_words` = two device int32: [0] the number of completed steps t (the launch applies step t + 1 and its last
+ * workgroup increments the word), [1] an arrival ticket that must be 0 before the first launch.  The learning rate
+ * is per tensor (= per param group): a host value, or a device float that a per-iteration schedule updates in place
+ * so that a captured step follows it.  Asynchronous on `stream`. */
+typedef struct VilOptimTensor {
+  void* param;            /* fp32, n elements                                             */
+  const void* grad;       /* grad_dtype, n elements                                       */
+  void* state1;           /* fp32: AdamW exp_avg / QHM momentum buffer                    */
+  void* state2;           /* fp32: AdamW exp_avg_sq; unused by QHM (may be NULL)          */
+  void* low;              /* low_dtype working copy written with the updated value, or NULL */
+  int64_t n;
+  int32_t grad_dtype;     /* VIL_DTYPE_F32 / _BF16 / _F16                                 */
+  int32_t low_dtype;      /* VIL_DTYPE_BF16 / _F16                                        */
+  float weight_decay;     /* the param group's weight_decay                               */
+  float lr;               /* the param group's learning rate, used when lr_dev is NULL     */
+  const float* lr_dev;    /* device float holding the learning rate (a captured step follows a per-iteration
+                             schedule that updates it in place), or NULL                   */
+} VilOptimTensor;
+size_t vil_optim_plan_bytes(const VilOptimTensor* tensors, int ntensors);
+int vil_optim_plan_build(const VilOptimTensor* tensors, int ntensors, void* host_plan, size_t bytes, int* nblocks);
+int vil_optim_adamw_step(const void* plan_dev, int nblocks, float beta1, float beta2, float eps, int correct_bias,
+                         int32_t* step_words, void* stream);
+int vil_optim_qhm_step(const void* plan_dev, int nblocks, float momentum, float nu, int32_t* step_words, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -250,3 +250,38 @@ def test_patchify_entry_points_validate_before_launching():
     assert b(a16, BF16, a16, None, a16, BF16, 2, 1, 8, 8, 96, 2, 2, None) == -1
     assert b(a16, BF16, a16, a16, a16, F16, 2, 1, 8, 8, 96, 2, 2, None) == -7
     assert b(a16, BF16, a16, a16, None, 0, 0, 1, 8, 8, 96, 2, 2, None) == -2
+
+
+def test_optimizer_entry_points_plan_and_validate_on_the_host():
+    """vil_optim_* (the reference's AdamW / QHM as one multi-tensor launch): the descriptor struct matches the header,
+    the plan builder lays out header + descriptors + 4096-element blocks, and argument errors come back as VIL_E_*
+    codes without touching a device."""
+    L = _lib.lib()
+    vp = ctypes.c_void_p
+    assert ctypes.sizeof(_lib.VilOptimTensor) == 5 * 8 + 8 + 4 * 4 + 8
+    T = _lib.VilOptimTensor
+    arr = (T * 3)()
+    for i, n in enumerate((10000, 37, 4096)):
+        arr[i].param, arr[i].grad, arr[i].state1, arr[i].state2 = 4096, 8192, 12288, 16384
+        arr[i].n, arr[i].grad_dtype, arr[i].low_dtype, arr[i].weight_decay = n, _lib.DTYPE_BF16, _lib.DTYPE_BF16, 0.05
+    nbytes = L.vil_optim_plan_bytes(arr, 3)
+    assert nbytes == 16 + 3 * ctypes.sizeof(T) + (3 + 1 + 1) * 16
+    buf = (ctypes.c_char * nbytes)()
+    nb = ctypes.c_int(0)
+    assert L.vil_optim_plan_build(arr, 3, buf, nbytes, ctypes.byref(nb)) == 0 and nb.value == 5
+    hdr = np.frombuffer(buf, dtype=np.int32, count=4)
+    assert hdr[0] == 3 and hdr[1] == 5
+    blocks = np.frombuffer(buf, dtype=np.int64, offset=16 + 3 * ctypes.sizeof(T)).reshape(5, 2)
+    assert [int(b[0] & 0xffffffff) for b in blocks] == [0, 0, 0, 1, 2] and [int(b[1]) for b in blocks] == [0, 4096, 8192, 0, 0]
+    assert L.vil_optim_plan_build(arr, 3, buf, nbytes - 1, ctypes.byref(nb)) == -9
+    arr[1].grad_dtype = _lib.DTYPE_F64
+    assert L.vil_optim_plan_build(arr, 3, buf, nbytes, ctypes.byref(nb)) == -7
+    arr[1].grad_dtype = _lib.DTYPE_F32
+    arr[2].n = 0
+    assert L.vil_optim_plan_build(arr, 3, buf, nbytes, ctypes.byref(nb)) == -2
+    a16 = vp(4096)
+    assert L.vil_optim_adamw_step(None, 5, 0.9, 0.999, 1e-6, 1, a16, None) == -1
+    assert L.vil_optim_adamw_step(a16, 5, 1.0, 0.999, 1e-6, 1, a16, None) == -2      # beta1 in [0, 1)
+    assert L.vil_optim_adamw_step(vp(4100), 5, 0.9, 0.999, 1e-6, 1, a16, None) == -8
+    assert L.vil_optim_qhm_step(a16, 0, 0.9, 1.0, a16, None) == -2
+    assert L.vil_optim_qhm_step(a16, 5, 1.5, 1.0, a16, None) == -2

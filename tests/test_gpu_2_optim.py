@@ -1,0 +1,170 @@
+"""GPU (-m gpu): the optimizer step -- the reference's AdamW / QHM update rules on the HIP multi-tensor
+kernel (csrc/vil_optim.hip through vision_longformer_amd.optim) against the parameters the imported reference
+optimizers produced (tests/golden/optim_reference.npz), with fp32 and 16-bit gradients, the fused 16-bit working copy,
+hipGraph replay and checkpoint round trips."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import optim_cases as OC
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optim_reference.npz")
+# fp32 tensors, same operation order as the reference; the CPU reference contracts `a + alpha*b` into an FMA in its
+# vectorised loops and not in its scalar tails, the kernel never contracts: a few ulp per step
+RTOL, ATOL = 2e-6, 2e-8
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _hip_opt(kind, groups, hyper):
+    from vision_longformer_amd import optim
+    return optim.AdamW(groups, **hyper) if kind == "adamw" else optim.QHM(groups, **hyper)
+
+
+def _run(dev, name, grad_dtype, bind_low):
+    """the seeded case on the GPU; returns (params after every step, working copies after the last step)"""
+    kind, hyper, wds = OC.CASES[name]
+    params, grads = OC.make_inputs()
+    ps = [torch.nn.Parameter(p.clone().to(dev)) for p in params]
+    lows = [torch.nn.Parameter(p.clone().to(dev, torch.bfloat16)) for p in params] if bind_low else None
+    groups = [{"params": ps[0::2], "weight_decay": wds[0]}, {"params": ps[1::2], "weight_decay": wds[1]}]
+    opt = _hip_opt(kind, groups, hyper)
+    if bind_low:
+        for p, l in zip(ps, lows):
+            opt.bind_working_copy(p, l)
+    out = []
+    for k in range(OC.NSTEPS):
+        for i, (p, g) in enumerate(zip(ps, grads[k])):
+            if bind_low:
+                lows[i].grad = g.to(dev, grad_dtype)
+            else:
+                p.grad = g.to(dev, grad_dtype)
+        opt.step()
+        out.append([p.detach().float().cpu().clone() for p in ps])
+    return out, lows, ps, opt
+
+
+@pytest.mark.parametrize("name", list(OC.CASES))
+@pytest.mark.parametrize("grad_dtype", [torch.float32, torch.bfloat16])
+def test_optimizer_kernel_vs_reference_fixtures(dev, name, grad_dtype):
+    gold = np.load(GOLD)
+    got, _, _, _ = _run(dev, name, grad_dtype, bind_low=False)
+    worst = 0.0
+    for k in (0, OC.NSTEPS - 1):
+        for i, t in enumerate(got[k]):
+            ref = torch.from_numpy(gold[f"{name}/step{k + 1}/p{i}"])
+            torch.testing.assert_close(t, ref, rtol=RTOL, atol=ATOL, msg=lambda m: f"{name} step {k + 1} tensor {i}: {m}")
+            worst = max(worst, float(((t - ref).abs() / (ATOL + RTOL * ref.abs())).max()))
+    assert worst <= 1.0
+
+
+@pytest.mark.parametrize("name", ["adamw_recipe", "qhm_recipe", "qhm_nu07_wd"])
+def test_optimizer_kernel_writes_the_working_copy_in_the_same_pass(dev, name):
+    gold = np.load(GOLD)
+    got, lows, ps, _ = _run(dev, name, torch.bfloat16, bind_low=True)
+    for i, t in enumerate(got[-1]):
+        ref = torch.from_numpy(gold[f"{name}/step{OC.NSTEPS}/p{i}"])
+        torch.testing.assert_close(t, ref, rtol=RTOL, atol=ATOL)
+        assert torch.equal(lows[i].detach(), ps[i].detach().to(torch.bfloat16)), i      # bf16(master), written by the kernel
+
+
+def test_optimizer_kernel_under_hipgraph_replay_with_device_lr(dev):
+    """One captured launch replayed N times == N eager steps: the plan of the captured addresses is uploaded on a
+    side stream, the step counter advances on the device, the lr is a device tensor the schedule updates in place."""
+    from vision_longformer_amd import optim
+    kind, hyper, wds = OC.CASES["adamw_recipe"]
+    params, grads = OC.make_inputs()
+
+    def make(lr):
+        ps = [torch.nn.Parameter(p.clone().to(dev)) for p in params]
+        h = dict(hyper); h["lr"] = lr
+        return ps, optim.AdamW([{"params": ps[0::2], "weight_decay": wds[0]}, {"params": ps[1::2], "weight_decay": wds[1]}], **h)
+
+    lrs = [5e-4, 4e-4, 3e-4, 2e-4, 1e-4]
+    pe, oe = make(lrs[0])
+    for k in range(OC.NSTEPS):
+        for g_ in oe.param_groups:
+            g_["lr"] = lrs[k]
+        for p, g in zip(pe, grads[k]):
+            p.grad = g.to(dev)
+        oe.step()
+    lr_dev = torch.tensor(lrs[0], device=dev)
+    pg, og = make(lr_dev)
+    static = [torch.zeros_like(p) for p in pg]
+    for p, s in zip(pg, static):
+        p.grad = s
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="allocate"):
+        with torch.cuda.graph(torch.cuda.CUDAGraph()):
+            og.step()
+    torch.cuda.synchronize()
+    og.allocate()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        og.step()
+    og.after_capture()
+    for k in range(OC.NSTEPS):
+        lr_dev.fill_(lrs[k])
+        for s, g in zip(static, grads[k]):
+            s.copy_(g)
+        graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(pe, pg):
+        assert torch.equal(a.detach(), b.detach())
+
+
+def test_optimizer_state_dict_round_trip_in_place(dev):
+    """load_state_dict copies the moments INTO the existing tensors (a captured step keeps reading them), keeps the lr
+    object and restores the step count: the resumed run continues bit-identically."""
+    from vision_longformer_amd import optim
+    kind, hyper, wds = OC.CASES["adamw_defaults"]
+    params, grads = OC.make_inputs()
+
+    def make():
+        ps = [torch.nn.Parameter(p.clone().to(dev)) for p in params]
+        return ps, optim.AdamW([{"params": ps[0::2], "weight_decay": wds[0]}, {"params": ps[1::2], "weight_decay": wds[1]}], **hyper)
+
+    pa, oa = make()
+    for k in range(3):
+        for p, g in zip(pa, grads[k]):
+            p.grad = g.to(dev)
+        oa.step()
+    sd = oa.state_dict()
+    assert sd["vil_steps"] == [3]
+    pb, ob = make()
+    for p, g in zip(pb, grads[0]):
+        p.grad = g.to(dev)
+    ob.step()                                        # state tensors exist before the load
+    ptr = ob.state[pb[0]]["exp_avg"].data_ptr()
+    with torch.no_grad():
+        for a, b in zip(pa, pb):
+            b.copy_(a)
+    ob.load_state_dict(sd)
+    assert ob.state[pb[0]]["exp_avg"].data_ptr() == ptr
+    for k in range(3, OC.NSTEPS):
+        for p, q, g in zip(pa, pb, grads[k]):
+            p.grad = g.to(dev); q.grad = g.to(dev)
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert torch.equal(a.detach(), b.detach())
+
+
+def test_optimizer_rejects_cpu_tensors():
+    from vision_longformer_amd import optim
+    p = torch.nn.Parameter(torch.zeros(8))
+    p.grad = torch.ones(8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        optim.AdamW([p], lr=1e-3).step()
+    with pytest.raises(ValueError):
+        optim.AdamW([p], lr=-1.0)
+    with pytest.raises(ValueError):
+        optim.QHM([p], lr=0.1, momentum=1.5)

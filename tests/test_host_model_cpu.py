@@ -11,6 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from vision_longformer_amd.engine import build_vil, make_optimizer, param_groups, CONFIGS
+from oracle import optim_oracle as OO        # the CPU stand-in for the HIP optimizer kernels (host-logic tests only)
 from vision_longformer_amd.msvit import MsViT, parse_arch, vil_arch
 from vision_longformer_amd.longformer2d import Long2DSCSelfAttention
 
@@ -90,7 +91,7 @@ def _ddp_worker(rank, world, port, ret):
     for mod in model.modules():
         if isinstance(mod, Long2DSCSelfAttention):
             mod.forward = types.MethodType(_oracle_forward, mod)
-    opt = make_optimizer(model, lr=1e-2)
+    opt = make_optimizer(model, lr=1e-2, optimizer_module=OO)
     ddp = wrap_ddp(model, device, world)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(4, 3, 32, 32, generator=g)
@@ -124,7 +125,7 @@ def test_ddp_gloo_world2_matches_single_process():
     for mod in model.modules():
         if isinstance(mod, Long2DSCSelfAttention):
             mod.forward = types.MethodType(_oracle_forward, mod)
-    opt = make_optimizer(model, lr=1e-2)
+    opt = make_optimizer(model, lr=1e-2, optimizer_module=OO)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(4, 3, 32, 32, generator=g)
     t = torch.softmax(torch.randn(4, 10, generator=g), -1)
@@ -152,8 +153,8 @@ def test_master_weight_adamw_matches_plain_adamw_in_fp32():
     x = torch.randn(4, 3, 32, 32, generator=g)
     t = torch.softmax(torch.randn(4, 10, generator=g), -1)
     a, b = make(), make()
-    oa = make_optimizer(a, lr=1e-2)
-    ob = MasterWeightAdamW(b, lr=1e-2, low_dtype=torch.float32)
+    oa = make_optimizer(a, lr=1e-2, optimizer_module=OO)
+    ob = MasterWeightAdamW(b, lr=1e-2, low_dtype=torch.float32, optimizer_module=OO)
     assert len(ob.low) > 10 and len(ob.direct) > 5
     for _ in range(2):
         train_step(a, oa, x, t, amp_dtype=None)
@@ -169,7 +170,7 @@ def test_master_weight_adamw_state_dict_roundtrip_and_fp32_export():
     from vision_longformer_amd.engine import MasterWeightAdamW, set_lr
     torch.manual_seed(0)
     m = MsViT(SMALL_ARCH, img_size=32, num_classes=10, sharew=True)
-    opt = MasterWeightAdamW(m, lr=1e-2)
+    opt = MasterWeightAdamW(m, lr=1e-2, optimizer_module=OO)
     for p in opt.low:
         p.grad = torch.randn_like(p)
     for p in opt.direct:
@@ -184,7 +185,7 @@ def test_master_weight_adamw_state_dict_roundtrip_and_fp32_export():
     # resume into a fresh model / optimizer
     torch.manual_seed(1)
     m2 = MsViT(SMALL_ARCH, img_size=32, num_classes=10, sharew=True)
-    opt2 = MasterWeightAdamW(m2, lr=1e-2)
+    opt2 = MasterWeightAdamW(m2, lr=1e-2, optimizer_module=OO)
     opt2.load_state_dict(sd)
     for a, b in zip(opt.master, opt2.master):
         assert torch.equal(a, b)
@@ -192,8 +193,23 @@ def test_master_weight_adamw_state_dict_roundtrip_and_fp32_export():
         assert torch.equal(a, b) and b.dtype == torch.bfloat16
     s1, s2 = opt.opt.state_dict()["state"], opt2.opt.state_dict()["state"]
     assert s1.keys() == s2.keys() and all(torch.equal(s1[k]["exp_avg"], s2[k]["exp_avg"]) for k in s1)
+    # the schedule must reach the INNER optimizer after a resume (its param_groups dicts are replaced by the load)
     set_lr(opt2, 5e-4)
-    assert all(float(g["lr"]) == 5e-4 for g in opt2.param_groups)
+    assert all(float(g["lr"]) == 5e-4 for g in opt2.opt.param_groups)
+    w0 = opt2.master[0].detach().clone()
+    for p in opt2.low:
+        p.grad = torch.ones_like(p)
+    for p in opt2.direct:
+        p.grad = torch.ones_like(p)
+    opt2.step()
+    # Adam's first resumed update of a weight with |m/sqrt(v)| ~ 1 moves it by about lr, not by the checkpointed 1e-2
+    assert float((opt2.master[0] - w0).abs().max()) < 5e-3
+
+
+def test_cpu_optimizer_is_refused_without_the_oracle_module():
+    m = MsViT(SMALL_ARCH, img_size=32, num_classes=10, sharew=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        make_optimizer(m)
 
 
 def test_attn_drop_in_training_is_refused_not_ignored():

@@ -121,3 +121,31 @@ def test_dense_closed_form_matches_chunked(c):
     a = O.local_attention(q, k, v, c["nx"], c["ny"], c["W"], G, **kw)
     b = O.local_attention_dense(q, k, v, c["nx"], c["ny"], c["W"], G, **kw)
     torch.testing.assert_close(a, b, rtol=1e-10, atol=1e-12)
+
+
+def test_optimizer_oracle_reproduces_the_reference_fixtures():
+    """oracle/optim_oracle.py (AdamW with the reference's eps / decay placement, QHM) against the parameters the
+    imported reference optimizers produced after 1 and 5 steps (tools/gen_golden_optim.py): bit-identical on CPU."""
+    import optim_cases as OC
+    from oracle import optim_oracle as OO
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optim_reference.npz"))
+
+    def ora(kind, groups, hyper):
+        return OO.AdamW(groups, **hyper) if kind == "adamw" else OO.QHM(groups, **hyper)
+
+    torch.set_num_threads(1)
+    for name in OC.CASES:
+        got = OC.run_case(ora, name)
+        for k in (0, OC.NSTEPS - 1):
+            for i, t in enumerate(got[k]):
+                assert np.array_equal(t.numpy(), gold[f"{name}/step{k + 1}/p{i}"]), (name, k, i)
+
+
+def test_reference_adamw_differs_from_torch_adamw():
+    """Why the build does not use torch.optim.AdamW: eps placement and decay order differ measurably."""
+    import optim_cases as OC
+    from oracle import optim_oracle as OO
+    kind, hyper, wds = OC.CASES["adamw_recipe"]
+    ref = OC.run_case(lambda k, g, h: OO.AdamW(g, **h), "adamw_recipe")
+    tor = OC.run_case(lambda k, g, h: torch.optim.AdamW(g, lr=h["lr"], betas=h["betas"], eps=h["eps"]), "adamw_recipe")
+    assert max(float((a - b).abs().max()) for a, b in zip(ref[-1], tor[-1])) > 1e-7

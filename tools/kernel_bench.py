@@ -9,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from vision_longformer_amd import _lib
+if os.environ.get("VIL_ATTN_LIB"):          # A/B against a library built from another revision (tools/ab/)
+    _lib.use_library_for_ab(os.environ["VIL_ATTN_LIB"])
 from vision_longformer_amd.ops import vil_local_attention, vil_dense_attention
 
 SHAPES = {  # H, M, W, nx, ny, G, mode, B

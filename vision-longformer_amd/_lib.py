@@ -12,8 +12,17 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# VIL_ATTN_LIB: A/B benchmarking hook (tools/kernel_bench.py against a library built from another revision)
-LIB_PATH = os.environ.get("VIL_ATTN_LIB") or os.path.join(_HERE, "libvilattn.so")
+LIB_PATH = os.path.join(_HERE, "libvilattn.so")
+_AB_LIBRARY = False          # set only by use_library_for_ab() (tools/): entry points an older build lacks stay unbound
+
+
+def use_library_for_ab(path):
+    """tools/ only (A/B kernel timing against a library built from another revision): must be called before the
+    first lib().  The product never calls this; it loads the in-tree libvilattn.so or raises."""
+    global LIB_PATH, _AB_LIBRARY
+    if _lib is not None:
+        raise RuntimeError("use_library_for_ab() after the library was loaded")
+    LIB_PATH, _AB_LIBRARY = path, True
 
 DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F64 = 0, 1, 2, 3
 BACKEND_AUTO, BACKEND_SCALAR, BACKEND_MFMA = 0, 1, 2
@@ -28,7 +37,8 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_colsum_workspace_bytes", "vil_colsum_bf16", "vil_colsum_f32",
            "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad",
            "vil_resln_fwd", "vil_resln_bwd", "vil_gemm_workspace_bytes", "vil_gemm_bf16", "vil_gemm_tune",
-           "vil_sc2d_qk", "vil_sc2d_av", "vil_sc2d_agrad", "vil_sc2d_mask")
+           "vil_sc2d_qk", "vil_sc2d_av", "vil_sc2d_agrad", "vil_sc2d_mask",
+           "vil_optim_plan_bytes", "vil_optim_plan_build", "vil_optim_adamw_step", "vil_optim_qhm_step")
 
 
 class VilAttnDesc(ctypes.Structure):
@@ -41,6 +51,13 @@ class VilAttnDesc(ctypes.Structure):
 
 
 VIL_E_BACKEND = -10
+
+
+class VilOptimTensor(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("state1", ctypes.c_void_p),
+                ("state2", ctypes.c_void_p), ("low", ctypes.c_void_p), ("n", ctypes.c_int64),
+                ("grad_dtype", ctypes.c_int32), ("low_dtype", ctypes.c_int32), ("weight_decay", ctypes.c_float),
+                ("lr", ctypes.c_float), ("lr_dev", ctypes.c_void_p)]
 
 
 class VilAttnError(RuntimeError):
@@ -81,9 +98,8 @@ def lib():
         L.vil_attn_profile_begin.argtypes = [ctypes.c_int]
         L.vil_attn_profile_end.restype = ctypes.c_int
         L.vil_attn_profile_end.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
-        if hasattr(L, "vil_attn_profile_end2"):
-            L.vil_attn_profile_end2.restype = ctypes.c_int
-            L.vil_attn_profile_end2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5
+        L.vil_attn_profile_end2.restype = ctypes.c_int
+        L.vil_attn_profile_end2.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5
         L.vil_attn_kernel_name.restype = ctypes.c_char_p
         L.vil_attn_kernel_name.argtypes = [ctypes.c_int]
         i64 = ctypes.c_int64
@@ -116,15 +132,23 @@ def lib():
         L.vil_gemm_bf16.argtypes = [ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                     ctypes.c_int64, vp, ctypes.c_size_t, vp]
         ci = ctypes.c_int
-        if not (os.environ.get("VIL_ATTN_LIB") and not hasattr(L, "vil_sc2d_qk")):   # (A/B against an older revision)
-            for fn in (L.vil_sc2d_qk, L.vil_sc2d_av, L.vil_sc2d_agrad):
-                fn.restype = ci
-                fn.argtypes = [vp, vp, vp] + [ci] * 7 + [vp]
-            L.vil_sc2d_mask.restype = ci
-            L.vil_sc2d_mask.argtypes = [vp] + [ci] * 9 + [vp, vp]
-        if hasattr(L, "vil_gemm_tune"):
-            L.vil_gemm_tune.restype = ctypes.c_int
-            L.vil_gemm_tune.argtypes = L.vil_gemm_bf16.argtypes
+        for fn in (L.vil_sc2d_qk, L.vil_sc2d_av, L.vil_sc2d_agrad):
+            fn.restype = ci
+            fn.argtypes = [vp, vp, vp] + [ci] * 7 + [vp]
+        L.vil_sc2d_mask.restype = ci
+        L.vil_sc2d_mask.argtypes = [vp] + [ci] * 9 + [vp, vp]
+        L.vil_gemm_tune.restype = ctypes.c_int
+        L.vil_gemm_tune.argtypes = L.vil_gemm_bf16.argtypes
+        if not (_AB_LIBRARY and not hasattr(L, "vil_optim_plan_bytes")):
+            otp = ctypes.POINTER(VilOptimTensor)
+            L.vil_optim_plan_bytes.restype = ctypes.c_size_t
+            L.vil_optim_plan_bytes.argtypes = [otp, ci]
+            L.vil_optim_plan_build.restype = ci
+            L.vil_optim_plan_build.argtypes = [otp, ci, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+            L.vil_optim_adamw_step.restype = ci
+            L.vil_optim_adamw_step.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp, vp]
+            L.vil_optim_qhm_step.restype = ci
+            L.vil_optim_qhm_step.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, vp, vp]
         L.vil_layernorm_workspace_bytes.restype = ctypes.c_size_t
         L.vil_layernorm_workspace_bytes.argtypes = [i64, ctypes.c_int]
         L.vil_layernorm_fwd.restype = ctypes.c_int
@@ -133,19 +157,16 @@ def lib():
         L.vil_layernorm_bwd.restype = ctypes.c_int
         L.vil_layernorm_bwd.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp,
                                         i64, ctypes.c_int, i64, i64, i64, vp]
-        if hasattr(L, "vil_layernorm_fwd_tokens"):
-            L.vil_layernorm_fwd_tokens.restype = ctypes.c_int
-            L.vil_layernorm_fwd_tokens.argtypes = [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp, vp, i64, ctypes.c_int,
-                                                   i64, ctypes.c_float, i64, i64, vp]
-            L.vil_layernorm_bwd_tokens.restype = ctypes.c_int
-            L.vil_layernorm_bwd_tokens.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp,
-                                                   vp, i64, ctypes.c_int, i64, i64, i64, i64, vp]
-        if hasattr(L, "vil_patchify_fwd"):
-            ci_ = ctypes.c_int
-            L.vil_patchify_fwd.restype = ci_
-            L.vil_patchify_fwd.argtypes = [vp, vp, ci_, vp, vp, ci_] + [ci_] * 7 + [vp]
-            L.vil_patchify_bwd.restype = ci_
-            L.vil_patchify_bwd.argtypes = [vp, ci_, vp, vp, vp, ci_] + [ci_] * 7 + [vp]
+        L.vil_layernorm_fwd_tokens.restype = ctypes.c_int
+        L.vil_layernorm_fwd_tokens.argtypes = [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp, vp, i64, ctypes.c_int,
+                                               i64, ctypes.c_float, i64, i64, vp]
+        L.vil_layernorm_bwd_tokens.restype = ctypes.c_int
+        L.vil_layernorm_bwd_tokens.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp,
+                                               vp, i64, ctypes.c_int, i64, i64, i64, i64, vp]
+        L.vil_patchify_fwd.restype = ci
+        L.vil_patchify_fwd.argtypes = [vp, vp, ci, vp, vp, ci] + [ci] * 7 + [vp]
+        L.vil_patchify_bwd.restype = ci
+        L.vil_patchify_bwd.argtypes = [vp, ci, vp, vp, vp, ci] + [ci] * 7 + [vp]
         if L.vil_attn_abi_version() != ABI_VERSION:
             raise RuntimeError("libvilattn.so ABI version mismatch; rebuild it")
         _lib = L

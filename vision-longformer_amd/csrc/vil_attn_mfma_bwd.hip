@@ -844,34 +844,48 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       wave_lds_fence();
       KV_STAMP(tb);
       KV_ADD(3, ta2, tb);
+      // The bias gathers of the WHOLE step are issued before its first MFMA (32 dword reads in flight, counted waits).
+      // Written per tile (gather 4x4, MFMA, next tile) the register allocator reused one C-operand quad for the tiles of
+      // the first half and that half walked 4 dependent LDS round trips.  Same-box A/B at ViL-Small stage 1: 375 -> 365 us
+      // (the same change in the forward / dQ kernels, which run 3 waves per SIMD: +4 % / +2.5 %, not applied there).
+      f32x4 nd4[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        X8 qa[MK], da[MK];
-#pragma unroll
-        for (int ks = 0; ks < MK; ++ks) {
-          X8 z = {};
-          qa[ks] = (ks * 32 + lg * 8) < M ? *(const X8*)(sq + row_off[hf][ks]) : z;
-          da[ks] = (ks * 32 + lg * 8) < M ? *(const X8*)(sd + row_off[hf][ks]) : z;
-        }
         const i32x4 aq4 = *(const i32x4*)(s_aq + st * 32 + hf * 16 + lg * 4);
-        const f32x4 nd4 = -*(const f32x4*)(s_dlt + st * 32 + hf * 16 + lg * 4);   // dP - delta rides in the accumulator
+        nd4[hf] = -*(const f32x4*)(s_dlt + st * 32 + hf * 16 + lg * 4);   // dP - delta rides in the accumulator
         lds_cvf tb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) tb[r] = lds_f32((unsigned)aq4[r] - akl);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-          f32x4 acc = {tb[0][kt], tb[1][kt], tb[2][kt], tb[3][kt]};
-          if (VIL_KV_ABL & 1) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-          f32x4 dp = nd4;
+          sacc[hf][kt] = (f32x4){tb[0][kt], tb[1][kt], tb[2][kt], tb[3][kt]};
+          if (VIL_KV_ABL & 1) sacc[hf][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      X8 qa[2][MK], da[2][MK];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int ks = 0; ks < MK; ++ks) {
+          X8 z = {};
+          qa[hf][ks] = (ks * 32 + lg * 8) < M ? *(const X8*)(sq + row_off[hf][ks]) : z;
+          da[hf][ks] = (ks * 32 + lg * 8) < M ? *(const X8*)(sd + row_off[hf][ks]) : z;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          f32x4 acc = sacc[hf][kt];
+          f32x4 dp = nd4[hf];
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) {
-            if (VIL_KV_ABL & 8) { acc[0] += (float)qa[ks][0]; dp[0] += (float)da[ks][0]; continue; }
-            acc = mfma16(qa[ks], kfb[ks][kt], acc);
-            dp = mfma16(da[ks], vfb[ks][kt], dp);
+            if (VIL_KV_ABL & 8) { acc[0] += (float)qa[hf][ks][0]; dp[0] += (float)da[hf][ks][0]; continue; }
+            acc = mfma16(qa[hf][ks], kfb[ks][kt], acc);
+            dp = mfma16(da[hf][ks], vfb[ks][kt], dp);
           }
           sacc[hf][kt] = acc; dpacc[hf][kt] = dp;
         }
-      }
       KV_STAMP(tc);
       KV_ADD(4, tb, tc);
     };

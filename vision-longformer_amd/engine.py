@@ -30,6 +30,12 @@ CONFIGS = {
 }
 
 
+def recipe_of(config):
+    """optimizer of the reference's recipe for a configuration: AdamW for the 224 training recipe (config/msvit.yaml),
+    QHM for the 384 fine-tuning recipe (config/msvit_384finetune.yaml)"""
+    return "qhm" if CONFIGS[config][1] == 384 else "adamw"
+
+
 def init_distributed():
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun / torch.distributed.run)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,24 +99,48 @@ def set_lr(optimizer, lr):
             g["lr"] = float(lr)
 
 
-def make_optimizer(model, lr=1e-3, weight_decay=0.05, capturable=False):
+# The reference's recipes (src/config/msvit.yaml:32-47: AdamW lr 5e-4, wd 0.05, betas (0.9, 0.999), eps 1e-8 through
+# get_opt; src/config/msvit_384finetune.yaml:28-35: QHM lr 0.01, momentum 0.9, nu 1, wd 0)
+RECIPES = {"adamw": dict(lr=5e-4, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, correct_bias=True),
+           "qhm": dict(lr=0.01, weight_decay=0.0, momentum=0.9, qhm_nu=1.0)}
+
+
+def _optimizer_classes(device, optimizer_module):
+    """The optimizer implementation: the HIP multi-tensor kernels (optim.py) on the GPU.  There is no CPU product path;
+    CPU host-logic tests and bench.py's cpu_baseline leg pass oracle.optim_oracle explicitly."""
+    if optimizer_module is not None:
+        return optimizer_module
+    if device.type != "cuda":
+        raise RuntimeError("the optimizer step is a HIP kernel (vision_longformer_amd.optim): no CPU fallback; "
+                           "CPU tests pass optimizer_module=oracle.optim_oracle")
+    from . import optim
+    return optim
+
+
+def _build(mod, kind, groups, hyper):
+    hyper = dict(hyper)
+    hyper.pop("weight_decay", None)                    # per group
+    return mod.AdamW(groups, **hyper) if kind == "adamw" else mod.QHM(groups, **hyper)
+
+
+def make_optimizer(model, kind="adamw", capturable=False, optimizer_module=None, **overrides):
+    """The reference's optimizer of the recipe `kind` on the model's fp32 parameters, with get_opt's two weight-decay
+    groups (src/optim/__init__.py:24-37)."""
     p0 = next(model.parameters())
-    fused = p0.is_cuda
-    cap = bool(capturable and fused)
-    return torch.optim.AdamW(param_groups(model, weight_decay), lr=_lr_value(lr, p0.device, cap), betas=(0.9, 0.999),
-                             fused=fused, capturable=cap)
+    mod = _optimizer_classes(p0.device, optimizer_module)
+    hyper = dict(RECIPES[kind]); hyper.update(overrides)
+    hyper["lr"] = _lr_value(hyper["lr"], p0.device, bool(capturable and p0.is_cuda))
+    return _build(mod, kind, param_groups(model, hyper["weight_decay"]), hyper)
 
 
-class MasterWeightAdamW:
-    """AdamW on fp32 master weights; the module holds bf16 working copies of every GEMM / conv
-    parameter.  Numerically this is bf16 autocast (weights rounded to bf16 once per step from the
-    fp32 master) but the per-call cast kernels disappear: autocast launches one cast per weight /
-    bias per forward and one per gradient in backward (~470 tiny kernels and 4 ms of a 31 ms ViL-Small
-    step, profiles/); here the refresh is a handful of multi-tensor (foreach) kernels per step, and
-    DDP all-reduces the bf16 gradients (half the bytes over xGMI)."""
+class MasterWeightOptimizer:
+    """The reference's optimizer (`kind`: "adamw" | "qhm") on fp32 master weights; the module holds 16-bit working
+    copies of every GEMM / conv parameter.  Numerically this is bf16 autocast (weights rounded to bf16 once per step
+    from the fp32 master) without the per-call cast kernels, and DDP all-reduces the bf16 gradients (half the bytes
+    over xGMI).  On the GPU the whole step is ONE kernel launch (csrc/vil_optim.hip): it reads the 16-bit gradients
+    autograd produced, updates master + state, and writes the working copy in the same pass."""
 
-    def __init__(self, model, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999), low_dtype=torch.bfloat16,
-                 capturable=False):
+    def __init__(self, model, kind="adamw", low_dtype=torch.bfloat16, capturable=False, optimizer_module=None, **overrides):
         skip = model.no_weight_decay()
         names = {id(p): n for n, p in model.named_parameters()}
         masters = {}
@@ -118,7 +148,7 @@ class MasterWeightAdamW:
             if isinstance(m, (torch.nn.Linear, torch.nn.Conv2d)):
                 for p in m.parameters(recurse=False):
                     if id(p) not in masters and p.dtype == torch.float32:
-                        masters[id(p)] = p.detach().clone()
+                        masters[id(p)] = torch.nn.Parameter(p.detach().clone(), requires_grad=False)
                         p.data = p.data.to(low_dtype)
         self.low, self.master, self.direct = [], [], []
         decay, no_decay = [], []
@@ -128,7 +158,6 @@ class MasterWeightAdamW:
             n = names[id(p)]
             if id(p) in masters:
                 mp = masters[id(p)]
-                mp.grad = torch.zeros_like(mp)
                 self.low.append(p); self.master.append(mp)
                 tgt = mp
             else:
@@ -136,16 +165,24 @@ class MasterWeightAdamW:
                 tgt = p
             (no_decay if _no_decay(n, skip) else decay).append(tgt)
         p0 = next(model.parameters())
-        fused = p0.is_cuda
-        cap = bool(capturable and fused)
-        self.opt = torch.optim.AdamW([{"params": decay, "weight_decay": weight_decay},
-                                      {"params": no_decay, "weight_decay": 0.0}], lr=_lr_value(lr, p0.device, cap),
-                                     betas=betas, fused=fused, capturable=cap)
-        self.param_groups = self.opt.param_groups
+        mod = _optimizer_classes(p0.device, optimizer_module)
+        self.kind = kind
+        hyper = dict(RECIPES[kind]); hyper.update(overrides)
+        hyper["lr"] = _lr_value(hyper["lr"], p0.device, bool(capturable and p0.is_cuda))
+        self.opt = _build(mod, kind, [{"params": decay, "weight_decay": hyper["weight_decay"]},
+                                      {"params": no_decay, "weight_decay": 0.0}], hyper)
+        self._fused = hasattr(self.opt, "bind_working_copy")
+        if self._fused:
+            for mp, p in zip(self.master, self.low):
+                self.opt.bind_working_copy(mp, p)
         self._low_names = [names[id(p)] for p in self.low]
 
+    @property
+    def param_groups(self):          # always the inner optimizer's live list (load_state_dict replaces the dicts)
+        return self.opt.param_groups
+
     # ---- checkpointing: the module's state_dict holds bf16-rounded working copies of the GEMM weights, so the
-    # fp32 masters and the Adam moments live here (reference checkpoints: utils/checkpoint.py:170-180 saves
+    # fp32 masters and the optimizer state live here (reference checkpoints: utils/checkpoint.py:170-180 saves
     # {net, optimizer}; `export_fp32_state_dict` gives the `net` entry in the reference's fp32 format)
     def state_dict(self):
         return {"master": {n: m.detach().clone() for n, m in zip(self._low_names, self.master)},
@@ -155,16 +192,19 @@ class MasterWeightAdamW:
     def load_state_dict(self, sd):
         for n, m, p in zip(self._low_names, self.master, self.low):
             m.copy_(sd["master"][n])
-            p.copy_(m)                              # refresh the bf16 working copy from the master
-        lrs = [g["lr"] for g in self.opt.param_groups]
-        self.opt.load_state_dict(sd["opt"])
-        for g, lr in zip(self.opt.param_groups, lrs):   # keep the (device-tensor) lr object the graph captured
-            if torch.is_tensor(lr):
-                lr.fill_(float(g["lr"]))
-                g["lr"] = lr
+            p.copy_(m)                              # refresh the working copy from the master
+        if self._fused:
+            self.opt.load_state_dict(sd["opt"])     # in place: state tensors and lr objects keep their addresses
+        else:
+            lrs = [g["lr"] for g in self.opt.param_groups]
+            self.opt.load_state_dict(sd["opt"])
+            for g, lr in zip(self.opt.param_groups, lrs):
+                if torch.is_tensor(lr):
+                    lr.fill_(float(g["lr"]))
+                    g["lr"] = lr
 
     def export_fp32_state_dict(self, model):
-        """model.state_dict() with every bf16 working weight replaced by its fp32 master."""
+        """model.state_dict() with every 16-bit working weight replaced by its fp32 master."""
         out = {k: v.detach().clone() for k, v in model.state_dict().items()}
         master_of = {id(p): m for p, m in zip(self.low, self.master)}
         for n, p in model.named_parameters(remove_duplicate=False):   # shared (sharew) weights appear under every alias
@@ -178,19 +218,27 @@ class MasterWeightAdamW:
         for p in self.direct:
             p.grad = None
 
+    def settle(self):
+        """waits for a pending plan upload (call before and after stream capture)"""
+        if self._fused:
+            self.opt.allocate()
+            self.opt.after_capture()
+
     @torch.no_grad()
     def step(self):
-        lows = [p for p in self.low if p.grad is not None]
-        if len(lows) == len(self.low):
-            torch._foreach_copy_([m.grad for m in self.master], [p.grad for p in self.low])
-        else:
-            for p, m in zip(self.low, self.master):
-                if p.grad is None:
-                    m.grad.zero_()
-                else:
-                    m.grad.copy_(p.grad)
+        if self._fused:
+            self.opt.step()                         # one launch: bf16 grads in, master + state + working copy out
+            return
+        # CPU host-logic tests (oracle optimizer): gradients up-cast, step, working copies refreshed
+        for p, m in zip(self.low, self.master):
+            m.grad = None if p.grad is None else p.grad.float()
         self.opt.step()
-        torch._foreach_copy_(self.low, self.master)
+        for p, m in zip(self.low, self.master):
+            p.copy_(m)
+
+
+def MasterWeightAdamW(model, **kw):
+    return MasterWeightOptimizer(model, kind="adamw", **kw)
 
 
 def wrap_ddp(model, device, world):
@@ -320,6 +368,11 @@ class GraphedTrainStep:
                 self._body(eager=True)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        settle = getattr(self.opt, "settle", None) or getattr(self.opt, "after_capture", None)
+        if hasattr(self.opt, "allocate"):
+            self.opt.allocate()
+        if settle:
+            settle()
         self.graphs, self.opt_graph = [], None
         if world == 1:
             g = torch.cuda.CUDAGraph()
@@ -340,6 +393,9 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.opt_graph, pool=pool):
                 self.opt.step()
         self.graph = self.graphs[0]
+        if settle:
+            settle()                                  # the optimizer's plan of the captured addresses is on the device
+        torch.cuda.synchronize(dev)
 
     def _draw_modes(self):
         if self.rs_layers and self.model.training:

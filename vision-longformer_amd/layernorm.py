@@ -124,11 +124,8 @@ class _TokensLN(torch.autograd.Function):
 
 def tokens_layernorm_ok(x, cls, norm):
     C = x.shape[-1]
-    if os.environ.get("VIL_UNFUSED_STAGE_ENTRY"):      # A/B switch for measurements: the concatenating path
-        return False
     return (isinstance(norm, VilLayerNorm) and x.is_cuda and x.dim() == 3 and x.dtype in _DT and cls is not None
-            and cls.shape[1] >= 1 and C % 8 == 0 and C <= 1024 and norm.elementwise_affine and norm.bias is not None
-            and hasattr(_lib.lib(), "vil_layernorm_fwd_tokens"))
+            and cls.shape[1] >= 1 and C % 8 == 0 and C <= 1024 and norm.elementwise_affine and norm.bias is not None)
 
 
 def tokens_layernorm(x, cls, norm):

@@ -105,7 +105,7 @@ def _gemm(op, inp2, w, bias):
             vp(out.data_ptr()), T, K, N, inp2.stride(0), N, vp(ws.data_ptr()), ws.numel(),
             vp(torch.cuda.current_stream(inp2.device).cuda_stream))
     key = (inp2.device, op, T, K, N, inp2.stride(0), bias is not None)
-    if key not in _GEMM_TUNED and hasattr(L, "vil_gemm_tune") and not torch.cuda.is_current_stream_capturing():
+    if key not in _GEMM_TUNED and not torch.cuda.is_current_stream_capturing():
         # explicit, one-off algorithm selection per problem (synchronises; never inside a captured region):
         # the launch call itself stays asynchronous
         _GEMM_TUNED.add(key)

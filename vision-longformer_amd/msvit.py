@@ -466,7 +466,7 @@ class MsViT(nn.Module):
             return False
         if pend is not None and (pend[0].shape != x.shape or pend[0].dtype not in (torch.float32, torch.bfloat16)):
             return False
-        return hasattr(_lib.lib(), "vil_patchify_fwd")
+        return True
 
     @staticmethod
     def _settle(x, pend):
