@@ -13,8 +13,15 @@ import optim_cases as OC
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optim_reference.npz")
 # fp32 tensors, same operation order as the reference; the CPU reference contracts `a + alpha*b` into an FMA in its
-# vectorised loops and not in its scalar tails, the kernel never contracts: a few ulp per step
-RTOL, ATOL = 2e-6, 2e-8
+# vectorised loops and not in its scalar tails, the kernel never contracts: a few ulp OF THE LARGEST TERM per step (a
+# parameter that ends near zero after steps of size ~1 carries the absolute rounding of those steps)
+RTOL, ATOL_REL = 2e-6, 3e-7
+
+
+def _close(t, ref, what):
+    atol = ATOL_REL * max(float(ref.abs().max()), 1e-3)
+    torch.testing.assert_close(t, ref, rtol=RTOL, atol=atol, msg=lambda m: f"{what}: {m}")
+    return float(((t - ref).abs() / (atol + RTOL * ref.abs())).max())
 
 
 @pytest.fixture(scope="module")
@@ -55,13 +62,13 @@ def _run(dev, name, grad_dtype, bind_low):
 @pytest.mark.parametrize("grad_dtype", [torch.float32, torch.bfloat16])
 def test_optimizer_kernel_vs_reference_fixtures(dev, name, grad_dtype):
     gold = np.load(GOLD)
-    got, _, _, _ = _run(dev, name, grad_dtype, bind_low=False)
+    # 16-bit gradients belong to 16-bit working copies bound to the fp32 masters (autograd's dtype rule)
+    got, _, _, _ = _run(dev, name, grad_dtype, bind_low=grad_dtype != torch.float32)
     worst = 0.0
     for k in (0, OC.NSTEPS - 1):
         for i, t in enumerate(got[k]):
             ref = torch.from_numpy(gold[f"{name}/step{k + 1}/p{i}"])
-            torch.testing.assert_close(t, ref, rtol=RTOL, atol=ATOL, msg=lambda m: f"{name} step {k + 1} tensor {i}: {m}")
-            worst = max(worst, float(((t - ref).abs() / (ATOL + RTOL * ref.abs())).max()))
+            worst = max(worst, _close(t, ref, f"{name} step {k + 1} tensor {i}"))
     assert worst <= 1.0
 
 
@@ -71,7 +78,7 @@ def test_optimizer_kernel_writes_the_working_copy_in_the_same_pass(dev, name):
     got, lows, ps, _ = _run(dev, name, torch.bfloat16, bind_low=True)
     for i, t in enumerate(got[-1]):
         ref = torch.from_numpy(gold[f"{name}/step{OC.NSTEPS}/p{i}"])
-        torch.testing.assert_close(t, ref, rtol=RTOL, atol=ATOL)
+        _close(t, ref, f"{name} tensor {i}")
         assert torch.equal(lows[i].detach(), ps[i].detach().to(torch.bfloat16)), i      # bf16(master), written by the kernel
 
 

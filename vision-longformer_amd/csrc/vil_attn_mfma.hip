@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_mfma_prep(VilParams p, MfmaCfg c, int r
   const int blk = blockIdx.x, ntab = ntx * p.H;
   if (blk < ntab) {
     const int h = blk / ntx, bx = blk - h * ntx;
-    table_element(p, c, (float*)c.tabws, h, bx * 256 + threadIdx.x);
+    table_element(p, c, (float*)c.tabws, h, bx * 256 + threadIdx.x, 1.0f / p.scale);
   } else if (threadIdx.x < 64) {
     key_slots_block(p, c, blk - ntab, threadIdx.x, row_stride_b, smem);
   }

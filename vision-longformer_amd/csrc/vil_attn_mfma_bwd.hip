@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void k_mfma_prep_bwd(VilParams p, MfmaCfg c, B
   int blk = blockIdx.x;
   if (blk < ntab) {
     const int h = blk / ntx, bx = blk - h * ntx;
-    table_element(p, c, (float*)c.tabws, h, bx * 256 + threadIdx.x);
+    table_element(p, c, (float*)c.tabws, h, bx * 256 + threadIdx.x, 1.0f / p.scale);
     return;
   }
   blk -= ntab;

@@ -230,12 +230,11 @@ __device__ __forceinline__ int load_key_slots(const MfmaCfg& c, int ch, int lane
   wave_lds_fence();
   return nslots;
 }
-// One element e of head h's LDS-image bias table (bias / scale so that one multiply by scale*log2e serves scores and
-// bias alike; masks and the exact window as VIL_MASK_VAL; one constant region per global token)
-__device__ __forceinline__ void table_element(const VilParams& p, const MfmaCfg& c, float* out, int h, int e) {
+// One element e of head h's LDS-image bias table: bias * inv (backward passes: inv = 1 / scale, so that one multiply by
+// scale*log2e serves scores and bias alike; forward: inv = log2(e), the scores of its pre-scaled Q are log2-domain; masks and the exact window as VIL_MASK_VAL; one constant region per global token)
+__device__ __forceinline__ void table_element(const VilParams& p, const MfmaCfg& c, float* out, int h, int e, float inv) {
   if (e >= c.tabsize) return;
   const int tbl = c.trows, W = p.g.W;
-  const float inv = 1.0f / p.scale;
   float v = 0.f;
   if (e < tbl * c.P) {
     const int row = e / c.P, col = e % c.P - VIL_CPAD;

@@ -123,43 +123,56 @@ __global__ __launch_bounds__(OPT_THREADS) void k_optim(const char* plan, OptHype
   const bool vec_ok = ((uintptr_t)t.param | (uintptr_t)t.state1 | (uintptr_t)(ALGO == 0 ? t.state2 : t.state1)) % 16 == 0 &&
                       (uintptr_t)t.grad % (t.grad_dtype == VIL_DTYPE_F32 ? 16 : 8) == 0 &&
                       (!t.low || (uintptr_t)t.low % 8 == 0);
+  if (vec_ok && base + OPT_BLOCK_ELEMS <= t.n) {
+    // full block: all 16-byte loads of the 4 iterations in flight before the first update (the kernel is a stream of
+    // ~30 bytes per element; issued one iteration at a time it ran at 3.3 TB/s)
+    of32x4 p[OPT_ITERS], s1[OPT_ITERS], s2[OPT_ITERS], g[OPT_ITERS];
 #pragma unroll
-  for (int it = 0; it < OPT_ITERS; ++it) {
-    const int64_t i = base + ((int64_t)it * OPT_THREADS + threadIdx.x) * OPT_VEC;
-    if (i >= end) break;
-    if (vec_ok && i + OPT_VEC <= end) {
-      of32x4 p = *(const of32x4*)(P + i);
-      of32x4 s1 = (ALGO == 1 && qhm_plain) ? (of32x4){0.f, 0.f, 0.f, 0.f} : *(const of32x4*)(S1 + i);
-      of32x4 s2 = ALGO == 0 ? *(const of32x4*)(S2 + i) : (of32x4){0.f, 0.f, 0.f, 0.f};
-      const of32x4 g = load_grad4(t.grad, t.grad_dtype, i);
+    for (int it = 0; it < OPT_ITERS; ++it) {
+      const int64_t i = base + ((int64_t)it * OPT_THREADS + threadIdx.x) * OPT_VEC;
+      p[it] = *(const of32x4*)(P + i);
+      s1[it] = (ALGO == 1 && qhm_plain) ? (of32x4){0.f, 0.f, 0.f, 0.f} : *(const of32x4*)(S1 + i);
+      s2[it] = ALGO == 0 ? *(const of32x4*)(S2 + i) : (of32x4){0.f, 0.f, 0.f, 0.f};
+      g[it] = load_grad4(t.grad, t.grad_dtype, i);
+    }
+#pragma unroll
+    for (int it = 0; it < OPT_ITERS; ++it) {
+      const int64_t i = base + ((int64_t)it * OPT_THREADS + threadIdx.x) * OPT_VEC;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float a = s1[e], b = s2[e];
-        p[e] = update(p[e], g[e], a, b);
-        s1[e] = a; s2[e] = b;
+        float a = s1[it][e], b = s2[it][e];
+        p[it][e] = update(p[it][e], g[it][e], a, b);
+        s1[it][e] = a; s2[it][e] = b;
       }
-      *(of32x4*)(P + i) = p;
-      if (!(ALGO == 1 && qhm_plain)) *(of32x4*)(S1 + i) = s1;
-      if (ALGO == 0) *(of32x4*)(S2 + i) = s2;
-      if (t.low) store_low4(t.low, t.low_dtype, i, p);
-    } else {
+      *(of32x4*)(P + i) = p[it];
+      if (!(ALGO == 1 && qhm_plain)) *(of32x4*)(S1 + i) = s1[it];
+      if (ALGO == 0) *(of32x4*)(S2 + i) = s2[it];
+      if (t.low) store_low4(t.low, t.low_dtype, i, p[it]);
+    }
+  } else {
+    for (int it = 0; it < OPT_ITERS; ++it) {
+      const int64_t i = base + ((int64_t)it * OPT_THREADS + threadIdx.x) * OPT_VEC;
+      if (i >= end) break;
       for (int64_t j = i; j < i + OPT_VEC && j < end; ++j) {
         float a = (ALGO == 1 && qhm_plain) ? 0.f : S1[j], b = ALGO == 0 ? S2[j] : 0.f;
-        const float p = update(P[j], load_grad(t.grad, t.grad_dtype, j), a, b);
-        P[j] = p;
+        const float pj = update(P[j], load_grad(t.grad, t.grad_dtype, j), a, b);
+        P[j] = pj;
         if (!(ALGO == 1 && qhm_plain)) S1[j] = a;
         if (ALGO == 0) S2[j] = b;
-        if (t.low) store_low(t.low, t.low_dtype, j, p);
+        if (t.low) store_low(t.low, t.low_dtype, j, pj);
       }
     }
   }
-  // the LAST workgroup to finish advances the step counter: every workgroup has read it by then
+  // The LAST workgroup to finish advances the step counter: every workgroup has read it by then (its ticket add is
+  // issued after its read of the counter returned -- the value feeds the step size).  Relaxed atomics only: an
+  // agent-scope release here would write back the XCD's L2 once per workgroup; the next launch sees the counter
+  // through the kernel boundary.
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int prev = __hip_atomic_fetch_add(&hp.step_words[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const int prev = __hip_atomic_fetch_add(&hp.step_words[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == (int)gridDim.x - 1) {
-      hp.step_words[1] = 0;
-      __hip_atomic_fetch_add(&hp.step_words[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&hp.step_words[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&hp.step_words[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
