@@ -50,40 +50,106 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 F32_VALU_PEAK_TFLOPS = 157.3
 
 
+def _host_cpu():
+    """(model name, physical cores visible to this process, logical cores visible)"""
+    model, cores = "?", set()
+    allowed = os.sched_getaffinity(0)
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if cur and int(cur.get("processor", -1)) in allowed:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+                continue
+            k, v = (t.strip() for t in line.split(":", 1))
+            cur[k] = v
+            if k == "model name":
+                model = v
+        if cur and int(cur.get("processor", -1)) in allowed:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except (OSError, ValueError):
+        pass
+    return model, max(len(cores), 1), len(allowed)
+
+
 def cpu_baseline(config, seconds):
-    """Bounded CPU sample: the same host model with every hot-path layer computed by the
-    oracle (fp32, B=2), fwd + bwd + the reference optimizer (oracle restatement), on this box's host cores."""
+    """The CPU leg of BASELINE.md section 3 on this box's host cores, bounded to ~`seconds` x 2 of CPU work: the oracle
+    (CPU restatement of the reference path, pinned to the imported reference by tests/golden/) in the same host model,
+    fp32, B = 2, the reference's optimizer rule (oracle restatement):
+      value        training steps (fwd + bwd + optimizer) of the bench configuration (images/s)
+      layers       one hot-path layer fwd + bwd at every BASELINE configuration shape, mode 0 and random shift
+      models       full training step of ViL-Tiny 224 (BASELINE configuration 0) and one ViL-Medium-Deep 384 step
+      thread_sweep images/s of the ViL-Tiny step by torch thread count, run once to choose `cores`."""
     from oracle.cpu_model import build_cpu_baseline_model
     from oracle import optim_oracle
+    from oracle import vil_oracle as O
     from vision_longformer_amd.engine import CONFIGS, make_optimizer, recipe_of, SyntheticBatches, train_step
-    cores = len(os.sched_getaffinity(0))
-    threads = min(cores, 32)          # measured: 64 threads across two sockets are slower than 8-32
-    torch.set_num_threads(threads)
-    torch.manual_seed(0)
-    img = CONFIGS[config][1]
+    cpu, phys, logical = _host_cpu()
     B = 2
-    model = build_cpu_baseline_model(config).train()
-    opt = make_optimizer(model, kind=recipe_of(config), optimizer_module=optim_oracle)     # the reference's update rule on CPU
-    data = SyntheticBatches(B, img, torch.device("cpu"))
-    train_step(model, opt, *data.next(), amp_dtype=None)           # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        train_step(model, opt, *data.next(), amp_dtype=None)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 50:
-            break
-    cpu = "?"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu = line.split(":", 1)[1].strip()
+
+    def model_rate(cfg, min_steps, budget):
+        torch.manual_seed(0)
+        model = build_cpu_baseline_model(cfg).train()
+        opt = make_optimizer(model, kind=recipe_of(cfg), optimizer_module=optim_oracle)   # the reference's update rule on CPU
+        data = SyntheticBatches(B, CONFIGS[cfg][1], torch.device("cpu"))
+        train_step(model, opt, *data.next(), amp_dtype=None)           # warm-up
+        best, n, t_all = 1e30, 0, time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            train_step(model, opt, *data.next(), amp_dtype=None)
+            best = min(best, time.perf_counter() - t0)
+            n += 1
+            if n >= min_steps and (time.perf_counter() - t_all >= budget or n >= 50):
                 break
-    except OSError:
-        pass
-    return {"value": round(B * n / el, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{n} train steps (fwd+bwd+{recipe_of(config)}) of {config}, batch {B}, fp32, oracle hot path, "
-                      f"{threads} threads of {cores} logical cores, {cpu}, {el:.1f} s"}
+        return B / best, n, time.perf_counter() - t_all
+
+    # ---- thread sweep on the ViL-Tiny step (a 2-socket host is slower with every core than with one socket's worth)
+    sweep = {}
+    for n in [t for t in (8, 16, 32, 64, 128, 256) if t <= max(phys, 8)]:
+        torch.set_num_threads(n)
+        sweep[n] = round(model_rate("vil_tiny_224", 2, 0.0)[0], 2)
+    threads = max(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+
+    # ---- (i) one hot-path layer, fwd + bwd, at every configuration shape
+    shapes = [("small_s1", 96, 3, 7, 56), ("small_s2", 192, 3, 7, 28), ("tiny_s1", 48, 1, 7, 56),
+              ("meddeep_s1_f7", 96, 3, 7, 96), ("meddeep_s1_f8", 96, 3, 8, 96),
+              ("meddeep_s2_f7", 192, 3, 7, 48), ("meddeep_s2_f12", 192, 3, 12, 48)]
+    layers = {}
+    g = torch.Generator().manual_seed(300)
+    for name, dim, H, W, nx in shapes:
+        prm = {}
+        for nm, shp in (("query.weight", (dim, dim)), ("query.bias", (dim,)), ("kv.weight", (2 * dim, dim)),
+                        ("kv.bias", (2 * dim,)), ("proj.weight", (dim, dim)), ("proj.bias", (dim,)),
+                        ("local_relative_position_bias_table", ((4 * W - 1) ** 2, H)),
+                        ("g2l_relative_position_bias", (2, H, 1)), ("g2g_relative_position_bias", (H, 1, 1))):
+            prm[nm] = (torch.randn(*shp, generator=g) * (dim ** -0.5 if nm.endswith("weight") else 0.1)).requires_grad_(True)
+        for nm in ("query", "kv", "proj"):
+            prm[nm + "_global.weight"], prm[nm + "_global.bias"] = prm[nm + ".weight"], prm[nm + ".bias"]
+        x = torch.randn(B, 1 + nx * nx, dim, generator=g, requires_grad=True)
+        for mode in (0, 3):
+            best = 1e30
+            for rep in range(3 if nx <= 56 else 2):
+                t0 = time.perf_counter()
+                out = O.long2dsc_forward(prm, x, nx, nx, num_heads=H, w=W, nglo=1, rpe=True, mode=mode)
+                out.square().mean().backward()
+                if rep:                                   # (first pass = warm-up)
+                    best = min(best, time.perf_counter() - t0)
+            layers[f"{name}_{'mode0' if mode == 0 else 'random_shift'}"] = round(best, 4)
+
+    # ---- (ii) models
+    v, n, el = model_rate(config, 3, seconds)
+    tiny = model_rate("vil_tiny_224", 3, 0.0)[0]
+    md = model_rate("vil_medium_deep_384", 1, 0.0)[0]
+    return {"value": round(v, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"best of {n} train steps (fwd+bwd+{recipe_of(config)}, reference update rule) of {config}, batch {B}, "
+                      f"fp32, oracle hot path, {threads} torch threads (best of the sweep) on {phys} physical / {logical} "
+                      f"logical cores, {cpu}, {el:.1f} s",
+            "cpu": cpu, "physical_cores": phys, "logical_cores": logical,
+            "thread_sweep_vil_tiny_images_per_s": sweep,
+            "layers_fwd_bwd_seconds_B2": layers,
+            "models_images_per_s_B2": {"vil_tiny_224": round(tiny, 2), config: round(v, 3), "vil_medium_deep_384": round(md, 3)}}
 
 
 def kernel_stats(recs):
@@ -224,7 +290,7 @@ def measure(args, config, B, steps, warmup, rank, world, device):
                 if use_master:
                     for m_ in opt.master:
                         dist.broadcast(m_, 0)
-            gstep = GraphedTrainStep(model, opt, *data.next(), world=world)
+            gstep = GraphedTrainStep(model, opt, *data.next(), world=world, force_segments=args.force_segments)
         except Exception as exc:          # capture refused: every rank falls back to the eager DDP step together
             print(f"[rank {rank}] hipGraph capture failed ({exc!r}); falling back to the eager step", file=sys.stderr)
             ok = 0
@@ -287,7 +353,7 @@ def measure(args, config, B, steps, warmup, rank, world, device):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(loss.item())
-    comm = gstep.comm_summary() if (use_graph and world > 1) else None
+    comm = gstep.comm_summary() if (use_graph and gstep.segmented) else None
     del step_fn
     return dict(elapsed=elapsed, recs=recs, nprof=nprof, loss=loss_val, use_graph=use_graph, use_master=use_master, optimizer=kind,
                 fam=fam, img=img, f1=f1, f2=f2, mode=mode, comm=comm)
@@ -300,13 +366,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="vil_small_224")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the ViL-Medium-Deep@384 leg (the second half of BASELINE's metric) of the default run")
     ap.add_argument("--backend", default="auto", choices=["auto", "scalar", "mfma"])
     ap.add_argument("--master-weights", default="on", choices=["on", "off"],
                     help="bf16 working weights + fp32 master (engine.MasterWeightOptimizer) instead of per-call autocast casts")
+    ap.add_argument("--force-segments", action="store_true",
+                    help="run the multi-GPU step structure (segment graphs + asynchronous RCCL all-reduce per segment + "
+                         "optimizer graph) even with one rank: a WORLD_SIZE=1 RCCL process group; emits the `comm` object")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="run the step as hipGraphs (auto = on; random-shift neighbours are device-side words refreshed per replay); "
                          "off = eager step under DDP (bucketed all-reduce overlapped with backward)")
@@ -314,7 +383,7 @@ def main():
 
     from vision_longformer_amd import _lib, ops
     from vision_longformer_amd.engine import CONFIGS, init_distributed
-    rank, local_rank, world, device = init_distributed()
+    rank, local_rank, world, device = init_distributed(single_rank_group=args.force_segments)
     if device.type != "cuda":
         raise SystemExit("bench.py needs a GPU: the product path is HIP-only (no CPU fallback)")
     if world != args.gpus and rank == 0:
@@ -338,7 +407,7 @@ def main():
                        "backend": args.backend, "random_shift_mode": m_["mode"],
                        "precision": "bf16 compute, fp32 master weights + fp32 optimizer state"
                                     + (" (bf16 working copy written by the optimizer kernel)" if m_["use_master"] else " (autocast casts)"),
-                       "launch": ("hipGraph replay (fwd+bwd+optimizer)" if world == 1 else
+                       "launch": ("hipGraph replay (fwd+bwd+optimizer)" if (world == 1 and not args.force_segments) else
                                   "hipGraph replay per stage segment (fwd+bwd), flat-gradient RCCL all-reduce per segment on a side "
                                   "stream overlapped with the next segment's replay, hipGraph replay (optimizer)")
                                  if m_["use_graph"] else "eager (DDP bucketed all-reduce)"},
@@ -376,13 +445,21 @@ def main():
         del m2
         torch.cuda.empty_cache()
 
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    # the ONE JSON line, last: RCCL writes a version banner through C stdio, which would otherwise be flushed at exit,
+    # after this line
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

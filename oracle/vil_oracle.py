@@ -418,3 +418,51 @@ def long2dsc_forward(params, x, nx, ny, *, num_heads, w, nglo=1, rpe=False,
     x0 = torch.einsum('bhgn,bhnc->bhgc', a0, vg).transpose(1, 2).reshape(B, G, C)
     x0 = lin('proj_global', x0)
     return torch.cat((x0, x1), dim=1)
+
+
+# --------------------------------------------------------------------------
+# the dense `Attention` of the s0 stages (reference src/models/msvit.py:37-120): full attention over
+# [G global | nx*ny local] tokens with the Swin-style relative position bias of a (2nx-1) x (2ny-1) table,
+# the g2l / g2g biases of the global tokens.  Pinned by tools/gen_golden.py against the reference module
+# (tests/golden/dense_cases.npz).
+# --------------------------------------------------------------------------
+def dense_relative_position_index(nx, ny):
+    """msvit.py:71-82: index into the ((2nx-1)(2ny-1), H) table for every (query, key) pair of the grid"""
+    ix, iy = torch.meshgrid(torch.arange(nx), torch.arange(ny), indexing="ij")
+    ix, iy = ix.reshape(-1), iy.reshape(-1)
+    return (ix[:, None] - ix[None, :] + nx - 1) * (2 * ny - 1) + (iy[:, None] - iy[None, :] + ny - 1)
+
+
+def dense_attention(qkv, table, g2l, g2g, nx, ny, G, H, scale=None):
+    """qkv (B, N, 3C) packed projection -> (B, N, C); msvit.py:84-120 (softmax over all N keys)."""
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    M = C // H
+    if scale is None:
+        scale = M ** -0.5
+    q, k, v = qkv.view(B, N, 3, H, M).permute(2, 0, 3, 1, 4)
+    attn = (q @ k.transpose(-2, -1)) * scale
+    if table is not None:
+        L = nx * ny
+        assert N == G + L, "For relative position, N != self.nglo + self.wx*self.wy!"
+        loc = table[dense_relative_position_index(nx, ny).reshape(-1)].view(L, L, H).permute(2, 0, 1)
+        if G > 0:
+            top = torch.cat([g2g, g2l[0].unsqueeze(-1).expand(-1, -1, L)], dim=-1)
+            bot = torch.cat([g2l[1].unsqueeze(1).expand(-1, L, -1), loc], dim=-1)
+            bias = torch.cat([top, bot], dim=1)
+        else:
+            bias = loc
+        attn = attn + bias.unsqueeze(0)
+    attn = attn.softmax(dim=-1)
+    return (attn @ v).transpose(1, 2).reshape(B, N, C)
+
+
+def dense_module_forward(params, x, nx, ny, *, num_heads, nglo=1, rpe=True, qk_scale=None):
+    """functional restatement of Attention.forward: qkv Linear -> dense_attention -> proj Linear"""
+    C = x.shape[-1]
+    qkv = F.linear(x, params["qkv.weight"], params.get("qkv.bias"))
+    out = dense_attention(qkv, params["local_relative_position_bias_table"] if rpe else None,
+                          params.get("g2l_relative_position_bias") if (rpe and nglo > 0) else None,
+                          params.get("g2g_relative_position_bias") if (rpe and nglo > 0) else None,
+                          nx, ny, nglo, num_heads, qk_scale or (C // num_heads) ** -0.5)
+    return F.linear(out, params["proj.weight"], params.get("proj.bias"))

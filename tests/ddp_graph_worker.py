@@ -43,10 +43,7 @@ def main():
             v.copy_(sd[k])
         for mm, v in zip(opt.master, msd):
             mm.copy_(v)
-    for st in opt.opt.state.values():
-        for v in st.values():
-            if torch.is_tensor(v):
-                v.zero_()
+    opt.reset_state()
     losses = [float(gs(x[half], t[half])) for x, t in zip(xs, ts)]
     torch.cuda.synchronize()
     flat = torch.cat([p.detach().float().reshape(-1) for p in m.parameters()])

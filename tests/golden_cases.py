@@ -56,10 +56,48 @@ MODULE_CASES = [
     _mc("tiny_s1_d48h1w7_56x56_g1", 48, 1, 7, 56, 56, 1),
     _mc("small_s2_d192h3w7_28x28_g1", 192, 3, 7, 28, 28, 1),
     _mc("meddeep_s2_d192h3w7_48x48_g1", 192, 3, 7, 48, 48, 1, B=1),
+    # the other windows / grids of BASELINE configs 4-5 (round 3): W = 6 with a random-shift neighbour on the 96x96 grid
+    # (16x16 chunks), W = 8 random shift and W = 12 on 48x48, and the 96x96 grid zero-padded to 98x98 under W = 7
+    _mc("basedeep_s1_d96h3w6_96x96_g1_mode4", 96, 3, 6, 96, 96, 1, mode=4, B=1),
+    _mc("basedeep_s2_d192h3w8_48x48_g1_mode6", 192, 3, 8, 48, 48, 1, mode=6, B=1),
+    _mc("meddeep_s2_d192h3w12_48x48_g1", 192, 3, 12, 48, 48, 1, B=1),
+    _mc("meddeep_s1_d96h3w7_96x96_g1_pad98", 96, 3, 7, 96, 96, 1, B=1),
 ]
 BIG_CASES = {"small_s1_d96h3w7_56x56_g1", "tiny_s1_d48h1w7_56x56_g1",
-             "small_s2_d192h3w7_28x28_g1", "meddeep_s2_d192h3w7_48x48_g1"}   # too slow for O(N^2) checks
+             "small_s2_d192h3w7_28x28_g1", "meddeep_s2_d192h3w7_48x48_g1",
+             "basedeep_s1_d96h3w6_96x96_g1_mode4", "basedeep_s2_d192h3w8_48x48_g1_mode6",
+             "meddeep_s2_d192h3w12_48x48_g1", "meddeep_s1_d96h3w7_96x96_g1_pad98"}   # too slow for O(N^2) checks
 SAMPLE_ABOVE = 4096   # tensors with more elements are stored as strided sample + sums
+
+
+# dense `Attention` module (the s0 stages, reference msvit.py:37-120): dict(name, dim, H, nx, G, B)
+DENSE_CASES = [
+    dict(name="dense_d384h6_14x14_g1", dim=384, H=6, nx=14, G=1, B=2),       # ViL-Small stage 3
+    dict(name="dense_d384h6_24x24_g1", dim=384, H=6, nx=24, G=1, B=1),       # ViL-Medium-Deep@384 stage 3
+    dict(name="dense_d128h2_14x14_g0", dim=128, H=2, nx=14, G=0, B=2),
+    dict(name="dense_d256h4_7x7_g0", dim=256, H=4, nx=7, G=0, B=2),
+    dict(name="dense_d32h2_5x5_g2", dim=32, H=2, nx=5, G=2, B=2),
+    dict(name="dense_d96h2_9x9_g1", dim=96, H=2, nx=9, G=1, B=2),            # head_dim 48
+]
+
+
+def dense_inputs(c, dtype=torch.float64):
+    """(params, x, dout) of a dense Attention case; weights ~ N(0, 1/sqrt(dim)), bias tables ~ N(0, 0.5)"""
+    g = torch.Generator().manual_seed(SEED + 1)
+    dim, H, nx, G = c["dim"], c["H"], c["nx"], c["G"]
+    shapes = [("qkv.weight", (3 * dim, dim)), ("qkv.bias", (3 * dim,)), ("proj.weight", (dim, dim)), ("proj.bias", (dim,)),
+              ("local_relative_position_bias_table", ((2 * nx - 1) ** 2, H))]
+    if G >= 1:
+        shapes += [("g2l_relative_position_bias", (2, H, G)), ("g2g_relative_position_bias", (H, G, G))]
+    params = {}
+    for name, shape in shapes:
+        t = torch.randn(*shape, generator=g, dtype=torch.float64)
+        t = t * (0.5 if "relative_position" in name else (dim ** -0.5 if name.endswith(".weight") else 0.1))
+        params[name] = t.to(dtype)
+    N = G + nx * nx
+    x = torch.randn(c["B"], N, dim, generator=g, dtype=torch.float64).to(dtype)
+    dout = torch.randn(c["B"], N, dim, generator=g, dtype=torch.float64).to(dtype)
+    return params, x, dout
 
 
 def op_inputs(case, dtype=torch.float64):

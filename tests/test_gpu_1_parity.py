@@ -64,6 +64,30 @@ def test_mfma_bf16_vs_oracle(c, dev):
     compare("mfma/bf16 " + cid(c), got, ref, BF16_TOL)
 
 
+def test_fp16_backward_propagates_non_finite_gradients(dev):
+    """fp16 training (the reference's AMP: autocast + GradScaler, src/engine.py:84, run_experiment.py:206) relies on the
+    inf / NaN of an overflowed scaled gradient reaching the parameter gradients, so that the scaler skips the step.
+    An inf in dout must come out as non-finite dq / dkv (the backward kernels are built WITH NaN semantics), and the
+    finite case must stay finite."""
+    from vision_longformer_amd.ops import vil_local_attention
+    c = case(2, 32, 7, 14, 14, 1)
+    q, kv, table, g2l, dout = make_inputs(c, torch.float16)
+    for poison in (None, float("inf"), float("nan")):
+        qd = q.to(dev, torch.float16).requires_grad_(True)
+        kvd = kv.to(dev, torch.float16).requires_grad_(True)
+        tab = table.to(dev).requires_grad_(True)
+        g2 = g2l.to(dev).requires_grad_(True)
+        out = vil_local_attention(qd, kvd, tab, g2, nx=c["nx"], ny=c["ny"], w=c["W"], nglo=c["G"], num_heads=c["H"],
+                                  mode=0, exact=0, backend="mfma")
+        d = dout.to(dev, torch.float16).clone()
+        if poison is not None:
+            d[1, 77, 5] = poison
+        out.backward(d)
+        torch.cuda.synchronize()
+        finite = bool(torch.isfinite(qd.grad).all() and torch.isfinite(kvd.grad).all())
+        assert finite == (poison is None), f"poison {poison}: gradients finite = {finite}"
+
+
 def test_mfma_forced_rescale_branch(dev):
     """The deferred-max rescale is rare on random data: force it with a spiked key
     (cdna guide 5.4 rule 26) late in the key order and check against the oracle."""
@@ -259,7 +283,7 @@ def test_module_bf16_autocast_vs_golden(c, dev, golden_dir):
     worst = []
     got, want, tols = {}, {}, {}
     t, ref = ref_of("dx", xd.grad)
-    got["dx"], want["dx"], tols["dx"] = t, ref, ("rms", 0.2, 5e-2)
+    got["dx"], want["dx"], tols["dx"] = t, ref, ("rms", 0.12, 5e-2)
     for n, p_ in mod.named_parameters():
         if p_.grad is None:
             continue
@@ -269,6 +293,78 @@ def test_module_bf16_autocast_vs_golden(c, dev, golden_dir):
             tols["d_" + n] = ("rms", 0.1, 5e-2)
     assert len(tols) >= 4, "golden gradients missing"
     compare("module/bf16-autocast backward " + c["name"], got, want, tols)
+
+
+@pytest.mark.parametrize("amp", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("c", GC.DENSE_CASES, ids=lambda c: c["name"])
+def test_dense_attention_module_vs_golden(c, amp, dev, golden_dir):
+    """The package's dense `Attention` (the s0 stages; one-chunk case of the fused kernels) under bf16 and fp16 autocast
+    against the REFERENCE module's fixtures (tools/gen_golden.py, src/models/msvit.py:37-120): output, dx and every
+    parameter gradient element-wise."""
+    from vision_longformer_amd.msvit import Attention
+    gold = np.load(os.path.join(golden_dir, "dense_cases.npz"))
+    params, x, dout = GC.dense_inputs(c)
+    mod = Attention(c["dim"], num_heads=c["H"], qkv_bias=True, rpe=True, wx=c["nx"], wy=c["nx"], nglo=c["G"])
+    sd = mod.state_dict()
+    for k in sd:
+        if k in params:
+            sd[k] = params[k].to(sd[k].dtype)
+    mod.load_state_dict(sd)
+    mod = mod.to(dev).train()
+    xd = x.float().to(dev).requires_grad_(True)
+    from vision_longformer_amd import _lib
+    _lib.profile_begin(64)
+    with torch.autocast("cuda", dtype=amp):
+        out = mod(xd, c["nx"], c["nx"])
+    out.backward(dout.to(dev, out.dtype))
+    torch.cuda.synchronize()
+    names = {r[0] for r in _lib.profile_end(64)}
+    assert any(n.startswith("k_mfma_fwd") for n in names) and any("dkdv" in n for n in names), names    # the HIP path ran
+    pre = c["name"] + "/"
+
+    def ref_of(nm, t):
+        t = t.detach().double().cpu()
+        if pre + nm in gold.files:
+            return t, torch.from_numpy(gold[pre + nm])
+        return GC.sample_big(t)[0], torch.from_numpy(gold[pre + nm + "@sample"])
+
+    t, ref = ref_of("out", out)
+    err = (t - ref).abs().max().item()
+    assert err < 0.06 * max(1.0, ref.abs().max().item()), err
+    got, want, tols = {}, {}, {}
+    got["dx"], want["dx"] = ref_of("dx", xd.grad)
+    tols["dx"] = ("rms", 0.12, 5e-2)
+    for n, p_ in mod.named_parameters():
+        got["d_" + n], want["d_" + n] = ref_of("d_" + n, p_.grad)
+        tols["d_" + n] = ("rms", 0.1, 5e-2)
+    compare(f"dense module/{'bf16' if amp == torch.bfloat16 else 'fp16'}-autocast " + c["name"], got, want, tols)
+
+
+def test_bias_gradients_at_the_bench_batch(dev):
+    """d(table) / d(g2l) are accumulated in int32 fixed point whose power-of-two scale comes from batch-wide maxima and
+    from the number of contributions a bin can receive in one workgroup: check them at the BENCH batch (ViL-Small stage
+    1, B = 128) against the fp64 oracle (summed over the batch in slices of 8 images), and twice for bit-reproducibility."""
+    c = case(3, 32, 7, 56, 56, 1, B=128)
+    q, kv, table, g2l, dout = make_inputs(c, torch.bfloat16, seed=23)
+    from vision_longformer_amd.ops import vil_local_attention
+    runs = []
+    for _ in range(2):
+        qd = q.to(dev, torch.bfloat16).requires_grad_(True)
+        kvd = kv.to(dev, torch.bfloat16).requires_grad_(True)
+        tab, g2 = table.to(dev).requires_grad_(True), g2l.to(dev).requires_grad_(True)
+        out = vil_local_attention(qd, kvd, tab, g2, nx=56, ny=56, w=7, nglo=1, num_heads=3, mode=0, exact=0, backend="mfma")
+        out.backward(dout.to(dev, torch.bfloat16))
+        torch.cuda.synchronize()
+        runs.append((tab.grad.clone(), g2.grad.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), "bias gradients not bit-reproducible"
+    dt, dg = torch.zeros_like(table, dtype=torch.float64), torch.zeros_like(g2l, dtype=torch.float64)
+    for b0 in range(0, 128, 8):
+        cs = dict(c, B=8)
+        r = run_oracle(cs, q[b0:b0 + 8], kv[b0:b0 + 8], table, g2l, dout[b0:b0 + 8])
+        dt += r["dtable"]; dg += r["dg2l"]
+    got = dict(dtable=runs[0][0].double().cpu(), dg2l=runs[0][1].double().cpu())
+    compare("bias gradients at the bench batch (B=128, small_s1)", got, dict(dtable=dt, dg2l=dg),
+            dict(dtable=BF16_TOL["dtable"], dg2l=BF16_TOL["dg2l"]))
 
 
 # ---------------------------------------------------------------- full-size properties
@@ -312,30 +408,6 @@ def test_full_size_properties(name, c, dev):
 
 
 # ---------------------------------------------------------------- dense attention (s0 stages)
-def _dense_reference(qkv, table, g2l, g2g, nx, ny, G, H, scale):
-    """fp64 restatement of the reference's dense Attention.forward (src/models/msvit.py:91-120)."""
-    B, N, C3 = qkv.shape
-    C = C3 // 3
-    M = C // H
-    q, k, v = qkv.view(B, N, 3, H, M).permute(2, 0, 3, 1, 4)
-    attn = (q @ k.transpose(-2, -1)) * scale
-    if table is not None:
-        L = nx * ny
-        ix, iy = torch.meshgrid(torch.arange(nx), torch.arange(ny), indexing="ij")
-        ix, iy = ix.reshape(-1), iy.reshape(-1)
-        rel = (ix[:, None] - ix[None, :] + nx - 1) * (2 * ny - 1) + (iy[:, None] - iy[None, :] + ny - 1)
-        loc = table[rel.reshape(-1)].view(L, L, H).permute(2, 0, 1)
-        if G > 0:
-            top = torch.cat([g2g, g2l[0].unsqueeze(-1).expand(-1, -1, L)], dim=-1)
-            bot = torch.cat([g2l[1].unsqueeze(1).expand(-1, L, -1), loc], dim=-1)
-            bias = torch.cat([top, bot], dim=1)
-        else:
-            bias = loc
-        attn = attn + bias.unsqueeze(0)
-    attn = attn.softmax(dim=-1)
-    return (attn @ v).transpose(1, 2).reshape(B, N, C)
-
-
 @pytest.mark.parametrize("nx,G,H,M,B,rpe", [(14, 1, 6, 64, 2, True), (7, 0, 12, 64, 2, True), (24, 1, 6, 64, 1, True),
                                              (12, 0, 12, 64, 1, True), (5, 2, 2, 16, 2, True), (14, 1, 3, 32, 2, False),
                                              (9, 1, 2, 48, 2, True)])
@@ -350,7 +422,7 @@ def test_dense_attention_one_chunk_vs_reference(dev, nx, G, H, M, B, rpe):
     g2g = torch.randn(H, G, G, generator=g) * 0.5 if (rpe and G) else None
     scale = M ** -0.5
     leaves = [t.double().requires_grad_(True) if t is not None else None for t in (qkv, table, g2l, g2g)]
-    ref = _dense_reference(leaves[0], leaves[1], leaves[2], leaves[3], nx, nx, G, H, scale)
+    ref = O.dense_attention(leaves[0], leaves[1], leaves[2], leaves[3], nx, nx, G, H, scale)      # oracle, pinned by dense_cases.npz
     (ref * dout.double()).sum().backward()
     dl = [t.to(dev, torch.bfloat16 if i == 0 else torch.float32).requires_grad_(True) if t is not None else None
           for i, t in enumerate((qkv, table, g2l, g2g))]

@@ -15,6 +15,19 @@ from oracle import vil_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def _reset(opt):
+    """optimizer state back to "never stepped" IN PLACE (moments and the device-side step count): a captured step keeps
+    reading the same tensors"""
+    if hasattr(opt, "reset_state"):
+        opt.reset_state()
+        return
+    for st in opt.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+    opt.reset_step_count()
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
@@ -47,10 +60,7 @@ def test_graphed_train_step_equals_eager(dev, master):
                     v.copy_(sd[k])
                 for mm, v in zip(opt.master if master else [], msd):
                     mm.copy_(v)
-            for st in (opt.opt if master else opt).state.values():
-                for k, v in st.items():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            _reset(opt)
             for x, t in zip(xs, ts):
                 losses.append(float(gs(x, t)))
         else:
@@ -88,10 +98,7 @@ def test_graphed_train_step_vil_small_shapes(dev):
                     v.copy_(sd[k])
                 for m, v in zip(opt.master, msd):
                     m.copy_(v)
-            for st in opt.opt.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            _reset(opt)
             data = SyntheticBatches(B, 224, dev, 0)
             for _ in range(steps):
                 losses.append(float(gs(*data.next())))
@@ -134,10 +141,7 @@ def test_graphed_train_step_multi_rank_path(dev, monkeypatch):
                     v.copy_(sd[k])
                 for mm, v in zip(opt.master, msd):
                     mm.copy_(v)
-            for st in opt.opt.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            _reset(opt)
             n0 = len(calls)
             for x, t in zip(xs, ts):
                 losses.append(float(gs(x, t)))
@@ -200,6 +204,33 @@ def test_graphed_step_two_processes_one_gpu(dev, tmp_path):
     assert dl < 2e-2 and dp < 2e-2
 
 
+def test_segmented_step_on_rccl_single_rank(dev):
+    """RCCL under the N > 1 code path before any multi-GPU run: a WORLD_SIZE=1 process group with backend "nccl" (= RCCL)
+    and a 120 s collective timeout; three segment graphs with a real asynchronous all_reduce(AVG) of each segment's flat
+    gradient buffers on the process group's stream between the replays, optimizer graph; five steps must reproduce the
+    single-graph step (same kernels, same reduction order: equal up to the float atomics of two bias gradients)."""
+    import json
+    import socket
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", VIL_DIST_TIMEOUT_S="120")
+    env.pop("VIL_SHARE_DEVICE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_graph_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_WORKER ")][-1]
+    got = json.loads(line[len("RCCL_WORKER "):])
+    assert got["backend"] == "nccl" and got["ngraphs"] == 3 and got["has_opt_graph"]
+    assert got["comm"]["exposed_bytes"] < got["comm"]["total_bytes"]
+    dl = max(abs(a - b) for a, b in zip(got["losses_single"], got["losses_segmented"]))
+    report(f"     segmented step on RCCL (world 1) vs single graph: max|dloss| {dl:.3e} max|dparam| {got['max_dparam']:.3e}; "
+           f"comm {got['comm']['segments_bytes']}")
+    assert dl < 1e-3 and got["max_dparam"] < 1e-3
+
+
 def test_graphed_step_observes_lr_schedule(dev):
     """A captured optimizer step must follow a per-iteration learning-rate schedule (the reference's warm-up + cosine,
     src/engine.py): with capturable=True the lr is a device tensor that engine.set_lr updates in place.  fp32 step (no
@@ -222,10 +253,7 @@ def test_graphed_step_observes_lr_schedule(dev):
             with torch.no_grad():
                 for k, v in m.state_dict().items():
                     v.copy_(sd[k])
-            for st in opt.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            _reset(opt)
         for i, (x, t) in enumerate(zip(xs, ts)):
             if schedule:
                 set_lr(opt, lrs[i])

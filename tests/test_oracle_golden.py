@@ -14,7 +14,7 @@ from oracle import vil_oracle as O
 @pytest.fixture(scope="module")
 def gold(golden_dir):
     return {n: np.load(os.path.join(golden_dir, n + ".npz")) for n in
-            ("rel_index", "masks", "op_cases", "module_cases")}
+            ("rel_index", "masks", "op_cases", "module_cases", "dense_cases")}
 
 
 @pytest.mark.parametrize("W", [2, 3, 4, 6, 7, 8, 12])
@@ -102,6 +102,32 @@ def test_module_level(gold, c):
             _check(gold, pre, "d_" + n, p.grad)
             checked += 1
     assert checked >= 6
+
+
+@pytest.mark.parametrize("c", GC.DENSE_CASES, ids=lambda c: c["name"])
+def test_dense_attention_module_level(gold, c):
+    """oracle.dense_module_forward (the s0 stages' Attention, msvit.py:37-120) against the reference module's outputs
+    and gradients frozen in tests/golden/dense_cases.npz."""
+    params, x, dout = GC.dense_inputs(c)
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = x.clone().requires_grad_(True)
+    out = O.dense_module_forward(op, xo, c["nx"], c["nx"], num_heads=c["H"], nglo=c["G"], rpe=True)
+    (out * dout).sum().backward()
+    dc = gold["dense_cases"]
+    pre = c["name"] + "/"
+
+    def chk(nm, t):
+        if pre + nm in dc.files:
+            torch.testing.assert_close(t, torch.from_numpy(dc[pre + nm]), rtol=1e-9, atol=1e-10, msg=pre + nm)
+        else:
+            s_, sums = GC.sample_big(t)
+            torch.testing.assert_close(s_, torch.from_numpy(dc[pre + nm + "@sample"]), rtol=1e-9, atol=1e-10, msg=pre + nm)
+            torch.testing.assert_close(sums, torch.from_numpy(dc[pre + nm + "@sums"]), rtol=1e-8, atol=1e-8, msg=pre + nm)
+
+    chk("out", out.detach())
+    chk("dx", xo.grad)
+    for n, p in op.items():
+        chk("d_" + n, p.grad)
 
 
 @pytest.mark.parametrize("c", [c for c in GC.MODULE_CASES if c["name"] not in GC.BIG_CASES

@@ -203,6 +203,44 @@ def main():
     np.savez_compressed(os.path.join(outdir, "module_cases.npz"), **mods)
     print("module cases ok, max |ref-oracle| out/grads =", worst_out, worst_g)
 
+    # ---------------- dense `Attention` module of the s0 stages (msvit.py:37-120) ----------------
+    from models import msvit as ref_msvit_mod
+    dense = {}
+    wd_out = wd_g = 0.0
+    for c in GC.DENSE_CASES:
+        params, x, dout = GC.dense_inputs(c)
+        mod = ref_msvit_mod.Attention(c["dim"], num_heads=c["H"], qkv_bias=True, rpe=True, wx=c["nx"], wy=c["nx"],
+                                      nglo=c["G"]).double()
+        sd = dict(params)
+        sd["relative_position_index"] = mod.relative_position_index
+        mod.load_state_dict(sd, strict=True)
+        mod.train()
+        xr = x.clone().requires_grad_(True)
+        out = mod(xr, c["nx"], c["nx"])
+        (out * dout).sum().backward()
+        assert torch.equal(mod.relative_position_index, O.dense_relative_position_index(c["nx"], c["nx"]))
+        ref_grads = {n: p.grad for n, p in mod.named_parameters()}
+        op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        xo = x.clone().requires_grad_(True)
+        out_o = O.dense_module_forward(op, xo, c["nx"], c["nx"], num_heads=c["H"], nglo=c["G"], rpe=True)
+        (out_o * dout).sum().backward()
+        wd_out = max(wd_out, float((out - out_o).abs().max()))
+        wd_g = max(wd_g, float((xr.grad - xo.grad).abs().max()))
+        for n, gref in ref_grads.items():
+            wd_g = max(wd_g, float((gref - op[n].grad).abs().max()))
+        pre = c["name"] + "/"
+        for nm, t in [("out", out.detach()), ("dx", xr.grad)] + [("d_" + n, g) for n, g in ref_grads.items()]:
+            if t.numel() > 4096:
+                s_, sums = GC.sample_big(t)
+                dense[pre + nm + "@sample"] = s_.numpy()
+                dense[pre + nm + "@sums"] = sums.numpy()
+            else:
+                dense[pre + nm] = t.numpy()
+        print(f"  dense {c['name']}: ok")
+    assert wd_out < 1e-11 and wd_g < 1e-10, (wd_out, wd_g)
+    np.savez_compressed(os.path.join(outdir, "dense_cases.npz"), **dense)
+    print("dense Attention cases ok, max |ref-oracle| out/grads =", wd_out, wd_g)
+
     # ---------------- model level (BASELINE config 1): ViL-Tiny 224, B=2 ----------------
     # The build's own MsViT provides the weights (seeded); the REFERENCE MsViT must accept
     # that state dict as is (drop-in contract: same parameter/buffer names and shapes).

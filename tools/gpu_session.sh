@@ -28,9 +28,6 @@ for STEP in "$@"; do
       cat "$OUT/ab.txt" ;;
     bench)
       timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 3000 "$OUT/bench.json" ;;
-    bench_r01lib)      # same engine, round-1 kernels: isolates kernel changes from box-to-box clock differences
-      VIL_ATTN_LIB=$PWD/tools/ab/libvilattn_r01.so timeout 600 python bench.py --no-cpu-baseline > "$OUT/bench_r01lib.json" 2> "$OUT/bench_r01lib.err"
-      python -c "import json,sys; d=json.load(open('$OUT/bench_r01lib.json')); print('r01 lib:', d['value'], d['ms_per_step'], d['hot_path_ms_per_step'])" ;;
     bench2)      # the driver's multi-GPU command line, two ranks SHARING this box's one GPU (gloo): exercises the whole N > 1 flow
       VIL_SHARE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 \
         bench.py --gpus 2 --steps 5 --warmup 2 > "$OUT/bench2.json" 2> "$OUT/bench2.err"
@@ -73,19 +70,6 @@ for STEP in "$@"; do
       done ;;
     opbench)
       timeout 900 python tools/op_benchmark.py > "$OUT/op_benchmark.jsonl" 2> "$OUT/op_benchmark.err"; cat "$OUT/op_benchmark.jsonl" ;;
-    wgradprobe)   # per-shape vil_linear_wgrad timings at the planner's workgroup targets in WGRAD_TARGETS
-      for W in ${WGRAD_TARGETS:-512 768 1024}; do
-        VIL_WGRAD_WGS=$W timeout 300 python tools/wgrad_probe2.py >> "$OUT/wgrad_probe.txt" 2>&1
-      done
-      cat "$OUT/wgrad_probe.txt" ;;
-    kvtiming)     # per-segment cycle budget of the dK/dV waves (diagnostics build, tools/kv_timing.py)
-      for SH in ${KVT_SHAPES:-small_s1 small_s3_dense}; do
-        for LIB in tools/ab/libvilattn_kvtiming*.so; do
-          echo "== $LIB" >> "$OUT/kv_timing.txt"
-          VIL_ATTN_LIB=$PWD/$LIB timeout 300 python tools/kv_timing.py $SH >> "$OUT/kv_timing.txt" 2>&1
-        done
-      done
-      cat "$OUT/kv_timing.txt" ;;
     smoke)
       python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" ;;
     *) echo "unknown step $STEP" ;;

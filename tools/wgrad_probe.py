@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from vision_longformer_amd.linear import _wgrad, _GEMM_WS
+from vision_longformer_amd.linear import _wgrad, _GEMM_WS, _colsum
 
 
 # the library-GEMM alternative (vil_gemm_bf16 op 2: dW by hipBLASLt, db by its BGRADB epilogue) -- measured 2-20x
@@ -56,9 +56,23 @@ for name, (T, ci, co) in shapes.items():
         err = max(float((r[0].float() - a[0].float()).abs().max() / a[0].float().abs().max()),
                   float((r[1].float() - a[1].float()).abs().max() / a[1].float().abs().max()))
         t_lt = bench(lambda: _wgrad_lt(dy, x, True))
+    # hipBLASLt for dW only (tuned: vil_gemm_tune through _gemm-like call below) + the HBM-rate column-sum kernel for db
+    import ctypes
+    from vision_longformer_amd import _lib
+    L = _lib.lib()
+    ws = _GEMM_WS[dev]
+    dwl = torch.empty(co, ci, dtype=torch.bfloat16, device=dev)
+    vp = ctypes.c_void_p
+    args = (2, vp(x.data_ptr()), vp(dy.data_ptr()), None, vp(dwl.data_ptr()), T, ci, co, x.stride(0), dy.stride(0),
+            vp(ws.data_ptr()), ws.numel(), vp(torch.cuda.current_stream(dev).cuda_stream))
+    rc = L.vil_gemm_tune(*args)
+    def lt_nobias():
+        L.vil_gemm_bf16(*args); return _colsum(dy)
+    t_ltn = bench(lt_nobias) if rc == 0 else float("nan")
+    t_cs = bench(lambda: _colsum(dy))
     S = 8; Tp = (T // S) * S
     def splitk():
         return torch.bmm(dy[:Tp].view(S, Tp // S, co).transpose(1, 2), x[:Tp].view(S, Tp // S, ci)).sum(0), dy.sum(0)
     t_sk = bench(splitk)
     fl = 2 * T * ci * co
-    print(f"{name:8s} T={T:6d} {ci:4d}->{co:4d}  fused dW+db {t_f:7.1f} us ({fl/t_f/1e6:6.1f} TF)   hipBLASLt+BGRADB {t_lt:7.1f} us (rel.diff {err:.1e})   bmm splitK8 + sum {t_sk:7.1f} us")
+    print(f"{name:8s} T={T:6d} {ci:4d}->{co:4d}  fused dW+db {t_f:7.1f} us ({fl/t_f/1e6:6.1f} TF)   hipBLASLt+BGRADB {t_lt:7.1f} us (rel.diff {err:.1e})   hipBLASLt(dW, tuned)+colsum {t_ltn:7.1f} us (colsum alone {t_cs:5.1f})   bmm splitK8 + sum {t_sk:7.1f} us")

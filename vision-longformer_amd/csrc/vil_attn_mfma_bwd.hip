@@ -19,7 +19,6 @@
 // Reference semantics: SlidingChunk2D.backward (src/models/layers/slidingchunk_2d.py:234-246)
 // plus the autograd of bias gather / mask / softmax in longformer2d.py:152-200.
 #include "vil_mfma_common.h"
-#include <cstdlib>
 #include <type_traits>
 
 #define LSE_PAD 1.0e30f
@@ -54,9 +53,6 @@ struct BwdCfg {
 // SIMD instead of one; same reasoning as KT of the dK/dV pass)
 // Tuning switches (see vil_attn_mfma.hip).  ViL-Small stage 1, round-1 kernel 407 us: ring 1 / 3 waves 367 us (default);
 // ring 2 / 3 waves 398; ring 1 / 4 waves (128 VGPRs, 36 B scratch) 389; software pipeline (219 VGPRs, 2 waves) 460.
-#ifndef VIL_DQ_ABL
-#define VIL_DQ_ABL 0       // ablation bits for TIMING diagnostics only (wrong results): 1 no histogram atomics in the step loop
-#endif
 #ifndef VIL_DQ_PIPE
 #define VIL_DQ_PIPE 0      // software pipeline over steps at head_dim 32
 #endif
@@ -348,7 +344,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
             for (int r = 0; r < 4; ++r) {
               const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][qt][r], c1, -lse2[qt]));
               ds[r] = pr * dpacc[hf][qt][r];
-              if (bc.do_hist && !(VIL_DQ_ABL & 1))
+              if (bc.do_hist)
                 __hip_atomic_fetch_add(lds_i32(i0[hf][r] + hist_off) + qt, __float2int_rn(FOLD ? ds[r] : ds[r] * hscale),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -504,10 +500,6 @@ __device__ __forceinline__ void reduce_hist_block(const VilParams& p, const Mfma
 #ifndef VIL_KV_WAVES
 #define VIL_KV_WAVES 2     // waves per SIMD of the head_dim 32 instantiation
 #endif
-#ifndef VIL_KV_ABL
-#define VIL_KV_ABL 0       // ablation bits for TIMING diagnostics only (results are wrong when non-zero): 1 no bias gather,
-#endif                     // 2 no exp, 4 no dV/dK MFMAs + transpose reads, 8 no S/dP MFMAs, 16 no global loads, 32 no LDS tiles,
-                           // 64 no step loop, 128 no global-row part, 256 no lse / delta gathers in the slot-table build
 // Streamed-query slot tables of the dK/dV pass.  Which query rows a key chunk is attended by, and the bias-table address
 // term of each, depend on the chunk position only -- not on the (image, head) -- so one wave per key
 // chunk (and per global-key split) builds the table ONCE per call (a role of k_mfma_prep_bwd); the dK/dV waves used to rebuild it per (image, head,
@@ -616,28 +608,6 @@ __global__ __launch_bounds__(256) void k_mfma_prep_bwd(VilParams p, MfmaCfg c, B
   }
 }
 
-#ifndef VIL_KV_PKFMA
-#define VIL_KV_PKFMA 0      // exponent arguments by v_pk_fma_f32 (two scores per instruction)
-#endif
-#ifndef VIL_KV_TIMING
-#define VIL_KV_TIMING 0     // diagnostics build only: per-segment s_memtime sums of the dK/dV waves (tools/kv_timing.py)
-#endif
-#if VIL_KV_TIMING
-__device__ unsigned long long vil_kv_timing[16];
-#ifndef VIL_KV_TIMING_EVERY
-#define VIL_KV_TIMING_EVERY 64     // only the waves of every 64th workgroup take stamps: s_memtime at full density slows the kernel 6x
-#endif
-#define KV_STAMP(v) __builtin_amdgcn_sched_barrier(0); unsigned v = 0; if (tme) v = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
-#define KV_ADD(i, a, b) tacc[i] += (b) - (a)
-extern "C" int vil_debug_kv_timing(unsigned long long* host16, int reset) {
-  if (host16 && hipMemcpyFromSymbol(host16, HIP_SYMBOL(vil_kv_timing), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(vil_kv_timing), z, sizeof(z)) != hipSuccess) return -1; }
-  return 0;
-}
-#else
-#define KV_STAMP(v)
-#define KV_ADD(i, a, b)
-#endif
 constexpr int kv_waves(int MD) { return MD == 2 ? VIL_KV_WAVES : 2; }
 template <typename T, int MD, int KT>
 __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
@@ -661,11 +631,6 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   const int wgi = fdiv(rem_, c.m_H), h = rem_ - wgi * p.H;
   const int bh = b * p.H + h;
   const unsigned tab_lds = lds_addr(smem);
-#if VIL_KV_TIMING
-  unsigned tacc[16] = {};
-  const bool tme = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % VIL_KV_TIMING_EVERY)) == 0;
-#endif
-  KV_STAMP(tk0);
 
   float* tab = (float*)smem;
   {
@@ -673,8 +638,6 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
   }
   __syncthreads();
-  KV_STAMP(tk1);
-  KV_ADD(11, tk0, tk1);
 
   char* wbase = smem + (size_t)c.tabsize * 4 + (size_t)wave * bc.kv_wave_lds;
   int* s_tok = (int*)wbase;                       // [nqs] token index of each streamed query slot (Q / dO row)
@@ -726,7 +689,6 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     const int ch = glo ? 0 : fdiv(unit, bc.m_kv_NWP), wp = glo ? 0 : unit - ch * bc.kv_NWP;
     const int km = fdiv(ch, c.m_my), kn = ch - km * g.my;
 
-    KV_STAMP(t0);
     // ---- streamed query slot table: the (token, bias address) columns come from the prologue kernel (kv_slots_block: one table per key chunk /
     // global-key split, built once per call); this wave adds the lse / delta of ITS (image, head).  256 slots per
     // round: table loads, then all gathers, then the LDS stores -- nothing waits on a single round trip.
@@ -754,8 +716,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int t = max(e[u].x, 0);
-          if (VIL_KV_ABL & 256) { l4[u] = 1.0f; d4[u] = 0.f; }
-          else { l4[u] = lse_bh[t]; d4[u] = dlt_bh[t]; }
+          l4[u] = lse_bh[t]; d4[u] = dlt_bh[t];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -768,9 +729,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
         }
       }
     }
-    const int nsteps = (VIL_KV_ABL & 64) ? 0 : (nchunks * W2 + 31) >> 5;
-    KV_STAMP(t1);
-    KV_ADD(0, t0, t1);
+    const int nsteps = (nchunks * W2 + 31) >> 5;
 
     // ---- this lane's key slots: column j of key-tile kt is key (x, y = KT*hq + KT-1 - kt)
     const int jj = wp * 16 + lj;
@@ -819,7 +778,6 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       for (int it = 0; it < MD; ++it) {
         const int row = (it * 64 + lane) / VCH;
         const int tok = s_tok[st * 32 + row];          // Q and dO may have different row strides (fused qkv)
-        if ((VIL_KV_ABL & 16) && st > 0) continue;
         qr_[sl][it] = __builtin_amdgcn_raw_buffer_load_b128(qrs, __mul24(tok, qstride_b) + ld_off[it], 0, 0);
         dr_[sl][it] = __builtin_amdgcn_raw_buffer_load_b128(drs, __mul24(tok, dostride_b) + ld_off[it], 0, 0);
       }
@@ -831,19 +789,13 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       constexpr int sl = decltype(slot_)::value;
       char* sq = s_q + (PIPE ? (st & 1) * 2 * TILE : 0);
       char* sd = sq + TILE;
-      KV_STAMP(ta);
 #pragma unroll
       for (int it = 0; it < MD; ++it) {
-        if ((VIL_KV_ABL & 32) && st > 0) break;
         *(u32x4*)(sq + st_off[it]) = qr_[sl][it];
         *(u32x4*)(sd + st_off[it]) = dr_[sl][it];
       }
-      KV_STAMP(ta2);
-      KV_ADD(2, ta, ta2);
       if (st + PF < nsteps) load_step(slot_, st + PF);
       wave_lds_fence();
-      KV_STAMP(tb);
-      KV_ADD(3, ta2, tb);
       // The bias gathers of the WHOLE step are issued before its first MFMA (32 dword reads in flight, counted waits).
       // Written per tile (gather 4x4, MFMA, next tile) the register allocator reused one C-operand quad for the tiles of
       // the first half and that half walked 4 dependent LDS round trips.  Same-box A/B at ViL-Small stage 1: 375 -> 365 us
@@ -859,7 +811,6 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
           sacc[hf][kt] = (f32x4){tb[0][kt], tb[1][kt], tb[2][kt], tb[3][kt]};
-          if (VIL_KV_ABL & 1) sacc[hf][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       }
       X8 qa[2][MK], da[2][MK];
@@ -880,21 +831,17 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           f32x4 dp = nd4[hf];
 #pragma unroll
           for (int ks = 0; ks < MK; ++ks) {
-            if (VIL_KV_ABL & 8) { acc[0] += (float)qa[hf][ks][0]; dp[0] += (float)da[hf][ks][0]; continue; }
             acc = mfma16(qa[hf][ks], kfb[ks][kt], acc);
             dp = mfma16(da[hf][ks], vfb[ks][kt], dp);
           }
           sacc[hf][kt] = acc; dpacc[hf][kt] = dp;
         }
-      KV_STAMP(tc);
-      KV_ADD(4, tb, tc);
     };
     // P = exp2(S c - lse), dS = P o (dP - delta);  dV^T += dO^T P ; dK^T += Q^T dS
     auto finish = [&](int st, const f32x4 (&sacc)[2][KT], const f32x4 (&dpacc)[2][KT]) {
       const char* sq = s_q + (PIPE ? (st & 1) * 2 * TILE : 0);
       const char* sd = sq + TILE;
       u32x4 pbw[KT], dsw[KT];       // the 8 packed 16-bit operand values of each key tile, as dwords (2 per query half)
-      KV_STAMP(td);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int sb = st * 32 + hf * 16 + lg * 4;
@@ -902,21 +849,9 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
           float pr[4];
-#if VIL_KV_PKFMA
-#pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            const f32x2 s2 = {sacc[hf][kt][2 * h2], sacc[hf][kt][2 * h2 + 1]};
-            const f32x2 l2 = {ls4[2 * h2], ls4[2 * h2 + 1]};
-            const f32x2 t2 = __builtin_elementwise_fma(s2, (f32x2){c1, c1}, -l2);
-            pr[2 * h2] = (VIL_KV_ABL & 2) ? t2[0] : __builtin_amdgcn_exp2f(t2[0]);
-            pr[2 * h2 + 1] = (VIL_KV_ABL & 2) ? t2[1] : __builtin_amdgcn_exp2f(t2[1]);
-          }
-#else
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            pr[r] = (VIL_KV_ABL & 2) ? __builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r])
-                                     : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r]));
-#endif
+            pr[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][kt][r], c1, -ls4[r]));
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
             const f32x2 p2 = {pr[2 * h2], pr[2 * h2 + 1]};
@@ -929,18 +864,8 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       X8 pb[KT], dsb[KT];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) { pb[kt] = __builtin_bit_cast(X8, pbw[kt]); dsb[kt] = __builtin_bit_cast(X8, dsw[kt]); }
-#if VIL_KV_TIMING
-      asm volatile("" :: "v"(pbw[0]), "v"(pbw[KT - 1]), "v"(dsw[0]), "v"(dsw[KT - 1]));
-#endif
-      KV_STAMP(te);
-      KV_ADD(5, td, te);
 #pragma unroll
       for (int dt = 0; dt < MD; ++dt) {
-        if (VIL_KV_ABL & 4) {
-#pragma unroll
-          for (int kt = 0; kt < KT; ++kt) { dv[dt][kt][0] += (float)pb[kt][dt]; dk[dt][kt][0] += (float)dsb[kt][dt]; }
-          continue;
-        }
         X8 qt_, dt_;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -957,14 +882,10 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           dk[dt][kt] = mfma16(qt_, dsb[kt], dk[dt][kt]);
         }
       }
-      KV_STAMP(tf);
-      KV_ADD(6, te, tf);
     };
 
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, PF - 1> S1;
-    KV_STAMP(t2);
-    KV_ADD(1, t1, t2);
     if (nsteps > 0) load_step(S0{}, 0);
     if constexpr (PF == 2) { if (nsteps > 1) load_step(S1{}, 1); }
     if constexpr (PIPE) {
@@ -992,13 +913,11 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       }
     }
 
-    KV_STAMP(t3);
-    KV_ADD(7, t2, t3);
     // ---- global-token QUERY rows (vil_attn_bwd_full): G extra queries that attend every key.  The unit's
     // K / V fragments are still in registers: scores by VALU dot products (G is 1..4, no MFMA tile to
     // fill), dK/dV added straight into the accumulators, the unit's share of dq_g / d(bias) to a partial
     // record.  Replaces a separate pass that re-read k, v, dk, dv and rewrote dk, dv.
-    if (!(VIL_KV_ABL & 128) && p.glo_rows && (!glo || split == 0)) {
+    if (p.glo_rows && (!glo || split == 0)) {
       float* rec = bc.gq_parts + ((int64_t)bh * (nown + 1) + (glo ? nown : unit)) * p.G * (M + 4);
       for (int gq = 0; gq < p.G; ++gq) {
         const T* qg = (const T*)(s_gq + gq * 3 * M * 2);
@@ -1094,8 +1013,6 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       }
     }
 
-    KV_STAMP(t4);
-    KV_ADD(8, t3, t4);
     // ---- epilogue
     if (!glo) {
 #pragma unroll
@@ -1125,22 +1042,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
         }
     }
     wave_lds_fence();
-    KV_STAMP(t5);
-    KV_ADD(9, t4, t5);
-    KV_ADD(10, t0, t5);
-#if VIL_KV_TIMING
-    tacc[12] += 1; tacc[13] += nsteps;
-#endif
   }
-#if VIL_KV_TIMING
-  {
-    KV_STAMP(t6);
-    KV_ADD(14, tk0, t6);
-    tacc[15] = 1;
-    if (lane == 0 && tme)
-      for (int i = 0; i < 16; ++i) atomicAdd(&vil_kv_timing[i], (unsigned long long)tacc[i]);
-  }
-#endif
 }
 
 // One workgroup per (image, head, global token gk):
@@ -1481,9 +1383,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     if ((e = (int)hipGetLastError())) return e;
   }
   {
-    // (diagnostics: VIL_DEBUG_KV_LDS_PAD=<bytes> of unused LDS per workgroup lowers the resident waves per SIMD)
-    static const size_t pad = [] { const char* e_ = getenv("VIL_DEBUG_KV_LDS_PAD"); return e_ ? (size_t)atol(e_) : (size_t)0; }();
-    const size_t lds = kv_lds(c, bc) + pad;
+    const size_t lds = kv_lds(c, bc);
     const unsigned grid = (unsigned)(p.B * p.H * bc.kv_wg_per_bh);
     vil_prof_begin(VIL_K_MFMA_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
     BWD_SWITCH({

@@ -7,7 +7,7 @@
 // vil_gemm_tune: it times the candidates on scratch operands with hipEvents (it synchronises -- call it outside
 // stream capture, once per problem) and caches the winner; vil_gemm_bf16 itself only launches (asynchronous, never
 // synchronises; an untuned problem runs the heuristic's first choice).
-// State: the plan cache below (problem -> descriptors + selected algorithm) is process-global and mutex-guarded; it
+// State: the plan cache below ((device, problem) -> descriptors + selected algorithm) is process-global and mutex-guarded; it
 // is the library's only mutable state besides the profiling sink of vil_attn_api.hip.
 #include "vil_internal.h"
 #include <hipblaslt/hipblaslt.h>
@@ -27,10 +27,11 @@ struct Plan {
   std::vector<hipblasLtMatmulHeuristicResult_t> cand;
 };
 
-typedef std::tuple<int, int64_t, int, int, int64_t, int64_t, int> Key;   // op, T, K, N, in stride, out stride, bias
+typedef std::tuple<int, int, int64_t, int, int, int64_t, int64_t, int> Key;   // device, op, T, K, N, in stride, out stride, bias
 std::map<Key, Plan> g_plans;
 std::mutex g_mu;
-hipblasLtHandle_t g_handle = nullptr;
+std::map<int, hipblasLtHandle_t> g_handles;      // one handle per device (a plan is tuned on, and valid for, its device)
+hipblasLtHandle_t g_handle = nullptr;            // the calling thread's current device's handle (set by get_plan under g_mu)
 
 int make_plan(Plan& pl, int op, int64_t T, int K, int N, int64_t in_rs, int64_t out_rs, bool bias, size_t wsz) {
   // row-major problem restated column-major: C (N x T, ld out_rs) = op(A) (N x K) * B (K x T, ld in_rs)
@@ -87,8 +88,12 @@ int make_plan(Plan& pl, int op, int64_t T, int K, int N, int64_t in_rs, int64_t 
 extern "C" size_t vil_gemm_workspace_bytes(void) { return (size_t)32 << 20; }
 
 static int get_plan(Plan*& out, int op, int64_t T, int K, int N, int64_t in_rs, int64_t out_rs, bool bias, size_t wsz) {
-  if (!g_handle && hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return VIL_E_BACKEND;
-  const Key key(op, T, K, N, in_rs, out_rs, bias ? 1 : 0);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return VIL_E_BACKEND;
+  hipblasLtHandle_t& hd = g_handles[dev];
+  if (!hd && hipblasLtCreate(&hd) != HIPBLAS_STATUS_SUCCESS) return VIL_E_BACKEND;
+  g_handle = hd;
+  const Key key(dev, op, T, K, N, in_rs, out_rs, bias ? 1 : 0);
   Plan& pl = g_plans[key];
   if (!pl.valid && make_plan(pl, op, T, K, N, in_rs, out_rs, bias, wsz)) return VIL_E_BACKEND;
   out = &pl;

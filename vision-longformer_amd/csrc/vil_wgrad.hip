@@ -10,7 +10,6 @@
 // (rows are the contraction index), fp32 partials per split, then one reduce pass.  db rides on the
 // A fragments already in registers.
 #include "vil_internal.h"
-#include <cstdlib>
 
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
@@ -207,11 +206,10 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradParams p) {
 static void wgrad_plan(int64_t T, int CO, int CI, int& tiles_co, int& tiles_ci, int& nsplit, int64_t& rps) {
   tiles_co = (CO + WG_TILE - 1) / WG_TILE; tiles_ci = (CI + WG_TILE - 1) / WG_TILE;
   const int tiles = tiles_co * tiles_ci;
-  static const int target = [] { const char* e = getenv("VIL_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
-  // ~2 workgroups per CU, whole XCD rounds (tuning hook: VIL_WGRAD_WGS).  The HBM-bound shapes (>= 64 k tokens into >= 3
-  // output tiles: the fc / qkv layers of stages 1-2) run 8-12 % faster with 3 per CU (tools/wgrad_probe2.py); the
-  // MFMA-bound ones (stages 3-4) and the one- and two-tile outputs lose 10-25 % there
-  const int tgt = (getenv("VIL_WGRAD_WGS") == nullptr && T >= 65536 && tiles >= 3) ? 768 : target;
+  // ~2 workgroups per CU, whole XCD rounds.  The HBM-bound shapes (>= 64 k tokens into >= 3 output tiles: the fc / qkv
+  // layers of stages 1-2) run 8-12 % faster with 3 per CU (round-2 sweep, tools/wgrad_probe2.py); the MFMA-bound ones
+  // (stages 3-4) and the one- and two-tile outputs lose 10-25 % there
+  const int tgt = (T >= 65536 && tiles >= 3) ? 768 : 512;
   int64_t s = ((tgt + tiles - 1) / tiles + 7) / 8 * 8;
   const int64_t max_by_rows = (T + 4 * WG_ROWS - 1) / (4 * WG_ROWS);   // >= 4 steps per workgroup
   const int64_t max_by_ws = ((int64_t)96 << 20) / ((int64_t)CO * CI * 4);

@@ -36,8 +36,12 @@ def recipe_of(config):
     return "qhm" if CONFIGS[config][1] == 384 else "adamw"
 
 
-def init_distributed():
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun / torch.distributed.run)."""
+def init_distributed(single_rank_group=False):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun / torch.distributed.run).  Collectives carry a
+    timeout (VIL_DIST_TIMEOUT_S, default 600 s) so that a mis-ordered stream or a missing rank fails loudly instead of
+    hanging.  single_rank_group: also create the (RCCL) process group when WORLD_SIZE == 1 -- the multi-GPU code path
+    (segment graphs + asynchronous all-reduce) then runs for real on one GPU (bench.py --force-segments, tests)."""
+    import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -47,13 +51,14 @@ def init_distributed():
     device = torch.device("cuda", 0 if share else local_rank) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        tmo = datetime.timedelta(seconds=float(os.environ.get("VIL_DIST_TIMEOUT_S", "600")))
         if use_cuda and not share:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=tmo)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
     return rank, local_rank, world, device
 
 
@@ -218,6 +223,19 @@ class MasterWeightOptimizer:
         for p in self.direct:
             p.grad = None
 
+    @torch.no_grad()
+    def reset_state(self):
+        """zeroes the optimizer state in place (moments / momentum buffers and the step count): the tensors a captured
+        step reads keep their addresses"""
+        for st in self.opt.state.values():
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    v.zero_()
+                elif k == "step":
+                    st[k] = 0
+        if self._fused:
+            self.opt.reset_step_count()
+
     def settle(self):
         """waits for a pending plan upload (call before and after stream capture)"""
         if self._fused:
@@ -303,8 +321,12 @@ class GraphedTrainStep:
     Random-shift training (mode > 0) stays graphable: the neighbour of each layer is a device word read by the
     kernels (VilAttnDesc.mode_dev), refreshed from the host before every replay."""
 
-    def __init__(self, model, optimizer, images, targets, world=1, amp_dtype=torch.bfloat16, warmup=3, segments=3):
+    def __init__(self, model, optimizer, images, targets, world=1, amp_dtype=torch.bfloat16, warmup=3, segments=3,
+                 force_segments=False):
         self.model, self.opt, self.world, self.amp = model, optimizer, world, amp_dtype
+        # force_segments: the multi-rank structure (segment graphs, flat-gradient all-reduce per segment on the process
+        # group's stream, optimizer graph) with world == 1 -- exercises the RCCL path on a single GPU
+        self.segmented = world > 1 or bool(force_segments)
         dev = images.device
         self.x = torch.empty_like(images)
         self.t = torch.empty_like(targets)
@@ -312,7 +334,7 @@ class GraphedTrainStep:
         # ---- backward segments (world > 1): parameters by the stage they belong to, last stage first
         self.seg_params, self.cut_stages = [self.params], []
         self.flats, self.views, self.seg_flats = [], {}, [[]]
-        if world > 1:
+        if self.segmented:
             L = model.num_layers
             nseg = max(1, min(int(segments), L))
             stage_of = {}
@@ -374,7 +396,7 @@ class GraphedTrainStep:
         if settle:
             settle()
         self.graphs, self.opt_graph = [], None
-        if world == 1:
+        if not self.segmented:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._segment(0, None)
@@ -455,7 +477,8 @@ class GraphedTrainStep:
                 w = dist.all_reduce(f, op=dist.ReduceOp.AVG, async_op=async_op)
             else:
                 w = dist.all_reduce(f, async_op=False)
-                f.div_(self.world)
+                if self.world > 1:
+                    f.div_(self.world)
             if async_op and w is not None:
                 works.append(w)
         return works
@@ -474,7 +497,7 @@ class GraphedTrainStep:
         state = None
         for k in range(len(self.seg_params)):
             state = self._segment(k, state)
-            if self.world > 1:
+            if self.segmented:
                 self._allreduce(self.seg_flats[k])
         self.opt.step()
 

@@ -6,7 +6,6 @@ in bf16 -- numerically identical to PyTorch's fp32 LayerNorm followed by autocas
 Linear, without the cast kernels and with half the write traffic.  CPU tensors fall through to
 `nn.LayerNorm.forward` (this layer is glue, not the hot path; the CPU baseline model uses it that way)."""
 import ctypes
-import os
 
 import torch
 from torch import nn
@@ -254,8 +253,7 @@ class _PassLN(torch.autograd.Function):
 def pass_layernorm_ok(x, norm):
     C = x.shape[-1]
     return (isinstance(norm, VilLayerNorm) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
-            and C % 8 == 0 and C <= 1024 and norm.elementwise_affine and norm.bias is not None
-            and not os.environ.get("VIL_UNFUSED_STAGE_ENTRY"))
+            and C % 8 == 0 and C <= 1024 and norm.elementwise_affine and norm.bias is not None)
 
 
 def pass_layernorm(x, norm):

@@ -109,7 +109,9 @@ def _gemm(op, inp2, w, bias):
         # explicit, one-off algorithm selection per problem (synchronises; never inside a captured region):
         # the launch call itself stays asynchronous
         _GEMM_TUNED.add(key)
-        L.vil_gemm_tune(*args)
+        rc = L.vil_gemm_tune(*args)
+        if rc not in (0, _lib.VIL_E_BACKEND):        # (BACKEND: no algorithm for this problem -> the caller's fallback)
+            _lib.check(rc)
     rc = L.vil_gemm_bf16(*args)
     if rc == _lib.VIL_E_BACKEND:
         return None
@@ -170,6 +172,83 @@ def vil_linear(x, weight, bias):
                 return _SplitKLinearFn.apply(x, w, b)
         return _SplitKLinearFn.apply(x, weight, bias)
     return F.linear(x, weight, bias)
+
+
+def _adjacent(a, b):
+    """b starts where a ends, in ONE storage (rows of one packed matrix)"""
+    return (a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous() and a.device == b.device
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and a.data_ptr() + a.numel() * a.element_size() == b.data_ptr())
+
+
+class _PairLinearFn(torch.autograd.Function):
+    """y = x [W1; W2]^T + [b1; b2] for two projections of the same input whose parameters are ROWS OF ONE PACKED MATRIX
+    (pack_pair): one forward GEMM, one input-gradient GEMM, one weight-gradient launch; the four parameter gradients
+    are row slices of the packed gradient (views: no cat in the forward, no split copies in the backward)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, w1, b1, w2, b2):
+        co1, ci = w1.shape
+        co = co1 + w2.shape[0]
+        w = w1.as_strided((co, ci), (ci, 1))
+        b = b1.as_strided((co,), (1,)) if b1 is not None else None
+        ctx.save_for_backward(x, w)
+        ctx.co1, ctx.has_bias = co1, b is not None
+        y = _gemm(0, x.reshape(-1, ci), w, b)
+        if y is None:
+            y = F.linear(x.reshape(-1, ci), w, b)
+        return y.view(*x.shape[:-1], co)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        co, ci = w.shape
+        dy2, x2 = dy.reshape(-1, co), x.reshape(-1, ci)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm(1, dy2, w, None)
+            dx = (dx if dx is not None else dy2 @ w).view(x.shape)
+        fused = _wgrad(dy2, x2, ctx.has_bias)
+        if fused is not None:
+            dw, db = fused[0].to(w.dtype), fused[1]
+        else:
+            dw = (dy2.t() @ x2).to(w.dtype)
+            db = _colsum(dy2) if ctx.has_bias else None
+        c = ctx.co1
+        return dx, dw[:c], (db[:c] if db is not None else None), dw[c:], (db[c:] if db is not None else None)
+
+
+def pack_pair(lin1, lin2):
+    """Re-homes the parameters of two Linears over the same input as rows of one packed (co1 + co2, ci) matrix (and
+    one packed bias): same Parameter objects, names, shapes and values (state dict unchanged), new storage.  Done
+    once; repeated only when something re-allocated a parameter (.to(), a dtype change)."""
+    with torch.no_grad():
+        w1, w2 = lin1.weight, lin2.weight
+        pw = torch.empty(w1.shape[0] + w2.shape[0], w1.shape[1], dtype=w1.dtype, device=w1.device)
+        pw[:w1.shape[0]].copy_(w1); pw[w1.shape[0]:].copy_(w2)
+        w1.data, w2.data = pw[:w1.shape[0]], pw[w1.shape[0]:]
+        if lin1.bias is not None:
+            b1, b2 = lin1.bias, lin2.bias
+            pb = torch.empty(b1.numel() + b2.numel(), dtype=b1.dtype, device=b1.device)
+            pb[:b1.numel()].copy_(b1); pb[b1.numel():].copy_(b2)
+            b1.data, b2.data = pb[:b1.numel()], pb[b1.numel():]
+
+
+def vil_linear_pair(x, lin1, lin2):
+    """lin1(x) and lin2(x) as ONE projection (columns [lin1 | lin2]); None when the pair cannot run packed (the
+    caller then applies the two Linears separately)."""
+    w1, w2, b1, b2 = lin1.weight, lin2.weight, lin1.bias, lin2.bias
+    if not (x.is_cuda and torch.is_grad_enabled() and w1.dtype == w2.dtype and w1.dtype == x.dtype == torch.bfloat16
+            and (b1 is None) == (b2 is None) and w1.shape[1] == w2.shape[1]):
+        return None
+    if not (_adjacent(w1, w2) and (b1 is None or _adjacent(b1, b2))):
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        pack_pair(lin1, lin2)
+    with torch.autocast("cuda", enabled=False):
+        return _PairLinearFn.apply(x, w1, b1, w2, b2)
 
 
 class VilLinear(nn.Linear):

@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from .ops import vil_local_attention, vil_full_attention, vil_full_attention_qkv, vil_global_attention, FULL_MAX_G
-from .linear import VilLinear, vil_linear
+from .linear import VilLinear, vil_linear, vil_linear_pair
 
 
 def _trunc_normal_(t, std):
@@ -108,10 +108,9 @@ class Long2DSCSelfAttention(nn.Module):
                 and self.proj_global is self.proj and not self.only_glo and M in (8, 16, 32, 48, 64))
 
     def _packed_projection_ok(self, x):
-        import os
         q, kv = self.query, self.kv
         return (x.is_cuda and isinstance(q, VilLinear) and isinstance(kv, VilLinear) and q.weight.dtype == kv.weight.dtype
-                and (q.bias is None) == (kv.bias is None) and not os.environ.get("VIL_UNPACKED_QKV"))
+                and (q.bias is None) == (kv.bias is None))
 
     def forward(self, x, nx, ny):
         B, N, C = x.shape
@@ -135,12 +134,20 @@ class Long2DSCSelfAttention(nn.Module):
             # gradient contributions to kv are summed inside the kernels
             kw = dict(nx=nx, ny=ny, w=self.attention_window, nglo=G, num_heads=H, mode=(1 if rs_dev else mode),
                       exact=self.exact, scale=self.scale, backend=self.backend, mode_dev=self.mode_dev if rs_dev else None)
+            qkv = None
             if self._packed_projection_ok(x):
                 # query and kv as ONE (3C, C) GEMM over the shared input: x is read once, and the backward is one input-
-                # gradient GEMM and one weight-gradient kernel instead of two of each plus an accumulation pass
-                wq, wkv = self.query.weight, self.kv.weight
-                bias = torch.cat([self.query.bias, self.kv.bias]) if self.query.bias is not None else None
-                out = vil_full_attention_qkv(vil_linear(x, torch.cat([wq, wkv], dim=0), bias), table, g2l, g2g, **kw)
+                # gradient GEMM and one weight-gradient kernel instead of two of each plus an accumulation pass.  With
+                # 16-bit working weights (engine.MasterWeightOptimizer) the two Linears' parameters are rows of one packed
+                # matrix (linear.pack_pair, once): no concatenation per forward, no split copies per backward.  Under
+                # per-call autocast casts the casted copies are concatenated instead.
+                qkv = vil_linear_pair(x, self.query, self.kv)
+                if qkv is None:
+                    wq, wkv = self.query.weight, self.kv.weight
+                    bias = torch.cat([self.query.bias, self.kv.bias]) if self.query.bias is not None else None
+                    qkv = vil_linear(x, torch.cat([wq, wkv], dim=0), bias)
+            if qkv is not None:
+                out = vil_full_attention_qkv(qkv, table, g2l, g2g, **kw)
             else:
                 out = vil_full_attention(self.query(x), self.kv(x), table, g2l, g2g, **kw)
             return self.proj_drop(self.proj(out))

@@ -193,7 +193,7 @@ class Attention(nn.Module):
         M = C // H
         nglo = self.nglo if self.rpe else (N - nx * ny if nx is not None else -1)
         gx, gy = (self.wx, self.wy) if self.rpe else (nx, ny)
-        if (qkv.is_cuda and qkv.dtype == torch.bfloat16 and gx is not None and gx == gy and gx <= 32
+        if (qkv.is_cuda and qkv.dtype in (torch.bfloat16, torch.float16) and gx is not None and gx == gy and gx <= 32
                 and 0 <= nglo <= FULL_MAX_G and nglo + gx * gy == N and M in (16, 32, 48, 64)
                 and (self.attn_drop.p == 0.0 or not self.training)):
             # the dense attention of the s0 stages is the one-chunk case of the fused
@@ -444,21 +444,28 @@ class MsViT(nn.Module):
         if not self.training or self.drop_path_rate <= 0.0 or device.type != "cuda":
             self._dp_scales = None
             return
-        keep = getattr(self, "_dp_keep", None)
-        if keep is None or keep.device != device:
-            blks = [blk for i in range(self.num_layers) for blk in list(getattr(self, "layer%d" % (i + 1)))[1:]
-                    if isinstance(getattr(blk, "drop_path", None), DropPath) and blk.drop_path.drop_prob > 0.0]
+        # rows are keyed by (stage, block index) and the cache by the tuple of drop probabilities, so a stochastic-depth
+        # schedule that changes drop_prob (or a deepcopy of the model) rebuilds it
+        blks, keys = [], []
+        for i in range(self.num_layers):
+            for j, blk in enumerate(list(getattr(self, "layer%d" % (i + 1)))[1:]):
+                if isinstance(getattr(blk, "drop_path", None), DropPath) and blk.drop_path.drop_prob > 0.0:
+                    blks.append(blk); keys.append((i, j, float(blk.drop_path.drop_prob)))
+        sig = (tuple(keys), device)
+        if getattr(self, "_dp_sig", None) != sig:
+            self._dp_sig = sig
             self._dp_rows = {id(blk): r for r, blk in enumerate(blks)}
-            keep = self._dp_keep = (1.0 - torch.tensor([b_.drop_path.drop_prob for b_ in blks], dtype=torch.float32,
-                                                       device=device)).view(-1, 1)
+            self._dp_keep = (1.0 - torch.tensor([k[2] for k in keys], dtype=torch.float32, device=device)).view(-1, 1)
+        keep = self._dp_keep
+        if keep.numel() == 0:
+            self._dp_scales = None
+            return
         u = torch.rand(keep.shape[0], B, device=device)
         self._dp_scales = (u < keep).to(torch.float32) / keep
 
     @staticmethod
     def _fused_transition_ok(x, pend, embed, nx, ny):
-        import os
-        from . import _lib
-        if os.environ.get("VIL_UNFUSED_STAGE_ENTRY") or not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
             return False
         ph, pw = embed.patch_size
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype

@@ -178,6 +178,11 @@ class _VilOptimizer(Optimizer):
             plan.pending = torch.cuda.Event()
             plan.pending.record(cur)
 
+    def reset_step_count(self, value=0):
+        for bucket in self._plans.values():
+            bucket.steps[0] = int(value)
+            bucket.steps[1] = 0
+
     def after_capture(self):
         for bucket in self._plans.values():
             for plan in (bucket.eager, bucket.graph):
