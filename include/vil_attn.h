@@ -193,7 +193,7 @@ int vil_patchify_bwd(const void* dpatches, int dp_dtype, const float* rscale, fl
 /* ---- the reference's OPERATOR-level surface (compatibility / parity; the hot path is vil_attn_fwd/_bwd, which never
  * builds the score tensor).  Chunked layouts of the reference: images (BH, M, mx, my, W^2), scores
  * (BH, mx, my, W^2, kv), kv = 9 W^2 (mode 0) | W^2 (mode -1) | 2 W^2 (mode 1..8: [own chunk | neighbour]); neighbours
- * are cyclic (torch.roll).  dtype VIL_DTYPE_F32 or VIL_DTYPE_F64; contiguous tensors.
+ * are cyclic (torch.roll).  dtype VIL_DTYPE_F32, _F64, _BF16 or _F16 (16-bit I/O accumulates in fp32); contiguous tensors.
  *   vil_sc2d_qk     SlidingChunk2D.slidingchunk_qk     (src/models/layers/slidingchunk_2d.py:26-79)
  *   vil_sc2d_av     SlidingChunk2D.slidingchunk_av     (:82-130)
  *   vil_sc2d_agrad  SlidingChunk2D.slidingchunk_agrad  (:132-200)

@@ -198,7 +198,7 @@ def test_round2_entry_points_validate_before_launching():
     a16 = vp(4096)
     F32, F64, BF16, F16 = _lib.DTYPE_F32, _lib.DTYPE_F64, _lib.DTYPE_BF16, _lib.DTYPE_F16
     assert L.vil_sc2d_qk(None, a16, a16, 2, 4, 2, 2, 4, 0, F32, None) == -1
-    assert L.vil_sc2d_qk(a16, a16, a16, 2, 4, 2, 2, 4, 0, BF16, None) == -7        # operator surface: fp32 / fp64 only
+    assert L.vil_sc2d_qk(a16, a16, a16, 2, 4, 2, 2, 4, 0, 7, None) == -7           # unknown dtype
     assert L.vil_sc2d_av(a16, a16, a16, 2, 4, 2, 2, 4, 9, F64, None) == -5         # mode out of range
     assert L.vil_sc2d_agrad(a16, a16, a16, 0, 4, 2, 2, 4, 0, F32, None) == -2
     assert L.vil_sc2d_mask(a16, 2, 2, 2, 0, 0, 4, 1, 3, F32, None, None) == -6     # exact=1 with mode != 0: the reference's ValueError

@@ -295,6 +295,53 @@ def test_module_bf16_autocast_vs_golden(c, dev, golden_dir):
     compare("module/bf16-autocast backward " + c["name"], got, want, tols)
 
 
+ATTN_DROP_CASES = [c for c in GC.MODULE_CASES if c["name"] in (
+    "d32h2w4_8x8_g1", "d32h2w4_10x9_g1", "d32h2w4_10x9_g1_exact1", "d32h2w4_10x9_g1_cyclic", "d48h3w3_7x7_g2_mode2",
+    "d48h3w3_7x7_g2_self", "d32h2w4_10x10_g0", "d32h2w4_8x8_g1_onlyglo", "d32h2w4_8x8_g1_nosharew", "d64h2w7_16x15_g1_mode3")]
+
+
+@pytest.mark.parametrize("c", ATTN_DROP_CASES, ids=lambda c: c["name"])
+def test_module_attn_drop_path_vs_golden(c, dev, golden_dir):
+    """attn_drop > 0 in training runs the reference's algorithm on the operator-level HIP kernels (scores materialised,
+    probabilities dropped: longformer2d.py:134-229).  With a drop probability of 1e-12 nothing is dropped, so the path
+    must reproduce the reference's fixtures (output, dx, every parameter gradient); with p = 0.5 it must stay finite,
+    differ from the undropped output, and keep its mean (inverted dropout)."""
+    import random
+    gold = np.load(os.path.join(golden_dir, "module_cases.npz"))
+    mod, x, dout = _load_module(c, dev, torch.float32)
+    mod.train()
+    mod.attn_drop.p = 1e-12
+    orig = random.randrange
+    random.randrange = (lambda a, b=None, _m=c["mode"]: _m)
+    try:
+        xd = x.float().to(dev).requires_grad_(True)
+        out = mod(xd, c["nx"], c["ny"])
+        out.backward(dout.float().to(dev))
+        torch.cuda.synchronize()
+        pre = c["name"] + "/"
+        torch.testing.assert_close(out.detach().double().cpu(), torch.from_numpy(gold[pre + "out"]), atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(xd.grad.double().cpu(), torch.from_numpy(gold[pre + "dx"]), atol=3e-4, rtol=1e-3)
+        n_checked = 0
+        for n, p_ in mod.named_parameters():
+            if p_.grad is not None and (pre + "d_" + n) in gold.files:
+                ref = torch.from_numpy(gold[pre + "d_" + n])
+                torch.testing.assert_close(p_.grad.double().cpu(), ref, atol=2e-3 * max(1.0, float(ref.abs().max())), rtol=2e-3,
+                                           msg=lambda m: f"{pre}d_{n}: {m}")
+                n_checked += 1
+        assert n_checked >= 4
+        mod.attn_drop.p = 0.5
+        torch.manual_seed(1)
+        outs = torch.stack([mod(xd.detach(), c["nx"], c["ny"]).detach() for _ in range(16)])
+        assert torch.isfinite(outs).all()
+        assert float((outs[0] - out.detach()).abs().max()) > 1e-3
+        if not c["only_glo"]:
+            err = float((outs.mean(0) - out.detach()).abs().mean() / out.detach().abs().mean())
+            assert err < 0.5, err
+    finally:
+        random.randrange = orig
+    report("ok   module attn_drop (materialised operator path) " + c["name"])
+
+
 @pytest.mark.parametrize("amp", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("c", GC.DENSE_CASES, ids=lambda c: c["name"])
 def test_dense_attention_module_vs_golden(c, amp, dev, golden_dir):
@@ -576,6 +623,34 @@ def test_operator_level_golden(opcase, dev, golden_dir):
                 # fixtures are stored in fp32: compare at fp32 resolution
                 torch.testing.assert_close(t.detach().cpu(), ref, rtol=2e-6, atol=2e-6, msg=lambda m_: f"{pre}{nm}: {m_}")
     report(f"ok   operator-level golden {name} (10 modes x 2 autograd flavours, fp64 on HIP)")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_operator_level_16bit_io(dtype, dev, golden_dir):
+    """The operator surface in the reference's AMP dtypes (its SlidingChunk2D runs under @autocast on GPU,
+    slidingchunk_2d.py:203,235): 16-bit I/O, fp32 accumulation inside the HIP kernels, against the reference's fp64
+    fixtures at 16-bit tolerances (the reference's own profiling tolerances, test_slidingchunk_2d.py:167-175)."""
+    from vision_longformer_amd.slidingchunk_2d import slidingchunk_2d, mask_invalid_locations
+    gold = np.load(os.path.join(golden_dir, "op_cases.npz"))
+    opcase = GC.OP_CASES[1]
+    name, BH, M, mx, my, W = opcase
+    for mode in (0, -1, 3, 6):
+        q, k, v = (t.to(dtype) for t in GC.op_inputs(opcase))
+        g = torch.Generator().manual_seed(GC.SEED + 1)
+        gout = torch.randn(q.shape, generator=g, dtype=torch.float64)
+        qq, kk, vv = (t.clone().to(dev).requires_grad_(True) for t in (q, k, v))
+        attn = slidingchunk_2d(qq, kk, False, mode)
+        assert attn.dtype == dtype
+        a2 = attn.float()
+        mask_invalid_locations(a2, mx, my, 0, 0, W, 0, mode)
+        out = slidingchunk_2d(torch.softmax(a2, dim=-1).to(dtype), vv, True, mode)
+        (out.float() * gout.float().to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        pre = f"{name}_m{mode}_"
+        for nm, t, atol, rtol in (("attn", attn, 2e-2, 1e-1), ("out", out, 2e-2, 1e-1), ("dq", qq.grad, 5e-2, 2e-1),
+                                  ("dk", kk.grad, 5e-2, 2e-1), ("dv", vv.grad, 5e-2, 2e-1)):
+            ref = torch.from_numpy(gold[pre + nm]).double()
+            torch.testing.assert_close(t.detach().double().cpu(), ref, rtol=rtol, atol=atol, msg=lambda m_: f"{pre}{nm}: {m_}")
 
 
 @pytest.mark.parametrize("grid", GC.MASK_GRIDS, ids=lambda g: "g%dx%dp%dx%dw%d" % g)

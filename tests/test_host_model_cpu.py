@@ -212,8 +212,11 @@ def test_cpu_optimizer_is_refused_without_the_oracle_module():
         make_optimizer(m)
 
 
-def test_attn_drop_in_training_is_refused_not_ignored():
+def test_attn_drop_in_training_takes_the_materialised_path_not_the_fused_one():
+    """attn_drop > 0 in training drops attention PROBABILITIES (reference longformer2d.py:186,224): the module must not
+    silently run the fused kernels (which never materialise them).  It runs the operator-level HIP path -- which, like
+    everything else, has no CPU fallback."""
     a = Long2DSCSelfAttention(32, num_heads=2, w=4, nglo=1, sharew=True, attn_drop=0.1)
     a.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         a(torch.zeros(1, 1 + 16, 32), 4, 4)

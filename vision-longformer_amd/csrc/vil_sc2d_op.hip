@@ -29,7 +29,9 @@ static int sc2d_fill(Sc2dParams& p, int BH, int M, int mx, int my, int W, int mo
 __device__ __forceinline__ int wrap(int a, int n) { a %= n; return a < 0 ? a + n : a; }
 
 // attn[b,m,n,l,a*W2+t] = sum_c q[b,c,m,n,l] * k[b,c,(m+dr_a) mod mx,(n+dc_a) mod my,t]      (slidingchunk_qk, :26-79)
-template <typename T>
+// T = I/O element type (double, float, __bf16, _Float16), A = accumulation type (double for double, float otherwise: the
+// reference's @autocast runs these einsums in fp16 with fp32 accumulation on GPU, slidingchunk_2d.py:203,235)
+template <typename T, typename A>
 __global__ void k_sc2d_qk(Sc2dParams p, const T* __restrict__ q, const T* __restrict__ k, T* __restrict__ attn) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n) return;
@@ -44,13 +46,13 @@ __global__ void k_sc2d_qk(Sc2dParams p, const T* __restrict__ q, const T* __rest
   const int64_t cs = (int64_t)p.mx * p.my * p.W2;
   const T* qp = q + (int64_t)b * p.M * cs + ((int64_t)m * p.my + n) * p.W2 + l;
   const T* kp = k + (int64_t)b * p.M * cs + ((int64_t)m2 * p.my + n2) * p.W2 + t;
-  T acc = 0;
-  for (int c = 0; c < p.M; ++c) acc += qp[c * cs] * kp[c * cs];
-  attn[i] = acc;
+  A acc = 0;
+  for (int c = 0; c < p.M; ++c) acc += (A)qp[c * cs] * (A)kp[c * cs];
+  attn[i] = (T)acc;
 }
 
 // out[b,c,m,n,l] = sum_a sum_t attn[b,m,n,l,a*W2+t] * v[b,c,(m+dr_a),(n+dc_a),t]             (slidingchunk_av, :82-130)
-template <typename T>
+template <typename T, typename A>
 __global__ void k_sc2d_av(Sc2dParams p, const T* __restrict__ attn, const T* __restrict__ v, T* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n) return;
@@ -61,18 +63,18 @@ __global__ void k_sc2d_av(Sc2dParams p, const T* __restrict__ attn, const T* __r
   const int c = (int)(r % p.M);
   const int b = (int)(r / p.M);
   const T* ap = attn + ((((int64_t)b * p.mx + m) * p.my + n) * p.W2 + l) * p.kv;
-  T acc = 0;
+  A acc = 0;
   for (int a = 0; a < p.nact; ++a) {
     const int m2 = wrap(m + p.adr[a], p.mx), n2 = wrap(n + p.adc[a], p.my);
     const T* vp = v + ((((int64_t)b * p.M + c) * p.mx + m2) * p.my + n2) * p.W2;
-    for (int t = 0; t < p.W2; ++t) acc += ap[a * p.W2 + t] * vp[t];
+    for (int t = 0; t < p.W2; ++t) acc += (A)ap[a * p.W2 + t] * (A)vp[t];
   }
-  out[i] = acc;
+  out[i] = (T)acc;
 }
 
 // grad_t2[b,c,m',n',t] = sum_a sum_l attn[b,m,n,l,a*W2+t] * g[b,c,m,n,l],  (m,n) = (m'-dr_a, n'-dc_a) cyclic
 // (slidingchunk_agrad, :132-200: the einsum followed by the REVERSE roll)
-template <typename T>
+template <typename T, typename A>
 __global__ void k_sc2d_agrad(Sc2dParams p, const T* __restrict__ attn, const T* __restrict__ g, T* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n) return;
@@ -82,14 +84,14 @@ __global__ void k_sc2d_agrad(Sc2dParams p, const T* __restrict__ attn, const T* 
   const int m2 = (int)(r % p.mx); r /= p.mx;
   const int c = (int)(r % p.M);
   const int b = (int)(r / p.M);
-  T acc = 0;
+  A acc = 0;
   for (int a = 0; a < p.nact; ++a) {
     const int m = wrap(m2 - p.adr[a], p.mx), n = wrap(n2 - p.adc[a], p.my);
     const T* ap = attn + ((((int64_t)b * p.mx + m) * p.my + n) * p.W2) * p.kv + a * p.W2 + t;
     const T* gp = g + ((((int64_t)b * p.M + c) * p.mx + m) * p.my + n) * p.W2;
-    for (int l = 0; l < p.W2; ++l) acc += ap[(int64_t)l * p.kv] * gp[l];
+    for (int l = 0; l < p.W2; ++l) acc += (A)ap[(int64_t)l * p.kv] * (A)gp[l];
   }
-  out[i] = acc;
+  out[i] = (T)acc;
 }
 
 // mask_invalid_locations (:321-357): attn[b,m,n,l,s] = -inf where key slot s of chunk (m,n) is not attended by query l
@@ -110,12 +112,22 @@ __global__ void k_sc2d_mask(Sc2dParams p, VilGeom g, T* __restrict__ attn, unsig
   int st = vil_key_state(g, m, n, g.adr[a], g.adc[a], t / W, t % W, kr, kc);
   if (st != VIL_KEY_MASKED && g.exact == 1 && !vil_exact_window(W, m * W + l / W, n * W + l % W, kr, kc)) st = VIL_KEY_MASKED;
   if (st == VIL_KEY_MASKED) {
-    attn[i] = -(T)__builtin_huge_valf();
+    attn[i] = (T)(-__builtin_huge_valf());
     if (b == 0 && count) atomicAdd(count, 1ull);
   }
 }
 
-static int sc2d_dtype_ok(int dtype) { return dtype == VIL_DTYPE_F32 || dtype == VIL_DTYPE_F64; }
+static int sc2d_dtype_ok(int dtype) {
+  return dtype == VIL_DTYPE_F32 || dtype == VIL_DTYPE_F64 || dtype == VIL_DTYPE_BF16 || dtype == VIL_DTYPE_F16;
+}
+// one launch per I/O dtype
+#define SC2D_DISPATCH(KERNEL, ...)                                                                                   \
+  switch (dtype) {                                                                                                   \
+    case VIL_DTYPE_F32: KERNEL<float, float><<<dim3(grid), dim3(256), 0, s>>>(__VA_ARGS__(float)); break;            \
+    case VIL_DTYPE_F64: KERNEL<double, double><<<dim3(grid), dim3(256), 0, s>>>(__VA_ARGS__(double)); break;         \
+    case VIL_DTYPE_BF16: KERNEL<__bf16, float><<<dim3(grid), dim3(256), 0, s>>>(__VA_ARGS__(__bf16)); break;         \
+    default: KERNEL<_Float16, float><<<dim3(grid), dim3(256), 0, s>>>(__VA_ARGS__(_Float16)); break;                 \
+  }
 
 extern "C" int vil_sc2d_qk(const void* q, const void* k, void* attn, int BH, int M, int mx, int my, int W, int mode,
                            int dtype, void* stream) {
@@ -126,8 +138,8 @@ extern "C" int vil_sc2d_qk(const void* q, const void* k, void* attn, int BH, int
   p.n = (int64_t)BH * mx * my * p.W2 * p.kv;
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)((p.n + 255) / 256);
-  if (dtype == VIL_DTYPE_F32) k_sc2d_qk<float><<<dim3(grid), dim3(256), 0, s>>>(p, (const float*)q, (const float*)k, (float*)attn);
-  else k_sc2d_qk<double><<<dim3(grid), dim3(256), 0, s>>>(p, (const double*)q, (const double*)k, (double*)attn);
+#define QK_ARGS(T_) p, (const T_*)q, (const T_*)k, (T_*)attn
+  SC2D_DISPATCH(k_sc2d_qk, QK_ARGS)
   return (int)hipGetLastError();
 }
 
@@ -140,8 +152,8 @@ extern "C" int vil_sc2d_av(const void* attn, const void* v, void* out, int BH, i
   p.n = (int64_t)BH * M * mx * my * p.W2;
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)((p.n + 255) / 256);
-  if (dtype == VIL_DTYPE_F32) k_sc2d_av<float><<<dim3(grid), dim3(256), 0, s>>>(p, (const float*)attn, (const float*)v, (float*)out);
-  else k_sc2d_av<double><<<dim3(grid), dim3(256), 0, s>>>(p, (const double*)attn, (const double*)v, (double*)out);
+#define AV_ARGS(T_) p, (const T_*)attn, (const T_*)v, (T_*)out
+  SC2D_DISPATCH(k_sc2d_av, AV_ARGS)
   return (int)hipGetLastError();
 }
 
@@ -154,8 +166,8 @@ extern "C" int vil_sc2d_agrad(const void* attn, const void* grad, void* out, int
   p.n = (int64_t)BH * M * mx * my * p.W2;
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)((p.n + 255) / 256);
-  if (dtype == VIL_DTYPE_F32) k_sc2d_agrad<float><<<dim3(grid), dim3(256), 0, s>>>(p, (const float*)attn, (const float*)grad, (float*)out);
-  else k_sc2d_agrad<double><<<dim3(grid), dim3(256), 0, s>>>(p, (const double*)attn, (const double*)grad, (double*)out);
+#define AG_ARGS(T_) p, (const T_*)attn, (const T_*)grad, (T_*)out
+  SC2D_DISPATCH(k_sc2d_agrad, AG_ARGS)
   return (int)hipGetLastError();
 }
 
@@ -171,7 +183,11 @@ extern "C" int vil_sc2d_mask(void* attn, int BH, int mx, int my, int padx, int p
   p.n = (int64_t)BH * mx * my * p.W2 * p.kv;
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)((p.n + 255) / 256);
-  if (dtype == VIL_DTYPE_F32) k_sc2d_mask<float><<<dim3(grid), dim3(256), 0, s>>>(p, g, (float*)attn, count);
-  else k_sc2d_mask<double><<<dim3(grid), dim3(256), 0, s>>>(p, g, (double*)attn, count);
+  switch (dtype) {
+    case VIL_DTYPE_F32: k_sc2d_mask<float><<<dim3(grid), dim3(256), 0, s>>>(p, g, (float*)attn, count); break;
+    case VIL_DTYPE_F64: k_sc2d_mask<double><<<dim3(grid), dim3(256), 0, s>>>(p, g, (double*)attn, count); break;
+    case VIL_DTYPE_BF16: k_sc2d_mask<__bf16><<<dim3(grid), dim3(256), 0, s>>>(p, g, (__bf16*)attn, count); break;
+    default: k_sc2d_mask<_Float16><<<dim3(grid), dim3(256), 0, s>>>(p, g, (_Float16*)attn, count); break;
+  }
   return (int)hipGetLastError();
 }

@@ -118,10 +118,10 @@ class Long2DSCSelfAttention(nn.Module):
         Nloc = nx * ny
         assert G + Nloc == N, "Global dimension does not match!"
         if self.training and self.attn_drop.p > 0.0:
-            # the reference drops attention probabilities of local AND global rows (longformer2d.py:186,224); the
-            # fused kernels never materialise them.  Every published config has ATTN_DROP = 0: refuse loudly
-            # instead of silently training with different semantics.
-            raise NotImplementedError("attn_drop > 0 in training is not supported by the fused attention kernels")
+            # the reference drops attention PROBABILITIES of local and global rows (longformer2d.py:186,224); the fused
+            # kernels never materialise them.  No published config sets ATTN_DROP > 0: that case runs the reference's
+            # own algorithm on the operator-level HIP kernels (scores materialised, as there)
+            return self._forward_materialised(x, nx, ny)
         mode = self._resolve_mode()
         rs_dev = self.mode_dev is not None and self.mode > 0 and self.training
         table = self.local_relative_position_bias_table if self.rpe else None
@@ -181,6 +181,77 @@ class Long2DSCSelfAttention(nn.Module):
             a0 = torch.softmax(a0.float(), dim=-1).to(kvh.dtype)
             x0 = torch.einsum('bhgn,bnhm->bghm', a0, kvh[:, :, 1]).reshape(B, G, C)
         x0 = self.proj_global(x0)
+        return self.proj_drop(torch.cat((x0, x1.to(x0.dtype)), dim=1))
+
+    def _forward_materialised(self, x, nx, ny):
+        """attn_drop > 0 in training: sliding-chunk scores are materialised by the operator-level HIP kernels
+        (slidingchunk_2d.slidingchunk_2d / mask_invalid_locations, the reference's SlidingChunk2D surface), the softmax
+        and the dropout of the probabilities are tensor ops -- the semantics of longformer2d.py:134-229 with dropout."""
+        from .slidingchunk_2d import slidingchunk_2d, mask_invalid_locations
+        import torch.nn.functional as F
+        B, N, C = x.shape
+        G, H, M, W = self.Nglo, self.num_heads, self.head_dim, self.attention_window
+        Nloc, W2 = nx * ny, W * W
+        mode = self._resolve_mode()
+        q = (self.scale * self.query(x[:, G:])).float().view(B, Nloc, H, M)
+        kv = self.kv(x).float().view(B, N, 2, H, M)
+        k, v = kv[:, :, 0], kv[:, :, 1]                                   # (B, N, H, M)
+        kg, vg = k[:, :G].permute(0, 2, 1, 3), v[:, :G].permute(0, 2, 1, 3)      # (B, H, G, M)
+        if self.only_glo:
+            s1 = torch.einsum("bnhm,bhgm->bhng", q, kg)
+            if self.rpe:
+                s1 = s1 + self.g2l_relative_position_bias[1][None, :, None, :]
+            p1 = self.attn_drop(torch.softmax(s1, dim=-1))
+            x1 = torch.einsum("bhng,bhgm->bnhm", p1, vg).reshape(B, Nloc, C)
+        else:
+            padx, pady = (W - nx % W) % W, (W - ny % W) % W
+            mx, my = (nx + padx) // W, (ny + pady) // W
+
+            def chunked(t):                                              # (B, Nloc, H, M) -> (B*H, M, mx, my, W^2)
+                t = t.view(B, nx, ny, H, M).permute(0, 3, 4, 1, 2)
+                t = F.pad(t, (0, pady, 0, padx))
+                return t.reshape(B * H, M, mx, W, my, W).permute(0, 1, 2, 4, 3, 5).reshape(B * H, M, mx, my, W2).contiguous()
+
+            qi, ki, vi = chunked(q), chunked(k[:, G:]), chunked(v[:, G:])
+            s11 = slidingchunk_2d(qi, ki, False, mode)                   # (BH, mx, my, W^2, kv)
+            kvn = s11.shape[-1]
+            if self.rpe:
+                if mode == 0:
+                    idx = self.relative_position_index
+                elif mode == -1:
+                    idx = self.relative_position_index[:, 4 * W2:5 * W2]
+                else:
+                    cid = mode if mode > 4 else mode - 1
+                    idx = torch.cat([self.relative_position_index[:, 4 * W2:5 * W2],
+                                     self.relative_position_index[:, cid * W2:(cid + 1) * W2]], dim=-1)
+                bias = self.local_relative_position_bias_table[idx.reshape(-1)].view(W2, kvn, H).permute(2, 0, 1)
+                s11 = (s11.view(B, H, mx, my, W2, kvn) + bias[None, :, None, None]).view(B * H, mx, my, W2, kvn)
+            mask_invalid_locations(s11, mx, my, padx, pady, W, self.exact, mode)
+            if G >= 1:
+                s10 = torch.einsum("bcmnl,bgc->bmnlg", qi, kg.reshape(B * H, G, M))
+                if self.rpe:
+                    s10 = s10 + self.g2l_relative_position_bias[1].repeat(B, 1)[:, None, None, None, :]
+                s1 = torch.cat((s10, s11), dim=-1)
+            else:
+                s1 = s11
+            p1 = self.attn_drop(torch.softmax(s1, dim=-1))
+            x1 = slidingchunk_2d(p1[..., G:].contiguous(), vi, True, mode)          # (BH, M, mx, my, W^2)
+            if G >= 1:
+                x1 = x1 + torch.einsum("bmnlg,bgc->bcmnl", p1[..., :G], vg.reshape(B * H, G, M))
+            x1 = x1.view(B, H, M, mx, my, W, W).permute(0, 3, 5, 4, 6, 1, 2).reshape(B, mx * W, my * W, C)
+            x1 = x1[:, :nx, :ny].reshape(B, Nloc, C)
+        x1 = self.proj(x1.to(x.dtype))
+        if G == 0:
+            return self.proj_drop(x1)
+        qg = (self.scale * self.query_global(x[:, :G])).float().view(B, G, H, M)
+        kvg = self.kv_global(x).float().view(B, N, 2, H, M)
+        s0 = torch.einsum("bghm,bnhm->bhgn", qg, kvg[:, :, 0])
+        if self.rpe:
+            s0 = s0 + torch.cat([self.g2g_relative_position_bias,
+                                 self.g2l_relative_position_bias[0].unsqueeze(-1).expand(-1, -1, Nloc)], dim=-1)[None]
+        p0 = self.attn_drop(torch.softmax(s0, dim=-1))
+        x0 = torch.einsum("bhgn,bnhm->bghm", p0, kvg[:, :, 1]).reshape(B, G, C)
+        x0 = self.proj_global(x0.to(x.dtype))
         return self.proj_drop(torch.cat((x0, x1.to(x0.dtype)), dim=1))
 
     @staticmethod

@@ -10,8 +10,9 @@ against the HIP path.  This surface MATERIALISES the (BH, mx, my, W^2, kv) score
 for parity / compatibility.  The hot path of the product is ``ops.vil_full_attention`` (fused, no score tensor).
 
 Layouts: images (BH, M, mx, my, W^2); scores (BH, mx, my, W^2, kv) with kv = 9 W^2 (mode 0), W^2 (mode -1) or
-2 W^2 (mode 1..8: [own chunk | that neighbour], slidingchunk_2d.py:15-24).  float32 / float64 run natively; half
-precisions are computed in float32 and cast back (the reference's @autocast does the opposite: fp16 einsums)."""
+2 W^2 (mode 1..8: [own chunk | that neighbour], slidingchunk_2d.py:15-24).  float64, float32, bfloat16 and float16
+tensors run natively (16-bit I/O with fp32 accumulation: what the reference's @autocast einsums do on GPU,
+slidingchunk_2d.py:203,235)."""
 import ctypes
 import math
 
@@ -19,7 +20,8 @@ import torch
 
 from . import _lib
 
-_DT = {torch.float32: _lib.DTYPE_F32, torch.float64: _lib.DTYPE_F64}
+_DT = {torch.float32: _lib.DTYPE_F32, torch.float64: _lib.DTYPE_F64, torch.bfloat16: _lib.DTYPE_BF16,
+       torch.float16: _lib.DTYPE_F16}
 
 
 def _stream(t):
