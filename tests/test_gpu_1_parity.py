@@ -319,15 +319,21 @@ def test_module_attn_drop_path_vs_golden(c, dev, golden_dir):
         out.backward(dout.float().to(dev))
         torch.cuda.synchronize()
         pre = c["name"] + "/"
-        torch.testing.assert_close(out.detach().double().cpu(), torch.from_numpy(gold[pre + "out"]), atol=1e-4, rtol=1e-4)
-        torch.testing.assert_close(xd.grad.double().cpu(), torch.from_numpy(gold[pre + "dx"]), atol=3e-4, rtol=1e-3)
-        n_checked = 0
-        for n, p_ in mod.named_parameters():
-            if p_.grad is not None and (pre + "d_" + n) in gold.files:
-                ref = torch.from_numpy(gold[pre + "d_" + n])
-                torch.testing.assert_close(p_.grad.double().cpu(), ref, atol=2e-3 * max(1.0, float(ref.abs().max())), rtol=2e-3,
-                                           msg=lambda m: f"{pre}d_{n}: {m}")
-                n_checked += 1
+
+        def check(nm, t, atol, rtol):
+            t = t.detach().double().cpu()
+            if pre + nm in gold.files:
+                ref = torch.from_numpy(gold[pre + nm])
+            elif pre + nm + "@sample" in gold.files:
+                t, ref = GC.sample_big(t)[0], torch.from_numpy(gold[pre + nm + "@sample"])
+            else:
+                return 0
+            torch.testing.assert_close(t, ref, atol=atol * max(1.0, float(ref.abs().max())), rtol=rtol,
+                                       msg=lambda m: f"{pre}{nm}: {m}")
+            return 1
+
+        assert check("out", out, 1e-4, 1e-4) and check("dx", xd.grad, 3e-4, 1e-3)
+        n_checked = sum(check("d_" + n, p_.grad, 2e-3, 2e-3) for n, p_ in mod.named_parameters() if p_.grad is not None)
         assert n_checked >= 4
         mod.attn_drop.p = 0.5
         torch.manual_seed(1)
@@ -647,8 +653,9 @@ def test_operator_level_16bit_io(dtype, dev, golden_dir):
         (out.float() * gout.float().to(dev)).sum().backward()
         torch.cuda.synchronize()
         pre = f"{name}_m{mode}_"
-        for nm, t, atol, rtol in (("attn", attn, 2e-2, 1e-1), ("out", out, 2e-2, 1e-1), ("dq", qq.grad, 5e-2, 2e-1),
-                                  ("dk", kk.grad, 5e-2, 2e-1), ("dv", vv.grad, 5e-2, 2e-1)):
+        k8 = 1 if dtype == torch.float16 else 4          # bf16 carries 3 mantissa bits less than the fp16 the reference bounds are for
+        for nm, t, atol, rtol in (("attn", attn, 2e-2 * k8, 1e-1), ("out", out, 2e-2 * k8, 1e-1), ("dq", qq.grad, 5e-2 * k8, 2e-1),
+                                  ("dk", kk.grad, 5e-2 * k8, 2e-1), ("dv", vv.grad, 5e-2 * k8, 2e-1)):
             ref = torch.from_numpy(gold[pre + nm]).double()
             torch.testing.assert_close(t.detach().double().cpu(), ref, rtol=rtol, atol=atol, msg=lambda m_: f"{pre}{nm}: {m_}")
 
