@@ -20,7 +20,7 @@ Extra objects on the same line:
                 tagged with its problem shape); achieved = ALGORITHMIC bytes of the launch /
                 its average duration.  `traffic` = PMC HBM bytes per launch of
                 that kernel at that shape, collected inside the real step (tools/pmc_step.sh ->
-                profiles/r02_pmc_traffic.json) and attached ONLY when the kernel sources'
+                profiles/r03_pmc_traffic.json) and attached ONLY when the kernel sources'
                 fingerprint matches the build that is running.
   roofline_by_shape   the same for fwd / dQ / dK+dV / delta at every hot-path shape of the
                 workload, plus `backward_unit`: SURVEY 8(d)'s whole-backward definition
@@ -224,7 +224,7 @@ def pmc_traffic(config, B, kernel, label):
     tools/pmc_step.sh; only for the build whose kernel sources it was collected on."""
     from vision_longformer_amd import _lib
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
         if pm.get("source_fingerprint") != _lib.source_fingerprint():
             return None
         e = pm["configs"][config]

@@ -64,6 +64,37 @@ def test_mfma_bf16_vs_oracle(c, dev):
     compare("mfma/bf16 " + cid(c), got, ref, BF16_TOL)
 
 
+F32_MFMA_CASES = [c for c in SMALL if c["M"] in (16, 32, 48, 64)] + [
+    case(12, 64, 8, 24, 24, 0, rpe=False), case(3, 32, 7, 28, 28, 1, B=3), case(2, 64, 12, 30, 25, 2, B=1), case(1, 16, 5, 11, 13, 3),
+]
+
+
+@pytest.mark.parametrize("c", F32_MFMA_CASES, ids=cid)
+def test_f32_matrix_core_family_vs_oracle(c, dev):
+    """fp32 I/O on v_mfma_f32_16x16x4_f32 (exact fp32 products): forward for every case (bias table, masks, modes, cyclic
+    padding, global keys); backward on the matrix cores where no bias-table gradient is requested, and -- in AUTO mode
+    with a bias table -- the VALU family's backward on the matrix-core forward's output / lse.  fp32 tolerances."""
+    from vision_longformer_amd import _lib
+    q, kv, table, g2l, dout = make_inputs(c, torch.float32)
+    ref = run_oracle(c, q, kv, table, g2l, dout)
+    # (1) forced matrix-core family, no bias parameters: forward + backward
+    c0 = dict(c, rpe=False)
+    ref0 = run_oracle(c0, q, kv, None, None, dout)
+    _lib.profile_begin(64)
+    got0 = run_hip(c0, q, kv, None, None, dout, torch.float32, "mfma", dev)
+    names = [r[0] for r in _lib.profile_end(64)]
+    assert "k_mfma_fwd" in names and "k_mfma_bwd_dq" in names and "k_mfma_bwd_dkdv" in names, names
+    compare("f32 matrix-core fwd+bwd (no bias) " + cid(c0), got0, ref0, F32_TOL)
+    # (2) AUTO with the case's bias parameters: matrix-core forward, backward wherever the library routes it
+    _lib.profile_begin(64)
+    got = run_hip(c, q, kv, table, g2l, dout, torch.float32, "auto", dev)
+    names = [r[0] for r in _lib.profile_end(64)]
+    assert "k_mfma_fwd" in names, names
+    if c["rpe"]:
+        assert "k_scalar_bwd_dq" in names, names            # bias-table gradients: the VALU family
+    compare("f32 matrix-core forward, auto backward " + cid(c), got, ref, F32_TOL)
+
+
 def test_fp16_backward_propagates_non_finite_gradients(dev):
     """fp16 training (the reference's AMP: autocast + GradScaler, src/engine.py:84, run_experiment.py:206) relies on the
     inf / NaN of an overflowed scaled gradient reaching the parameter gradients, so that the scaler skips the step.

@@ -1,4 +1,4 @@
-"""Builds the PMC traffic file bench.py attaches to its roofline objects (profiles/r02_pmc_traffic.json) from the
+"""Builds the PMC traffic file bench.py attaches to its roofline objects (profiles/r03_pmc_traffic.json) from the
 rocprofv3 --pmc passes of tools/pmc_step.sh.  Dispatches are matched to problem shapes by launch order: every eager
 step launches the library kernels in the same order, which bench.py dumped (VIL_BENCH_DUMP_TAGS) together with each
 launch's algorithmic bytes.  FETCH_SIZE (KB) is doubled (gfx950: the counter reports half of a wide coalesced stream --

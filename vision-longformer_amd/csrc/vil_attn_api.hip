@@ -100,7 +100,10 @@ extern "C" int vil_attn_bwd(const VilAttnDesc* d, const void* q, const void* k, 
   if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv) return VIL_E_NULL;
   if (bias_table && !dbias_table) return VIL_E_NULL;
   if (g2l && d->G > 0 && !dg2l) return VIL_E_NULL;
-  const int be = pick_backend(d, 1);
+  int be = pick_backend(d, 1);
+  // fp32: the matrix-core family has no bias-gradient histogram; gradients of the bias table / g2l run on the VALU family
+  if (be == VIL_BACKEND_MFMA && d->dtype == VIL_DTYPE_F32 && (dbias_table || (dg2l && d->G > 0)))
+    be = (d->backend == VIL_BACKEND_AUTO && vil_scalar_supported(d) == VIL_OK) ? VIL_BACKEND_SCALAR : 0;
   if (!be) return d->backend == VIL_BACKEND_AUTO ? vil_scalar_supported(d) : VIL_E_BACKEND;
   if (!workspace && vil_attn_workspace_bytes(d, 1) > 0) return VIL_E_WORKSPACE;
   VilParams p; memset(&p, 0, sizeof(p));
@@ -126,7 +129,7 @@ extern "C" int vil_attn_bwd_full(const VilAttnDesc* d, const void* q_all, const 
   if (bias_table && !dbias_table) return VIL_E_NULL;
   if ((g2l && !dg2l) || (g2g && !dg2g)) return VIL_E_NULL;
   if (d->G < 1 || d->G > 4 || d->only_glo) return VIL_E_BACKEND;
-  if (d->backend == VIL_BACKEND_SCALAR || vil_mfma_supported(d, 1) != VIL_OK) return VIL_E_BACKEND;
+  if (d->backend == VIL_BACKEND_SCALAR || d->dtype == VIL_DTYPE_F32 || vil_mfma_supported(d, 1) != VIL_OK) return VIL_E_BACKEND;
   if (!workspace) return VIL_E_WORKSPACE;
   const int64_t es = 2;                                   // the MFMA family: bf16 or fp16
   VilParams p; memset(&p, 0, sizeof(p));

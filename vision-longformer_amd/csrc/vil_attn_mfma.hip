@@ -388,7 +388,15 @@ static size_t mfma_lds_bytes(const MfmaCfg& c) { return (size_t)c.tabsize * 4 + 
 int vil_mfma_bwd_supported(const VilAttnDesc* d);
 size_t vil_mfma_bwd_workspace(const VilAttnDesc* d);
 
+int vil_mfma_launch_prep(const VilParams& p, const MfmaCfg& c, int row_stride_b, hipStream_t s) {
+  const int ntx = (c.tabsize + 255) / 256, nch = p.g.mx * p.g.my;
+  if (int he = vil_ensure_dyn_lds((const void*)k_mfma_prep, (size_t)c.NSP * 8)) return he;
+  k_mfma_prep<<<dim3((unsigned)(ntx * p.H + nch)), dim3(256), (size_t)c.NSP * 8, s>>>(p, c, row_stride_b, ntx);
+  return (int)hipGetLastError();
+}
+
 int vil_mfma_supported(const VilAttnDesc* d, int pass) {
+  if (d->dtype == VIL_DTYPE_F32) return vil_f32_supported(d, pass);
   if (d->dtype != VIL_DTYPE_BF16 && d->dtype != VIL_DTYPE_F16) return VIL_E_DTYPE;
   if (d->M != 16 && d->M != 32 && d->M != 48 && d->M != 64) return VIL_E_HEAD_DIM;
   if (d->W < 1 || d->W > 32) return VIL_E_WINDOW;
@@ -408,6 +416,7 @@ int vil_mfma_supported(const VilAttnDesc* d, int pass) {
 }
 
 size_t vil_mfma_workspace(const VilAttnDesc* d, int pass) {
+  if (d->dtype == VIL_DTYPE_F32) return vil_f32_workspace(d, pass);
   if (pass != 0) return vil_mfma_bwd_workspace(d);
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
@@ -415,6 +424,7 @@ size_t vil_mfma_workspace(const VilAttnDesc* d, int pass) {
 }
 
 int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
+  if (d->dtype == VIL_DTYPE_F32) return vil_f32_fwd(d, p, s);
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   float* tabws = (float*)p.delta;          // workspace base
   c.tabws = tabws;

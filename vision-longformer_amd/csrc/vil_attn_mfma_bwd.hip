@@ -23,31 +23,6 @@
 
 #define LSE_PAD 1.0e30f
 
-#define VIL_NORM_SLOTS 64
-struct BwdCfg {
-  int nch;            // query/key chunks per (image, head) = mx*my
-  int nsplit;         // global-key owner units per (image, head)
-  int glo_from_dq;    // G <= 4: dK/dV of the global keys are a by-product of the dQ pass (one owner unit, streaming nothing)
-  int glo_nrec;       // partial records per (image, head) in glo_parts: dq units + 1, or nsplit
-  int units_kv_bh;    // nch*NWP + (G ? nsplit : 0)
-  int kv_wg_per_bh, kv_gpw, kv_wpw;
-  int dq_QT, dq_HQ, dq_NWP, dq_units_bh, dq_wg_per_bh, dq_gpw, dq_wpw;   // dQ pass: query tiles per wave, ...
-  int kv_KT, kv_HQ, kv_NWP;   // dK/dV pass: key tiles per wave, key quads (pairs) per chunk row, waves per chunk
-  int nqs;            // streamed query slots per owner unit (padded to 32)
-  int kv_wave_lds, dq_wave_lds;
-  int do_hist;
-  float* hist_parts;  // (dq workgroups, tabsize) int32
-  float* glo_parts;   // (B*H, glo_nrec, G, 2, M)
-  float* gq_parts;    // (B*H, nch*NWP + 1, G, M + 4): per-unit partial dq of the global QUERY rows, [M] = sum of dS
-  int dq_nwg;
-  int hist_nmax;      // upper bound of contributions one histogram bin can receive in one workgroup
-  unsigned* norm2;    // VIL_NORM_SLOTS x 32 words; slot k: [0] max ||dO_q||^2, [1] max ||v_k||^2 as float bits
-                      // (partial maxima written by k_mfma_delta); word 2 of slot 0: the histogram scale lfx
-  unsigned m_dq_wgbh, m_dq_NWP, m_dq_HQ, m_kv_wgbh, m_kv_NWP, m_kv_HQ;   // magic reciprocals (vil_magic, fdiv)
-  int2* kv_slots;     // (nch + nsplit, nqs): streamed-query slot tables of the dK/dV pass (kv_slots_block)
-  int* kv_nchunks;    // (nch + nsplit)
-};
-
 // ===================================================================== dQ pass
 // QT = query tiles (of 16 columns) per wave: 4 (64 query slots) for M <= 32, 2 for M >= 48 (two waves per
 // SIMD instead of one; same reasoning as KT of the dK/dV pass)
@@ -579,7 +554,6 @@ __device__ __forceinline__ void kv_slots_block(const VilParams& p, const MfmaCfg
 // tables (dQ pass), streamed-query slot tables (dK/dV pass), and the words that must be zero before the passes run.
 // (Kernels instead of hipMemsetAsync for the zeroing: memset nodes captured into a hipGraph were observed to run out of
 // order with their neighbouring kernel nodes on replay, tools/graph_op_check.py.)
-struct PrepZero { unsigned* ptr[5]; int n[5]; int total; };
 __global__ __launch_bounds__(256) void k_mfma_prep_bwd(VilParams p, MfmaCfg c, BwdCfg bc, int row_stride_b, int ntx, PrepZero zr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntab = ntx * p.H, nkv = bc.nch + bc.nsplit;
@@ -1214,6 +1188,15 @@ __global__ void k_mfma_delta(VilParams p, unsigned* norm2) {
 }
 
 // ===================================================================== host side
+// (the fp32 family, vil_attn_mfma_f32.hip, builds its tables with the same prologue kernel)
+int vil_mfma_launch_prep_bwd(const VilParams& p, const MfmaCfg& c, const BwdCfg& bc, int row_stride_b, const PrepZero& zr, hipStream_t s) {
+  const int ntx = (c.tabsize + 255) / 256, nzb = (zr.total + 255) / 256;
+  const size_t lds = (size_t)(c.NSP > bc.nqs ? c.NSP : bc.nqs) * 8;
+  if (int he = vil_ensure_dyn_lds((const void*)k_mfma_prep_bwd, lds)) return he;
+  k_mfma_prep_bwd<<<dim3((unsigned)(ntx * p.H + bc.nch + bc.nch + bc.nsplit + nzb)), dim3(256), lds, s>>>(p, c, bc, row_stride_b, ntx, zr);
+  return (int)hipGetLastError();
+}
+
 static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   memset(&bc, 0, sizeof(bc));
   VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
@@ -1315,6 +1298,7 @@ size_t vil_mfma_bwd_workspace(const VilAttnDesc* d) {
 }
 
 int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
+  if (d->dtype == VIL_DTYPE_F32) return vil_f32_bwd(d, p, s);
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   BwdCfg bc; bwd_cfg(d, c, bc);
   size_t off[9]; bwd_ws_layout(d, c, bc, off);

@@ -278,3 +278,40 @@ static inline size_t vil_key_slots_floats(const MfmaCfg& c, int nch) {
 // host: fills the launch configuration for a descriptor
 bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c);
 
+// ---- backward configuration (vil_attn_mfma_bwd.hip; the table / slot-table fields are shared with the fp32 family)
+#define VIL_NORM_SLOTS 64
+struct BwdCfg {
+  int nch;            // query/key chunks per (image, head) = mx*my
+  int nsplit;         // global-key owner units per (image, head)
+  int glo_from_dq;    // G <= 4: dK/dV of the global keys are a by-product of the dQ pass (one owner unit, streaming nothing)
+  int glo_nrec;       // partial records per (image, head) in glo_parts: dq units + 1, or nsplit
+  int units_kv_bh;    // nch*NWP + (G ? nsplit : 0)
+  int kv_wg_per_bh, kv_gpw, kv_wpw;
+  int dq_QT, dq_HQ, dq_NWP, dq_units_bh, dq_wg_per_bh, dq_gpw, dq_wpw;   // dQ pass: query tiles per wave, ...
+  int kv_KT, kv_HQ, kv_NWP;   // dK/dV pass: key tiles per wave, key quads (pairs) per chunk row, waves per chunk
+  int nqs;            // streamed query slots per owner unit (padded to 32)
+  int kv_wave_lds, dq_wave_lds;
+  int do_hist;
+  float* hist_parts;  // (dq workgroups, tabsize) int32
+  float* glo_parts;   // (B*H, glo_nrec, G, 2, M)
+  float* gq_parts;    // (B*H, nch*NWP + 1, G, M + 4): per-unit partial dq of the global QUERY rows, [M] = sum of dS
+  int dq_nwg;
+  int hist_nmax;      // upper bound of contributions one histogram bin can receive in one workgroup
+  unsigned* norm2;    // VIL_NORM_SLOTS x 32 words; slot k: [0] max ||dO_q||^2, [1] max ||v_k||^2 as float bits
+                      // (partial maxima written by k_mfma_delta); word 2 of slot 0: the histogram scale lfx
+  unsigned m_dq_wgbh, m_dq_NWP, m_dq_HQ, m_kv_wgbh, m_kv_NWP, m_kv_HQ;   // magic reciprocals (vil_magic, fdiv)
+  int2* kv_slots;     // (nch + nsplit, nqs): streamed-query slot tables of the dK/dV pass (kv_slots_block)
+  int* kv_nchunks;    // (nch + nsplit)
+};
+
+struct PrepZero { unsigned* ptr[5]; int n[5]; int total; };
+// prologue launches (bias-table images + slot tables + zero fill) as host functions callable from the other kernel files
+int vil_mfma_launch_prep(const VilParams& p, const MfmaCfg& c, int row_stride_b, hipStream_t s);
+int vil_mfma_launch_prep_bwd(const VilParams& p, const MfmaCfg& c, const BwdCfg& bc, int row_stride_b, const PrepZero& zr, hipStream_t s);
+// the fp32 matrix-core family (vil_attn_mfma_f32.hip: v_mfma_f32_16x16x4_f32)
+int vil_f32_supported(const VilAttnDesc* d, int pass);
+size_t vil_f32_workspace(const VilAttnDesc* d, int pass);
+int vil_f32_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s);
+int vil_f32_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s);
+
+
