@@ -5,7 +5,8 @@ B=2, H=12, M=64, W=8, seed 300, q/k/v ~ N(0,1), no bias, no global token, `conte
 
 Rows printed per n (GPU):
   fused bf16     the product path: ops.vil_local_attention, MFMA kernels, bf16 I/O (no score tensor exists)
-  fused fp32     the same op on the fp32 (scalar-family) kernels
+  fused fp32     the same op with fp32 I/O on the fp32 matrix-core family (v_mfma_f32_16x16x4_f32)
+  fused fp32 valu  ... on the one-query-per-lane VALU family (the fp32 path of rounds 1-2)
   operator fp32  the reference's own pipeline on the operator-level HIP surface (slidingchunk_2d ->
                  mask_invalid_locations -> softmax -> slidingchunk_2d), which materialises the score tensor like the
                  reference's `scwbackward` method does
@@ -41,6 +42,7 @@ def run(method, n, reps, B=2, H=12, M=64, W=8):
         value = torch.randn(B * H * N * M, device=dev).view(B, H, N, M).requires_grad_(True)
         if method.startswith("fused"):
             dt = torch.bfloat16 if method == "fused bf16" else torch.float32
+            be = {"fused bf16": "mfma", "fused fp32": "mfma", "fused fp32 valu": "scalar"}[method]
             # the product's layout: (B, N, H*M) token-major projections (the layout change is setup, not the op)
             q = query.detach().transpose(1, 2).reshape(B, N, H * M).to(dt).requires_grad_(True)
             kv = torch.cat([key.detach().transpose(1, 2).reshape(B, N, H * M),
@@ -49,7 +51,7 @@ def run(method, n, reps, B=2, H=12, M=64, W=8):
         t0 = time.time()
         if method.startswith("fused"):
             ctx = vil_local_attention(q, kv, None, None, nx=n, ny=n, w=W, nglo=0, num_heads=H, mode=0, exact=0, scale=1.0,
-                                      backend="mfma" if method == "fused bf16" else "scalar")
+                                      backend=be)
         else:
             q_img, k_img, v_img = (rearrange(t, "b h (x y) c -> (b h) c x y", x=n) for t in (query, key, value))
             pad = (W - n % W) % W
@@ -71,7 +73,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", type=int, nargs="*", default=[48, 96, 144, 192, 240, 288])
     ap.add_argument("--reps", type=int, default=30)
-    ap.add_argument("--methods", nargs="*", default=["fused bf16", "fused fp32", "operator fp32"])
+    ap.add_argument("--methods", nargs="*", default=["fused bf16", "fused fp32", "fused fp32 valu", "operator fp32"])
     a = ap.parse_args()
     torch.manual_seed(300)
     rows = []
