@@ -196,8 +196,9 @@ def per_shape_stats(recs):
                         "frac_hbm": round(by / n / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else 0.0,
                         "TFLOPs": round(fl / n / t / 1e12, 1) if t > 0 else 0.0,
                         "frac_mfma": round(fl / n / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if t > 0 else 0.0}
-        bw = [k for k in ("k_delta", "k_mfma_bwd_dq", "k_mfma_bwd_dkdv", "k_reduce_glo", "k_reduce_bias", "k_glo_bwd") if k in ks]
-        if "k_mfma_bwd_dkdv" in ks:
+        bw = [k for k in ("k_delta", "k_mfma_bwd_dq", "k_mfma_bwd_dkdv", "k_reduce_glo", "k_reduce_bias", "k_glo_bwd",
+                          "k_dense_bwd_dq", "k_dense_bwd_dkdv", "k_dense_reduce") if k in ks]
+        if "k_mfma_bwd_dkdv" in ks or "k_dense_bwd_dkdv" in ks:
             nloc, n_all, C = nx * ny, nx * ny + G, H * M
             unit_bytes = B * ((4 * nloc + 4 * n_all) * C * 2 + 4 * H * nloc)
             t = sum(ks[k]["avg_ms"] for k in bw) * 1e-3

@@ -150,6 +150,29 @@ int vil_attn_bwd_full(const VilAttnDesc* d, const void* q_all, const void* k, co
                       void* dq_all, void* dk, void* dv, float* dbias_table, float* dg2l, float* dg2g,
                       void* workspace, void* stream);
 
+/* ---- dense `Attention` of the s0 stages as its own kernel family (reference
+ * src/models/msvit.py:91-120): every one of the N = G + nx*ny tokens attends every token,
+ *   logit[i][j] = scale * q_i.k_j + bias[h][i][j],
+ *   bias = local_relative_position_bias_table[relative_position_index] (local i, local j; msvit.py:74-95),
+ *          g2l[1][h][j] (local i, global j), g2l[0][h][i] (global i, local j), g2g[h][i][j] (both global; :97-111).
+ * q / k / v / out / dout / dq / dk / dv point at TOKEN 0 of (B, N, H*M) views addressed with the descriptor's strides
+ * (three views of one packed qkv tensor in the product); the descriptor's W, mode, exact, bias_side are ignored.
+ * bias_table: float32 ((2nx-1)*(2ny-1), H) or NULL (rpe off); g2l (2,H,G), g2g (H,G,G) float32 or NULL.
+ * lse: (B,H,N+1) float32 -- N log-sum-exps, then max_k |v_k|^2 of the (image, head) (the backward's fixed-point scale).
+ * bf16 / fp16, M == 64, G <= 4.
+ * The backward overwrites dq / dk / dv and dbias_table / dg2l / dg2g (bit-reproducible: fixed-point histogram,
+ * fixed summation order); workspace >= vil_dense_attn_workspace_bytes(d, 1), 16-byte aligned. */
+int vil_dense_attn_supported(const VilAttnDesc* d);
+size_t vil_dense_attn_workspace_bytes(const VilAttnDesc* d, int pass);
+int vil_dense_attn_fwd(const VilAttnDesc* d, const void* q, const void* k, const void* v,
+                       const float* bias_table, const float* g2l, const float* g2g,
+                       void* out, float* lse, void* stream);
+int vil_dense_attn_bwd(const VilAttnDesc* d, const void* q, const void* k, const void* v,
+                       const void* out, const void* dout, const float* lse,
+                       const float* bias_table, const float* g2l, const float* g2g,
+                       void* dq, void* dk, void* dv, float* dbias_table, float* dg2l, float* dg2g,
+                       void* workspace, void* stream);
+
 /* ---- block glue: fused LayerNorm around the attention / MLP blocks
  * (`x + drop_path(attn(norm(x), nx, ny))`, reference src/models/msvit.py:313-316,336-340).
  * x: (rows, C) fp32 or bf16 with a row stride (elements); y is written in y_dtype (bf16 feeds the

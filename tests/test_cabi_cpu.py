@@ -285,3 +285,37 @@ def test_optimizer_entry_points_plan_and_validate_on_the_host():
     assert L.vil_optim_adamw_step(vp(4100), 5, 0.9, 0.999, 1e-6, 1, a16, None) == -8
     assert L.vil_optim_qhm_step(a16, 0, 0.9, 1.0, a16, None) == -2
     assert L.vil_optim_qhm_step(a16, 5, 1.5, 1.0, a16, None) == -2
+
+
+def test_dense_family_entry_points_validate_on_the_host():
+    """vil_dense_attn_* (csrc/vil_attn_dense.hip): descriptor checks, workspace size and NULL rejection run before any
+    launch, so they are testable without a GPU"""
+    L = _lib.lib()
+
+    def dd(**kw):
+        base = dict(B=4, H=6, M=64, nx=14, ny=14, W=14, G=1, mode=-1, dtype=_lib.DTYPE_BF16)
+        base.update(kw)
+        d = _desc(**base)
+        C = d.H * d.M
+        N = d.G + d.nx * d.ny
+        for pre in ("q", "k", "v", "do", "dq", "dk", "dv"):
+            setattr(d, pre + "_sb", N * 3 * C); setattr(d, pre + "_st", 3 * C); setattr(d, pre + "_sh", d.M)
+        d.o_sb, d.o_st, d.o_sh = N * C, C, d.M
+        return d
+
+    ok = dd()
+    assert L.vil_dense_attn_supported(ctypes.byref(ok)) == 0
+    assert L.vil_dense_attn_supported(ctypes.byref(dd(nx=24, ny=24))) == 0          # any sequence length
+    assert L.vil_dense_attn_supported(ctypes.byref(dd(nx=9, ny=17, G=4))) == 0       # rectangular grids, up to 4 global tokens
+    assert L.vil_dense_attn_supported(ctypes.byref(dd(M=32))) == _lib.VIL_E_HEAD_DIM if hasattr(_lib, "VIL_E_HEAD_DIM") else -3
+    assert L.vil_dense_attn_supported(ctypes.byref(dd(dtype=_lib.DTYPE_F32))) == -7
+    assert L.vil_dense_attn_supported(ctypes.byref(dd(G=5))) == _lib.VIL_E_BACKEND
+    assert L.vil_dense_attn_supported(ctypes.byref(dd(B=0))) == -2
+    assert L.vil_dense_attn_workspace_bytes(ctypes.byref(ok), 0) == 0
+    # backward: delta (B*H*N floats) + one histogram record per dQ workgroup
+    N, TS = 197, 27 * 27
+    nwg = 2                                     # 13 row units of 16 queries -> two workgroups of <= 8 waves
+    want = ((4 * 6 * N + 3) // 4 * 4) * 4 + 4 * 6 * nwg * (((TS + 1) // 2 * 2) + 32) * 4
+    assert L.vil_dense_attn_workspace_bytes(ctypes.byref(ok), 1) == want
+    assert L.vil_dense_attn_fwd(ctypes.byref(ok), None, None, None, None, None, None, None, None, None) == -1
+    assert L.vil_dense_attn_bwd(ctypes.byref(ok), *([None] * 17)) == -1

@@ -382,7 +382,8 @@ def test_module_attn_drop_path_vs_golden(c, dev, golden_dir):
 @pytest.mark.parametrize("amp", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("c", GC.DENSE_CASES, ids=lambda c: c["name"])
 def test_dense_attention_module_vs_golden(c, amp, dev, golden_dir):
-    """The package's dense `Attention` (the s0 stages; one-chunk case of the fused kernels) under bf16 and fp16 autocast
+    """The package's dense `Attention` (the s0 stages; csrc/vil_attn_dense.hip, or the one-chunk case of the fused kernels
+    when head_dim != 64) under bf16 and fp16 autocast
     against the REFERENCE module's fixtures (tools/gen_golden.py, src/models/msvit.py:37-120): output, dx and every
     parameter gradient element-wise."""
     from vision_longformer_amd.msvit import Attention
@@ -403,7 +404,9 @@ def test_dense_attention_module_vs_golden(c, amp, dev, golden_dir):
     out.backward(dout.to(dev, out.dtype))
     torch.cuda.synchronize()
     names = {r[0] for r in _lib.profile_end(64)}
-    assert any(n.startswith("k_mfma_fwd") for n in names) and any("dkdv" in n for n in names), names    # the HIP path ran
+    # the HIP path ran: the dense kernel family for head_dim 64, the one-chunk case of the sliding-chunk kernels otherwise
+    fam = "k_dense_fwd" if c["dim"] // c["H"] == 64 else "k_mfma_fwd"
+    assert any(n.startswith(fam) for n in names) and any("dkdv" in n for n in names), names
     pre = c["name"] + "/"
 
     def ref_of(nm, t):
@@ -520,6 +523,59 @@ def test_dense_attention_one_chunk_vs_reference(dev, nx, G, H, M, B, rpe):
             got[nm] = dl[i].grad.double().cpu(); want[nm] = leaves[i].grad
     tol = {k: BF16_TOL[k] for k in ("out", "dqkv", "dtable", "dg2l", "dg2g")}
     compare(f"dense one-chunk nx{nx} G{G} H{H} M{M}", got, want, tol)
+
+
+DENSE_FAMILY = [  # nx, ny, G, H, B, rpe, dtype
+    (14, 14, 1, 6, 2, True, torch.bfloat16), (7, 7, 0, 12, 2, True, torch.bfloat16), (12, 12, 0, 12, 1, True, torch.bfloat16),
+    (14, 14, 1, 6, 2, True, torch.float16), (5, 5, 2, 2, 3, True, torch.bfloat16), (9, 11, 4, 2, 2, True, torch.bfloat16),
+    (14, 14, 1, 3, 2, False, torch.bfloat16), (3, 2, 1, 1, 2, True, torch.float16), (16, 16, 3, 2, 1, True, torch.bfloat16),
+    (15, 17, 1, 2, 1, True, torch.float16), (1, 1, 1, 2, 2, True, torch.bfloat16), (14, 14, 0, 2, 5, True, torch.bfloat16),
+    (21, 19, 2, 2, 1, True, torch.float16), (24, 24, 1, 6, 1, True, torch.bfloat16), (32, 32, 1, 1, 1, True, torch.bfloat16),
+]
+
+
+def _dense_family_case(dev, nx, ny, G, H, B, rpe, dtype, seed=23):
+    from vision_longformer_amd.ops import vil_dense_attention
+    M = 64
+    g = torch.Generator().manual_seed(seed)
+    N, C = G + nx * ny, H * M
+    qkv = torch.randn(B, N, 3 * C, generator=g).to(dtype).float()
+    dout = torch.randn(B, N, C, generator=g).to(dtype).float()
+    table = torch.randn((2 * nx - 1) * (2 * ny - 1), H, generator=g) * 0.5 if rpe else None
+    g2l = torch.randn(2, H, G, generator=g) * 0.5 if (rpe and G) else None
+    g2g = torch.randn(H, G, G, generator=g) * 0.5 if (rpe and G) else None
+    scale = M ** -0.5
+    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (qkv, table, g2l, g2g)]
+    ref = O.dense_attention(leaves[0], leaves[1], leaves[2], leaves[3], nx, ny, G, H, scale)
+    (ref * dout.double()).sum().backward()
+    dl = [t.to(dev, dtype if i == 0 else torch.float32).requires_grad_(True) if t is not None else None
+          for i, t in enumerate((qkv, table, g2l, g2g))]
+    out = vil_dense_attention(dl[0], dl[1], dl[2], dl[3], nx=nx, ny=ny, nglo=G, num_heads=H, scale=scale, backend="dense")
+    out.backward(dout.to(dev, dtype))
+    torch.cuda.synchronize()
+    got = dict(out=out.detach().double().cpu(), dqkv=dl[0].grad.double().cpu())
+    want = dict(out=ref.detach(), dqkv=leaves[0].grad)
+    for nm, i in (("dtable", 1), ("dg2l", 2), ("dg2g", 3)):
+        if leaves[i] is not None:
+            got[nm] = dl[i].grad.double().cpu(); want[nm] = leaves[i].grad
+    return got, want, dl
+
+
+@pytest.mark.parametrize("nx,ny,G,H,B,rpe,dtype", DENSE_FAMILY)
+def test_dense_family_vs_oracle(dev, nx, ny, G, H, B, rpe, dtype):
+    """csrc/vil_attn_dense.hip (the s0 stages' own kernels: global tokens as ordinary rows / columns, delta and the
+    bias-gradient histogram inside the dQ pass) against the fp64 oracle of msvit.py:91-120, forward and every gradient"""
+    got, want, _ = _dense_family_case(dev, nx, ny, G, H, B, rpe, dtype)
+    tol = {k: LOW_TOL[k] for k in ("out", "dqkv", "dtable", "dg2l", "dg2g")}
+    compare(f"dense family {nx}x{ny} G{G} H{H} {dtype}", got, want, tol)
+
+
+def test_dense_family_bias_gradients_bit_reproducible(dev):
+    """fixed-point histogram + fixed-order reduce: two runs give identical bits for every output"""
+    a, _, _ = _dense_family_case(dev, 14, 14, 1, 6, 4, True, torch.bfloat16)
+    b, _, _ = _dense_family_case(dev, 14, 14, 1, 6, 4, True, torch.bfloat16)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize("nx,W,M,H", [(16, 4, 32, 2), (20, 7, 64, 3), (21, 6, 32, 2)])

@@ -17,7 +17,8 @@ from vision_longformer_amd import _lib  # noqa: E402
 
 SINK = {"k_mfma_prep": "k_mfma_table", "k_mfma_prep_bwd": "k_mfma_table", "k_mfma_fwd": "k_mfma_fwd", "k_mfma_delta": "k_delta", "k_mfma_bwd_dq": "k_mfma_bwd_dq",
         "k_mfma_bwd_dkdv": "k_mfma_bwd_dkdv", "k_mfma_post_bwd": "k_reduce_glo",
-        "k_glo_fwd": "k_glo_fwd", "k_glo_bwd": "k_glo_bwd", "k_wgrad": "k_wgrad", "k_wgrad_reduce": "k_wgrad_reduce"}
+        "k_glo_fwd": "k_glo_fwd", "k_glo_bwd": "k_glo_bwd", "k_dense_fwd": "k_dense_fwd", "k_dense_bwd_dq": "k_dense_bwd_dq",
+        "k_dense_bwd_dkdv": "k_dense_bwd_dkdv", "k_dense_reduce": "k_dense_reduce", "k_wgrad": "k_wgrad", "k_wgrad_reduce": "k_wgrad_reduce"}
 
 
 def base(name):

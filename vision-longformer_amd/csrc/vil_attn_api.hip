@@ -236,7 +236,8 @@ void vil_prof_end(hipStream_t s) {
 extern "C" const char* vil_attn_kernel_name(int kid) {
   static const char* names[VIL_K_COUNT] = {"k_mfma_table", "k_mfma_fwd", "k_scalar_fwd", "k_delta", "k_scalar_bwd_dq",
                                            "k_scalar_bwd_dkdv", "k_reduce_glo", "k_reduce_bias", "k_mfma_bwd_dq",
-                                           "k_mfma_bwd_dkdv", "k_glo_fwd", "k_glo_bwd", "k_wgrad", "k_wgrad_reduce"};
+                                           "k_mfma_bwd_dkdv", "k_glo_fwd", "k_glo_bwd", "k_wgrad", "k_wgrad_reduce",
+                                           "k_dense_fwd", "k_dense_bwd_dq", "k_dense_bwd_dkdv", "k_dense_reduce"};
   return (kid >= 0 && kid < VIL_K_COUNT) ? names[kid] : "?";
 }
 

@@ -68,7 +68,7 @@ __host__ __device__ __forceinline__ vil_bf16 vil_f2bf(float f) {
 // launch with hipEvents on the launch stream and records its algorithmic bytes/flops
 enum { VIL_K_TABLE = 0, VIL_K_MFMA_FWD, VIL_K_SCALAR_FWD, VIL_K_DELTA, VIL_K_SCALAR_DQ, VIL_K_SCALAR_DKDV,
        VIL_K_REDUCE_GLO, VIL_K_REDUCE_BIAS, VIL_K_MFMA_DQ, VIL_K_MFMA_DKDV, VIL_K_GLO_FWD, VIL_K_GLO_BWD,
-       VIL_K_WGRAD, VIL_K_WGRAD_REDUCE, VIL_K_COUNT };
+       VIL_K_WGRAD, VIL_K_WGRAD_REDUCE, VIL_K_DENSE_FWD, VIL_K_DENSE_DQ, VIL_K_DENSE_DKDV, VIL_K_DENSE_REDUCE, VIL_K_COUNT };
 void vil_prof_begin(int kid, hipStream_t s, double bytes, double flops);
 void vil_prof_end(hipStream_t s);
 // problem tag attached to the records that follow (attention: B,H,M,nx,ny,W,G,mode; wgrad: T,CO,CI): lets bench.py

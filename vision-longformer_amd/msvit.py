@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .longformer2d import Long2DSCSelfAttention, _trunc_normal_
-from .ops import vil_dense_attention, FULL_MAX_G
+from .ops import vil_dense_attention, dense_family_supported, FULL_MAX_G
 from .layernorm import (VilLayerNorm, res_layernorm, res_layernorm_ok, tokens_layernorm, tokens_layernorm_ok,
                         pass_layernorm, pass_layernorm_ok)
 from .linear import VilLinear, vil_linear, expand_rows
@@ -193,11 +193,13 @@ class Attention(nn.Module):
         M = C // H
         nglo = self.nglo if self.rpe else (N - nx * ny if nx is not None else -1)
         gx, gy = (self.wx, self.wy) if self.rpe else (nx, ny)
-        if (qkv.is_cuda and qkv.dtype in (torch.bfloat16, torch.float16) and gx is not None and gx == gy and gx <= 32
-                and 0 <= nglo <= FULL_MAX_G and nglo + gx * gy == N and M in (16, 32, 48, 64)
-                and (self.attn_drop.p == 0.0 or not self.training)):
-            # the dense attention of the s0 stages is the one-chunk case of the fused
-            # sliding-chunk kernels (bias table gathered in-kernel, no (H,N,N) bias tensor, no SDPA mask)
+        ok = (qkv.is_cuda and qkv.dtype in (torch.bfloat16, torch.float16) and gx is not None and 0 <= nglo
+              and nglo + gx * gy == N and (self.attn_drop.p == 0.0 or not self.training))
+        if ok and (dense_family_supported(qkv, gx, gy, nglo, H)
+                   or (gx == gy and gx <= 32 and nglo <= FULL_MAX_G and M in (16, 32, 48, 64))):
+            # the dense attention of the s0 stages on its own HIP kernels (csrc/vil_attn_dense.hip:
+            # head_dim 64, any grid) or, for the other head sizes, as the one-chunk case of the fused sliding-chunk kernels
+            # -- bias table gathered in-kernel, no (H,N,N) bias tensor, no SDPA mask
             out = vil_dense_attention(qkv, self.local_relative_position_bias_table if self.rpe else None,
                                       self.g2l_relative_position_bias if (self.rpe and nglo > 0) else None,
                                       self.g2g_relative_position_bias if (self.rpe and nglo > 0) else None,

@@ -62,12 +62,12 @@ def _make_desc(q, k, v, out, cfg, backend):
 _WS = {}
 
 
-def _workspace(d, pass_, device):
+def _workspace(d, pass_, device, query=None):
     """Scratch of one library call.  The library uses it only between the call's own launches, and launches on one
     stream are ordered, so ONE buffer per (device, stream) is reused by every call on that stream (grown on demand)
     instead of a torch.empty per call (host cost in the eager step).  During stream capture a fresh allocation is
     taken from the graph's private pool, as before."""
-    n = max(int(_lib.lib().vil_attn_workspace_bytes(ctypes.byref(d), pass_)), 4) // 4 + 1
+    n = max(int((query or _lib.lib().vil_attn_workspace_bytes)(ctypes.byref(d), pass_)), 4) // 4 + 1
     if torch.cuda.is_current_stream_capturing():
         return torch.empty(n, dtype=torch.float32, device=device)
     key = (device, torch.cuda.current_stream(device).cuda_stream)
@@ -410,17 +410,100 @@ def vil_full_attention_qkv(qkv, bias_table, g2l_bias, g2g_bias, *, nx, ny, w, ng
     return _VilQKVAttention.apply(qkv, bias_table, g2l_bias, g2g_bias, cfg, backend or DEFAULT_BACKEND)
 
 
+class _VilDenseAttention(torch.autograd.Function):
+    """The dense `Attention` of the s0 stages on its own kernel family (vil_dense_attn_fwd / _bwd, csrc/vil_attn_dense.hip):
+    packed (B, N, 3C) projection in, (B, N, C) out, the gradient back as ONE (B, N, 3C) tensor; the global tokens are
+    ordinary rows / columns of the same kernels.  1 forward launch, 3 backward launches."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, g2l, g2g, cfg):
+        _check_dev(qkv, "vil_dense_attention")
+        qkv = _last_contig(qkv)
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        H = cfg["H"]
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        tab, g2l_f, g2g_f = _f32c(table), _f32c(g2l), _f32c(g2g)
+        out = torch.empty(B, N, C, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(B, H, N + 1, dtype=torch.float32, device=qkv.device)     # [..., N]: max |v_k|^2 (see include/vil_attn.h)
+        d = _make_desc(q, k, v, out, cfg, "auto")
+        stream = ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
+        with torch.cuda.device(qkv.device):
+            _lib.check(_lib.lib().vil_dense_attn_fwd(ctypes.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(tab), _ptr(g2l_f),
+                                                     _ptr(g2g_f), _ptr(out), _ptr(lse), stream))
+        ctx.save_for_backward(qkv, out, lse, tab, g2l_f, g2g_f)
+        ctx.cfg = cfg
+        ctx.dts = tuple(t.dtype if t is not None else None for t in (table, g2l, g2g))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, tab, g2l_f, g2g_f = ctx.saved_tensors
+        cfg = ctx.cfg
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        M = C // cfg["H"]
+        L = _lib.lib()
+        dout = _last_contig(dout).to(qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
+        dtab = torch.empty_like(tab) if tab is not None else None
+        dg2l = torch.empty_like(g2l_f) if g2l_f is not None else None
+        dg2g = torch.empty_like(g2g_f) if g2g_f is not None else None
+        d = _make_desc(q, k, v, out, cfg, "auto")
+        d.do_sb, d.do_st, d.do_sh = _strides(dout, M)
+        d.dq_sb, d.dq_st, d.dq_sh = _strides(dq, M)
+        d.dk_sb, d.dk_st, d.dk_sh = _strides(dk, M)
+        d.dv_sb, d.dv_st, d.dv_sh = _strides(dv, M)
+        ws = _workspace(d, 1, qkv.device, L.vil_dense_attn_workspace_bytes)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
+        with torch.cuda.device(qkv.device):
+            _lib.check(L.vil_dense_attn_bwd(ctypes.byref(d), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse),
+                                            _ptr(tab), _ptr(g2l_f), _ptr(g2g_f), _ptr(dq), _ptr(dk), _ptr(dv),
+                                            _ptr(dtab), _ptr(dg2l), _ptr(dg2g), _ptr(ws), stream))
+        tdt, ldt, gdt = ctx.dts
+        return (dqkv, dtab.to(tdt) if dtab is not None else None, dg2l.to(ldt) if dg2l is not None else None,
+                dg2g.to(gdt) if dg2g is not None else None, None)
+
+
+def dense_family_supported(qkv, nx, ny, nglo, num_heads):
+    """True when the dedicated dense kernels (csrc/vil_attn_dense.hip) take this problem: bf16 / fp16, head_dim 64,
+    nglo <= 4, K and V of one (image, head) within the LDS."""
+    if not qkv.is_cuda or qkv.dtype not in (torch.bfloat16, torch.float16) or qkv.stride(-1) != 1:
+        return False
+    C = qkv.shape[-1] // 3
+    cfg = _cfg(C, nx, ny, max(int(nx), int(ny)), nglo, num_heads, -1, 0, None)
+    d = _make_desc(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], qkv[..., :C], cfg, "auto")
+    d.o_sb, d.o_st = qkv.shape[1] * C, C                 # the (B, N, C) output the call allocates
+    return _lib.lib().vil_dense_attn_supported(ctypes.byref(d)) == 0
+
+
 def vil_dense_attention(qkv, bias_table, g2l_bias, g2g_bias, *, nx, ny, nglo, num_heads, scale=None, backend=None):
     """Dense attention over an (nglo + nx*ny)-token sequence with the Swin-style relative position bias
-    of the `s0` stages (reference msvit.py:37-120), expressed as the ONE-CHUNK case of the sliding-chunk
-    kernels: chunk side w = max(nx, ny), mode -1 (own chunk only), bias table side 2w-1.
-    qkv: (B, N, 3C) packed projection; bias_table ((2w-1)^2, H) or None.  Returns (B, N, C)."""
+    of the `s0` stages (reference msvit.py:37-120).  qkv: (B, N, 3C) packed projection; bias_table
+    ((2nx-1)*(2ny-1), H) or None.  Returns (B, N, C).
+
+    backend None / "auto" / "dense": the dedicated dense kernel family (csrc/vil_attn_dense.hip) when it takes the
+    problem (bf16 / fp16, head_dim 64, nglo <= 4, sequence within the LDS); otherwise -- and with backend "mfma" /
+    "scalar" -- the ONE-CHUNK case of the sliding-chunk kernels (chunk side w = max(nx, ny), mode -1, bias table side
+    2w-1; square grids)."""
+    backend = backend or DEFAULT_BACKEND
+    if nglo == 0:
+        g2l_bias = g2g_bias = None
+    if backend in ("auto", "dense"):
+        ok = (bias_table is None or bias_table.shape[0] == (2 * int(nx) - 1) * (2 * int(ny) - 1)) and \
+            dense_family_supported(qkv, nx, ny, nglo, num_heads)
+        if ok:
+            cfg = _cfg(qkv.shape[-1] // 3, nx, ny, max(int(nx), int(ny)), nglo, num_heads, -1, 0, scale)
+            return _VilDenseAttention.apply(qkv, bias_table, g2l_bias, g2g_bias, cfg)
+        if backend == "dense":
+            raise RuntimeError("vil_dense_attention: the dense kernel family does not take this problem")
+        backend = "auto"
     w = max(int(nx), int(ny))
     assert 0 <= nglo <= FULL_MAX_G
     side = 2 * w - 1 if bias_table is not None else 0
     if bias_table is not None:
         assert bias_table.shape[0] == side * side, "dense bias table must be ((2w-1)^2, H) with w = max(nx, ny)"
     cfg = _cfg(qkv.shape[-1] // 3, nx, ny, w, nglo, num_heads, -1, 0, scale, bias_side=side)
-    if nglo == 0:
-        g2l_bias = g2g_bias = None
-    return _VilQKVAttention.apply(qkv, bias_table, g2l_bias, g2g_bias, cfg, backend or DEFAULT_BACKEND)
+    return _VilQKVAttention.apply(qkv, bias_table, g2l_bias, g2g_bias, cfg, backend)
