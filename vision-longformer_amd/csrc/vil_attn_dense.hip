@@ -32,13 +32,32 @@
 #include <type_traits>
 
 #define DN_LSE_PAD 1.0e30f
+#define DN_GGL 80               // floats of the small bias block in LDS: [4 q + k] g2g[h][q][k] / scale, [64 + g] g2l[0][h][g] / scale
 #define DN_REC_EXTRA 32        // ints behind the TS bins of a record: [0] lfx, [2 + 2 g] int64 sum of global key g's region, [12 + 5 g] d g2l[0][g], [13 + 5 g + g'] d g2g[g][g']
-// workgroup shape: at most DN_MAXW waves, DN_OCC waves per SIMD (128 registers)
-#ifndef DN_MAXW
-#define DN_MAXW 8
+// workgroup shape per kernel (F forward, Q dQ, K dK/dV): at most MAXW waves, OCC waves per SIMD (4: 128 registers)
+#ifndef DN_MAXW_F
+#define DN_MAXW_F 8
 #endif
-#ifndef DN_OCC
-#define DN_OCC 4
+#ifndef DN_OCC_F
+#define DN_OCC_F 4
+#endif
+#ifndef DN_MAXW_Q
+#define DN_MAXW_Q 8
+#endif
+#ifndef DN_OCC_Q
+#define DN_OCC_Q 4
+#endif
+// dQ pass with two tiles per wave (151 registers, 3 waves per SIMD, workgroups of <= 4 waves): less LDS traffic and per-step
+// overhead per score; measured against the one-tile form (hipEvents, bf16): N 197: 51 vs 65 us, N 145: 22.7 vs 24.2,
+// N 50: 27.9 vs 22.3, N 577: 86 vs 82 -- taken for 96 < N <= 384 (dense_dq_tiles)
+#ifndef DN_MAXW_Q2
+#define DN_MAXW_Q2 4
+#endif
+#ifndef DN_MAXW_K
+#define DN_MAXW_K 8
+#endif
+#ifndef DN_OCC_K
+#define DN_OCC_K 4
 #endif
 struct DenseCfg {
   int N, NSP, G, nx, ny;
@@ -144,12 +163,13 @@ struct DnDma {
     if (ak_)                                                                                             \
       for (int s2 = tid; s2 < c.NSP; s2 += nthr) ak_[s2] = dn_akey(c, s2);                               \
     if (tid < 64) ggl[tid] = ((tid >> 2) < G && (tid & 3) < G) ? gg_ * inv_s : 0.f;                      \
+    if (tid < 4) ggl[64 + tid] = tid < G ? gl0 : 0.f;                                                    \
   }
 
 // ===================================================================== forward
 // lse: (B*H, N + 1) floats -- [N] = max_k |v_k|^2 of the (image, head), which the backward's histogram scale needs
 template <typename T, int QT>
-__global__ __launch_bounds__(64 * DN_MAXW, DN_OCC) void k_dense_fwd(VilParams p, DenseCfg c) {
+__global__ __launch_bounds__(64 * DN_MAXW_F, DN_OCC_F) void k_dense_fwd(VilParams p, DenseCfg c) {
   typedef typename V16<T>::x8 X8;
   typedef typename V16<T>::x4 X4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(64 * DN_MAXW, DN_OCC) void k_dense_fwd(VilParams p,
   float* tab = (float*)smem;
   int* akey = (int*)(tab + c.tabsize);
   float* ggl = (float*)(akey + c.NSP);
-  unsigned* misc = (unsigned*)(ggl + 64);
+  unsigned* misc = (unsigned*)(ggl + DN_GGL);
   char* Kl = (char*)(misc + 16);
   char* Vl = Kl + DN_RING;
   const unsigned tab_lds = lds_addr(smem);
@@ -379,7 +399,7 @@ __global__ __launch_bounds__(64 * DN_MAXW, DN_OCC) void k_dense_fwd(VilParams p,
 
 // ===================================================================== backward: dQ (+ delta, + bias gradients)
 template <typename T, int QT, bool HIST>
-__global__ __launch_bounds__(64 * DN_MAXW, DN_OCC) void k_dense_bwd_dq(VilParams p, DenseCfg c) {
+__global__ __launch_bounds__(QT == 1 ? 64 * DN_MAXW_Q : 64 * DN_MAXW_Q2, QT == 1 ? DN_OCC_Q : 3) void k_dense_bwd_dq(VilParams p, DenseCfg c) {
   typedef typename V16<T>::x8 X8;
   typedef typename V16<T>::x4 X4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(64 * DN_MAXW, DN_OCC) void k_dense_bwd_dq(VilParams
   int* hist = (int*)(tab + c.tabsize);
   int* akey = hist + c.tabsize;
   float* ggl = (float*)(akey + c.NSP);
-  unsigned* misc = (unsigned*)(ggl + 64);          // [0] max |dO_q|^2 over the workgroup's rows (float bits)
+  unsigned* misc = (unsigned*)(ggl + DN_GGL);          // [0] max |dO_q|^2 over the workgroup's rows (float bits)
   char* Kl = (char*)(misc + 16);
   char* Vl = Kl + DN_RING;
   const unsigned tab_lds = lds_addr(smem);
@@ -644,7 +664,7 @@ __global__ __launch_bounds__(64 * DN_MAXW, DN_OCC) void k_dense_bwd_dq(VilParams
 
 // ===================================================================== backward: dK, dV
 template <typename T, int KT>
-__global__ __launch_bounds__(64 * DN_MAXW, DN_OCC) void k_dense_bwd_dkdv(VilParams p, DenseCfg c) {
+__global__ __launch_bounds__(64 * DN_MAXW_K, DN_OCC_K) void k_dense_bwd_dkdv(VilParams p, DenseCfg c) {
   typedef typename V16<T>::x8 X8;
   typedef typename V16<T>::x4 X4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -657,7 +677,7 @@ __global__ __launch_bounds__(64 * DN_MAXW, DN_OCC) void k_dense_bwd_dkdv(VilPara
 
   float* tab = (float*)smem;
   float* ggl = tab + c.tabsize;
-  int* aqs = (int*)(ggl + 64);                    // [NSP] 4 * A(query slot)
+  int* aqs = (int*)(ggl + DN_GGL);                    // [NSP] 4 * A(query slot)
   float* lses = (float*)(aqs + c.NSP);            // [NSP] lse * log2e (padding: +big)
   float* dlts = lses + c.NSP;                     // [NSP] -delta
   char* Ql = (char*)(dlts + c.NSP);
@@ -705,13 +725,7 @@ __global__ __launch_bounds__(64 * DN_MAXW, DN_OCC) void k_dense_bwd_dkdv(VilPara
     dv_[u] = s < N ? -c.delta[(int64_t)bh * N + s] : 0.f;
   }
   DN_PROLOGUE_LOADS
-  float g0a = 0.f, g0b = 0.f, g0c = 0.f, g0d = 0.f;      // g2l[0][h][g]: bias of global query row g against the local keys
-  if (p.has_g2l) {
-    g0a = p.g2l0[h * G]; g0b = p.g2l0[h * G + min(1, G - 1)];
-    g0c = p.g2l0[h * G + min(2, G - 1)]; g0d = p.g2l0[h * G + min(3, G - 1)];
-  }
   DN_PROLOGUE_WRITES((int*)nullptr)
-  g0a *= inv_s; g0b *= inv_s; g0c *= inv_s; g0d *= inv_s;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int s = tid + u * nthr;
@@ -769,8 +783,7 @@ __global__ __launch_bounds__(64 * DN_MAXW, DN_OCC) void k_dense_bwd_dkdv(VilPara
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int t = ktok[kt];
-            const float g0r = r == 0 ? g0a : (r == 1 ? g0b : (r == 2 ? g0c : g0d));
-            const float v = t < G ? ggl[r * 4 + (t & 3)] : (t < N ? g0r : VIL_MASK_VAL);
+            const float v = t < G ? ggl[r * 4 + (t & 3)] : (t < N ? ggl[64 + r] : VIL_MASK_VAL);
             if (lg == 0 && r < G) sacc[kt][r] = v;
           }
       }
@@ -910,7 +923,7 @@ __global__ __launch_bounds__(1024) void k_dense_reduce(VilParams p, DenseCfg c, 
 }
 
 // ===================================================================== host side
-static bool dense_cfg(const VilAttnDesc* d, int rows_per_wave, DenseCfg& c, bool query_side = false) {
+static bool dense_cfg(const VilAttnDesc* d, int rows_per_wave, int maxw, DenseCfg& c, bool query_side = false) {
   memset(&c, 0, sizeof(c));
   c.nx = d->nx; c.ny = d->ny; c.G = d->G;
   c.N = d->G + d->nx * d->ny;
@@ -923,7 +936,7 @@ static bool dense_cfg(const VilAttnDesc* d, int rows_per_wave, DenseCfg& c, bool
   c.nunits = (c.N + rows_per_wave - 1) / rows_per_wave;
   if (query_side && d->G > 0 && rows_per_wave > 16)          // unit 0 = tokens 0..15 (k_dense_fwd / _bwd_dq: split0)
     c.nunits = 1 + (c.N > 16 ? (c.N - 16 + rows_per_wave - 1) / rows_per_wave : 0);
-  c.nwg_bh = (c.nunits + DN_MAXW - 1) / DN_MAXW;
+  c.nwg_bh = (c.nunits + maxw - 1) / maxw;
   c.wpw = (c.nunits + c.nwg_bh - 1) / c.nwg_bh;
   c.rec_base = (c.TS + 1) & ~1;
   c.m_ny = vil_magic((unsigned)d->ny);
@@ -931,16 +944,14 @@ static bool dense_cfg(const VilAttnDesc* d, int rows_per_wave, DenseCfg& c, bool
   return true;
 }
 static size_t dense_lds(const DenseCfg& c, int pass) {   // 0 forward, 1 dQ, 2 dK/dV: see the kernels' LDS maps
-  if (pass == 0) return (size_t)c.tabsize * 4 + (size_t)c.NSP * 4 + 256 + 64 + 2 * DN_RING;
-  if (pass == 1) return (size_t)c.tabsize * 8 + (size_t)c.NSP * 4 + 256 + 64 + 2 * DN_RING;
-  return (size_t)c.tabsize * 4 + 256 + 3 * (size_t)c.NSP * 4 + 2 * DN_RING;
+  if (pass == 0) return (size_t)c.tabsize * 4 + (size_t)c.NSP * 4 + DN_GGL * 4 + 64 + 2 * DN_RING;
+  if (pass == 1) return (size_t)c.tabsize * 8 + (size_t)c.NSP * 4 + DN_GGL * 4 + 64 + 2 * DN_RING;
+  return (size_t)c.tabsize * 4 + DN_GGL * 4 + 3 * (size_t)c.NSP * 4 + 2 * DN_RING;
 }
 #ifndef VIL_DENSE_QT
 #define VIL_DENSE_QT 2
 #endif
-#ifndef VIL_DENSE_DQT
-#define VIL_DENSE_DQT 1
-#endif
+static inline int dense_dq_tiles(int N) { return (N > 96 && N <= 384) ? 2 : 1; }
 #ifndef VIL_DENSE_KT
 #define VIL_DENSE_KT 1
 #endif
@@ -957,7 +968,7 @@ extern "C" int vil_dense_attn_supported(const VilAttnDesc* d) {
   const int64_t smax = d->q_st > d->k_st ? (d->q_st > d->v_st ? d->q_st : d->v_st) : (d->k_st > d->v_st ? d->k_st : d->v_st);
   if (smax * 2 * ntok >= (1ll << 31)) return VIL_E_BACKEND;
   DenseCfg c;
-  dense_cfg(d, 16, c);
+  dense_cfg(d, 16, 1, c);
   for (int pass = 0; pass < 3; ++pass)
     if (dense_lds(c, pass) > 160 * 1024) return VIL_E_BACKEND;
   if ((uint64_t)d->B * d->H * c.nwg_bh * (uint64_t)c.nwg_bh >= (1ull << 32)) return VIL_E_BACKEND;
@@ -967,7 +978,8 @@ extern "C" int vil_dense_attn_supported(const VilAttnDesc* d) {
 extern "C" size_t vil_dense_attn_workspace_bytes(const VilAttnDesc* d, int pass) {
   if (vil_dense_attn_supported(d) != VIL_OK || pass == 0) return 0;
   DenseCfg c;
-  dense_cfg(d, 16 * VIL_DENSE_DQT, c, true);
+  const int dqt = dense_dq_tiles(d->G + d->nx * d->ny);
+  dense_cfg(d, 16 * dqt, dqt == 1 ? DN_MAXW_Q : DN_MAXW_Q2, c, true);
   const size_t delta = (((size_t)d->B * d->H * c.N + 3) & ~(size_t)3) * 4;
   return delta + (size_t)d->B * d->H * c.nwg_bh * (c.rec_base + DN_REC_EXTRA) * 4;
 }
@@ -993,8 +1005,10 @@ static void dense_params(VilParams& p, const VilAttnDesc* d, const float* table,
     else DN_LAUNCH_T(KERNEL, __bf16, grid, wpw_, lds, s, __VA_ARGS__)                                     \
   }
 #define DN_K_FWD(T) k_dense_fwd<T, VIL_DENSE_QT>
-#define DN_K_DQ_H(T) k_dense_bwd_dq<T, VIL_DENSE_DQT, true>
-#define DN_K_DQ_N(T) k_dense_bwd_dq<T, VIL_DENSE_DQT, false>
+#define DN_K_DQ1_H(T) k_dense_bwd_dq<T, 1, true>
+#define DN_K_DQ1_N(T) k_dense_bwd_dq<T, 1, false>
+#define DN_K_DQ2_H(T) k_dense_bwd_dq<T, 2, true>
+#define DN_K_DQ2_N(T) k_dense_bwd_dq<T, 2, false>
 #define DN_K_DKDV(T) k_dense_bwd_dkdv<T, VIL_DENSE_KT>
 
 extern "C" int vil_dense_attn_fwd(const VilAttnDesc* d, const void* q, const void* k, const void* v,
@@ -1010,7 +1024,7 @@ extern "C" int vil_dense_attn_fwd(const VilAttnDesc* d, const void* q, const voi
   dense_params(p, d, bias_table, g2l, g2g);
   p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse;
   DenseCfg c;
-  dense_cfg(d, 16 * VIL_DENSE_QT, c, true);
+  dense_cfg(d, 16 * VIL_DENSE_QT, DN_MAXW_F, c, true);
   vil_prof_tag(d->B, d->H, d->M, d->nx, d->ny, d->nx > d->ny ? d->nx : d->ny, d->G, -1);
   const double n = c.N, ce = (double)d->H * d->M * 2;
   vil_prof_begin(VIL_K_DENSE_FWD, s, d->B * (4 * n * ce + 4.0 * d->H * n), d->B * 4.0 * n * n * d->H * d->M);
@@ -1047,16 +1061,23 @@ extern "C" int vil_dense_attn_bwd(const VilAttnDesc* d, const void* q, const voi
   p.dg2l0 = hg ? dg2l : nullptr;
   p.dg2g = (d->G > 0 && g2g) ? dg2g : nullptr;
   DenseCfg cq, ck;
-  dense_cfg(d, 16 * VIL_DENSE_DQT, cq, true);
-  dense_cfg(d, 16 * VIL_DENSE_KT, ck);
+  const int dqt = dense_dq_tiles(d->G + d->nx * d->ny);
+  dense_cfg(d, 16 * dqt, dqt == 1 ? DN_MAXW_Q : DN_MAXW_Q2, cq, true);
+  dense_cfg(d, 16 * VIL_DENSE_KT, DN_MAXW_K, ck);
   cq.delta = ck.delta = (float*)workspace;
   cq.parts = (int*)((char*)workspace + (((size_t)d->B * d->H * cq.N + 3) & ~(size_t)3) * 4);
   cq.do_hist = (p.dtable || p.dg2l || p.dg2g) ? 1 : 0;
   vil_prof_tag(d->B, d->H, d->M, d->nx, d->ny, d->nx > d->ny ? d->nx : d->ny, d->G, -1);
   const double n = cq.N, ce = (double)d->H * d->M * 2;
   vil_prof_begin(VIL_K_DENSE_DQ, s, d->B * (6 * n * ce + 8.0 * d->H * n), d->B * 6.0 * n * n * d->H * d->M);
-  if (cq.do_hist) DN_LAUNCH(DN_K_DQ_H, (unsigned)(d->B * d->H * cq.nwg_bh), cq.wpw, dense_lds(cq, 1), s, p, cq)
-  else DN_LAUNCH(DN_K_DQ_N, (unsigned)(d->B * d->H * cq.nwg_bh), cq.wpw, dense_lds(cq, 1), s, p, cq)
+  const unsigned gq = (unsigned)(d->B * d->H * cq.nwg_bh);
+  if (dqt == 1) {
+    if (cq.do_hist) DN_LAUNCH(DN_K_DQ1_H, gq, cq.wpw, dense_lds(cq, 1), s, p, cq)
+    else DN_LAUNCH(DN_K_DQ1_N, gq, cq.wpw, dense_lds(cq, 1), s, p, cq)
+  } else {
+    if (cq.do_hist) DN_LAUNCH(DN_K_DQ2_H, gq, cq.wpw, dense_lds(cq, 1), s, p, cq)
+    else DN_LAUNCH(DN_K_DQ2_N, gq, cq.wpw, dense_lds(cq, 1), s, p, cq)
+  }
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
   vil_prof_begin(VIL_K_DENSE_DKDV, s, d->B * (6 * n * ce + 8.0 * d->H * n), d->B * 8.0 * n * n * d->H * d->M);
