@@ -237,3 +237,65 @@ def test_library_gemm_selected_algorithm(dev, T, K, N):
     y = _gemm(0, wide.to(dev)[:, K:], w.to(dev), None)
     want = wide[rows, K:].double() @ w.double().t()
     assert (y[rows].float().cpu().double() - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
+
+
+# ---------------------------------------------------------------- MLP tail: fc2's input gradient with the GELU backward fused
+def _gelu_grad64(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+@pytest.mark.parametrize("T,K,N", [(25216, 384, 1536), (6400, 768, 3072), (4001, 96, 384), (130, 192, 768), (7, 32, 128),
+                                    (401536, 96, 384)])
+def test_fused_dgrad_dgelu_vs_fp64(dev, T, K, N):
+    """vil_gemm_dgelu_bf16: dh = (dy W) * gelu'(h), exact-erf GELU (reference msvit.py:17-34), against fp64 on sampled rows;
+    includes a K that is not a multiple of the 64-deep block, a ragged last row tile and the stage-1 token count"""
+    from vision_longformer_amd import linear
+    from vision_longformer_amd.linear import _dgrad_dgelu
+    linear._DGELU_FORCE = True                   # every shape the kernel accepts, not only the ones the product routes to it
+    g = torch.Generator().manual_seed(29)
+    dy = torch.randn(T, K, generator=g).bfloat16().to(dev)
+    w = (torch.randn(K, N, generator=g) * 0.05).bfloat16().to(dev)
+    h = (torch.randn(T, N, generator=g) * 1.5).bfloat16().to(dev)
+    dh = _dgrad_dgelu(dy, w, h)
+    assert dh is not None and dh.shape == (T, N) and dh.dtype == torch.bfloat16
+    rows = torch.cat([torch.arange(0, min(T, 200)), torch.arange(max(T - 200, 0), T), torch.randint(0, T, (200,), generator=g)]).unique()
+    want = (dy[rows].double() @ w.double()) * _gelu_grad64(h[rows].double())
+    got = dh[rows].double()
+    err = (got - want).abs().max().item()
+    assert err <= 1.2e-2 * max(1.0, want.abs().max().item()), err          # bf16 output rounding (2^-8 relative)
+    # strided dy (a column slice of a wider gradient) and strided h
+    wide = torch.randn(T, 2 * K, generator=g).bfloat16().to(dev)
+    hw = (torch.randn(T, N + 64, generator=g)).bfloat16().to(dev)
+    dh2 = _dgrad_dgelu(wide[:, K:], w, hw[:, :N])
+    want = (wide[rows][:, K:].double() @ w.double()) * _gelu_grad64(hw[rows][:, :N].double())
+    assert (dh2[rows].double() - want).abs().max().item() <= 1.2e-2 * max(1.0, want.abs().max().item())
+    linear._DGELU_FORCE = False
+
+
+@pytest.mark.parametrize("B,N,C", [(4, 197, 384), (2, 3137, 96), (3, 50, 768)])
+def test_mlp_block_fused_tail_matches_unfused(dev, B, N, C):
+    """msvit.Mlp (fc1 -> exact GELU -> fc2) through vil_gelu_linear against the same module evaluated with plain torch
+    ops in fp64: output, input gradient and every parameter gradient under bf16 autocast"""
+    from vision_longformer_amd.msvit import Mlp
+    torch.manual_seed(5)
+    m = Mlp(C, 4 * C).to(dev)
+    x = torch.randn(B, N, C, device=dev, requires_grad=True)
+    dout = torch.randn(B, N, C, device=dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(x)
+    y.float().backward(dout)
+    torch.cuda.synchronize()
+    m64 = Mlp(C, 4 * C).double().cpu()
+    m64.load_state_dict({k: v.double().cpu() for k, v in m.state_dict().items()})
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    y64 = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(x64, m64.fc1.weight, m64.fc1.bias)),
+                                     m64.fc2.weight, m64.fc2.bias)
+    y64.backward(dout.double().cpu())
+    def close(a, b, what):
+        a, b = a.detach().double().cpu(), b.detach()
+        e = (a - b).abs().max().item()
+        assert e <= 3e-2 * max(b.abs().max().item(), 1e-3) + 0.1 * rms(b), (what, e, b.abs().max().item())
+    close(y, y64, "y")
+    close(x.grad, x64.grad, "dx")
+    for (n, p), (_, p64) in zip(m.named_parameters(), m64.named_parameters()):
+        close(p.grad, p64.grad, n)

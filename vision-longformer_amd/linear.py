@@ -159,6 +159,94 @@ class _SplitKLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+# The fused kernel re-streams its operands per 128 x 128 tile through a two-slot ring: where the GEMM is HBM-bound (the
+# stage-1 MLPs, K = C = 96: 256 vs 373 us at ViL-Small's 401 536 tokens, 176 vs 240 us at Medium-Deep's) it beats
+# library GEMM + gelu_backward; at K = 192 / 384 it ties (158 vs 164, 94 vs 92 us) and at K = 768 it loses (81 vs 66):
+# tools/mlp_bench.py.  The product takes it where it wins.
+_DGELU_MAX_K = 128
+_DGELU_FORCE = False          # tools / tests: run the fused kernel at every shape it accepts
+
+
+def _dgrad_dgelu(dy2, weight, h2):
+    """(dy2 @ weight) * gelu'(h2) in one launch (vil_gemm_dgelu_bf16), or None outside the kernel's contract."""
+    T, K = dy2.shape
+    N = weight.shape[1]
+    if K > _DGELU_MAX_K and not _DGELU_FORCE:
+        return None
+    if not (dy2.is_cuda and dy2.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and h2.dtype == torch.bfloat16
+            and weight.is_contiguous() and weight.shape[0] == K and h2.shape == (T, N) and K % 32 == 0 and N % 128 == 0
+            and dy2.stride(1) == 1 and h2.stride(1) == 1 and dy2.stride(0) % 8 == 0 and h2.stride(0) % 4 == 0
+            and dy2.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and h2.data_ptr() % 8 == 0):
+        return None
+    import ctypes
+    from . import _lib
+    dh = torch.empty(T, N, dtype=torch.bfloat16, device=dy2.device)
+    vp = ctypes.c_void_p
+    rc = _lib.lib().vil_gemm_dgelu_bf16(vp(dy2.data_ptr()), vp(weight.data_ptr()), vp(h2.data_ptr()), vp(dh.data_ptr()), T, K, N,
+                                        dy2.stride(0), h2.stride(0), N, vp(torch.cuda.current_stream(dy2.device).cuda_stream))
+    if rc == _lib.VIL_E_BACKEND:
+        return None
+    _lib.check(rc)
+    return dh
+
+
+class _GeluLinearFn(torch.autograd.Function):
+    """y = gelu(h) W^T + b (the tail of the MLP block, reference msvit.py:29-33) with ONE launch for the input gradient:
+    dh = (dy W) * gelu'(h) -- fc2's dgrad GEMM with the exact-erf GELU backward in its epilogue -- instead of a library
+    GEMM + an elementwise kernel that re-reads h and the GEMM's output."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, h, weight, bias):
+        a = F.gelu(h)
+        ctx.save_for_backward(h, a, weight)
+        ctx.has_bias = bias is not None
+        a2 = a.reshape(-1, a.shape[-1])
+        y = _gemm(0, a2, weight, bias) if a.is_cuda else None
+        if y is None:
+            return F.linear(a, weight, bias)
+        return y.view(*a.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        h, a, weight = ctx.saved_tensors
+        co, ci = weight.shape
+        dy2 = dy.reshape(-1, co)
+        a2, h2 = a.reshape(-1, ci), h.reshape(-1, ci)
+        dh = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dh = _dgrad_dgelu(dy2, weight, h2)
+            if dh is None:
+                da = _gemm(1, dy2, weight, None)
+                da = da if da is not None else dy2 @ weight
+                dh = torch.ops.aten.gelu_backward(da, h2)
+            dh = dh.view(h.shape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            fused = _wgrad(dy2, a2, want_db)
+            if fused is not None:
+                return dh, fused[0].to(weight.dtype), (fused[1] if want_db else None)
+            dw = dy2.t() @ a2
+        if want_db:
+            db = _colsum(dy2)
+        return dh, dw, db
+
+
+def vil_gelu_linear(h, weight, bias):
+    """F.linear(F.gelu(h), weight, bias) (exact GELU) whose backward fuses the GELU derivative into the input-gradient
+    GEMM; same autocast semantics as vil_linear."""
+    if h.is_cuda and torch.is_grad_enabled():
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            h, w = h.to(dt), weight.to(dt)
+            b = bias.to(dt) if bias is not None else None
+            with torch.autocast("cuda", enabled=False):
+                return _GeluLinearFn.apply(h, w, b)
+        return _GeluLinearFn.apply(h, weight, bias)
+    return F.linear(F.gelu(h), weight, bias)
+
+
 def vil_linear(x, weight, bias):
     """F.linear with the library's weight / bias gradient on device tensors (any number of tokens: every bias
     gradient must stay off PyTorch's multi-block reductions, see _colsum)."""
