@@ -135,7 +135,6 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
     if (unit >= c.units_bh) break;
     const int ch = fdiv(unit, c.m_NWP), wp = unit - ch * c.NWP;
     const int cm = fdiv(ch, c.m_my), cn = ch - cm * g.my;
-    const int nslots = load_key_slots(c, ch, lane, s_koff, s_akey);
 
     // ---- query slots of this lane: column j of q-tile qt is query (x, y = 4*hq + qt)
     const int jj = wp * 16 + lj;
@@ -159,6 +158,9 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
         X8 z = {};
         qf[ks][qt] = d0 < M ? *(const X8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
       }
+    // (the Q fragments above are requested BEFORE the chunk's key-slot table is fetched: a unit's prologue used to be
+    //  table -> Q -> first K/V, three dependent round trips; the table's and Q's now overlap)
+    const int nslots = load_key_slots(c, ch, lane, s_koff, s_akey);
 
     f32x4 o[MD][4], lacc[4];
     float mrow[4];

@@ -137,7 +137,6 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
     if (unit < bc.dq_units_bh) {
       const int ch = fdiv(unit, bc.m_dq_NWP), wp = unit - ch * bc.dq_NWP;
       const int cm = fdiv(ch, c.m_my), cn = ch - cm * g.my;
-      const int nslots = load_key_slots(c, ch, lane, s_koff, s_akey);
       const int jj = wp * 16 + lj;
       const int qx = fdiv(jj, bc.m_dq_HQ), qhq = jj - qx * bc.dq_HQ;
       const unsigned aq0b = tab_lds + (min(qx, W - 1) * c.P + QT * qhq) * 4;
@@ -164,6 +163,8 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
           qf[ks][qt] = d0 < M ? *(const X8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
           dof[ks][qt] = d0 < M ? *(const X8*)(dob + (int64_t)qtok[qt] * p.do_st + d0) : z;
         }
+      // (requested after this wave's own rows, so that the table's round trip overlaps theirs: see k_mfma_fwd)
+      const int nslots = load_key_slots(c, ch, lane, s_koff, s_akey);
       if (bc.glo_from_dq) {
         // dK / dV of the G global keys as a by-product of this pass: the wave holds the Q / dO rows, lse and delta of its
         // queries; its share of dK_g = scale * sum_q dS[q,g] Q[q] and dV_g = sum_q P[q,g] dO[q] is ~250 VALU instructions
@@ -663,6 +664,42 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     const int ch = glo ? 0 : fdiv(unit, bc.m_kv_NWP), wp = glo ? 0 : unit - ch * bc.kv_NWP;
     const int km = fdiv(ch, c.m_my), kn = ch - km * g.my;
 
+    // ---- this lane's key slots: column j of key-tile kt is key (x, y = KT*hq + KT-1 - kt)
+    const int jj = wp * 16 + lj;
+    const int kx = fdiv(jj, bc.m_kv_HQ), khq = jj - kx * bc.kv_HQ;
+    const unsigned akl = (unsigned)(glo ? -(c.glo0 + min(lj, max(p.G - 1, 0)) * c.gsz) * 4
+                                        : (min(kx, W - 1) * c.P + KT * khq + KT - 1) * 4) - tab_lds;
+    int ktok[KT];
+    bool kreal[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      if (glo) {
+        kreal[kt] = kt == 0 && lj < p.G;
+        ktok[kt] = kreal[kt] ? lj : 0;
+      } else {
+        const int ky = KT * khq + KT - 1 - kt;
+        const int kr = km * W + kx, kc = kn * W + ky;
+        kreal[kt] = kx < W && ky < W && kr < g.nx && kc < g.ny;
+        ktok[kt] = p.G + (kreal[kt] ? kr * g.ny + kc : (km * W) * g.ny + kn * W);
+      }
+    }
+    // The K / V fragments of these slots: at head_dim 64 they are requested HERE, so that their round trip runs under
+    // the slot-table -> lse / delta gather chain below (28x28 stage: dK/dV -1.5 %, dQ -3 %, forward -2 % from the same
+    // reordering); at head_dim <= 32 that measured +1 % on this pass (four key tiles: 32 more registers live across the
+    // chain), so there they are requested behind it as before
+    X8 kfb[MK][KT], vfb[MK][KT];
+    auto load_own = [&]() {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < MK; ++ks) {
+          const int d0 = ks * 32 + lg * 8;
+          X8 z = {};
+          kfb[ks][kt] = d0 < M ? *(const X8*)(kb + (int64_t)ktok[kt] * p.k_st + d0) : z;
+          vfb[ks][kt] = d0 < M ? *(const X8*)(vb + (int64_t)ktok[kt] * p.v_st + d0) : z;
+        }
+    };
+    if constexpr (MD > 2) load_own();
     // ---- streamed query slot table: the (token, bias address) columns come from the prologue kernel (kv_slots_block: one table per key chunk /
     // global-key split, built once per call); this wave adds the lse / delta of ITS (image, head).  256 slots per
     // round: table loads, then all gathers, then the LDS stores -- nothing waits on a single round trip.
@@ -705,35 +742,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     }
     const int nsteps = (nchunks * W2 + 31) >> 5;
 
-    // ---- this lane's key slots: column j of key-tile kt is key (x, y = KT*hq + KT-1 - kt)
-    const int jj = wp * 16 + lj;
-    const int kx = fdiv(jj, bc.m_kv_HQ), khq = jj - kx * bc.kv_HQ;
-    const unsigned akl = (unsigned)(glo ? -(c.glo0 + min(lj, max(p.G - 1, 0)) * c.gsz) * 4
-                                        : (min(kx, W - 1) * c.P + KT * khq + KT - 1) * 4) - tab_lds;
-    int ktok[KT];
-    bool kreal[KT];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      if (glo) {
-        kreal[kt] = kt == 0 && lj < p.G;
-        ktok[kt] = kreal[kt] ? lj : 0;
-      } else {
-        const int ky = KT * khq + KT - 1 - kt;
-        const int kr = km * W + kx, kc = kn * W + ky;
-        kreal[kt] = kx < W && ky < W && kr < g.nx && kc < g.ny;
-        ktok[kt] = p.G + (kreal[kt] ? kr * g.ny + kc : (km * W) * g.ny + kn * W);
-      }
-    }
-    X8 kfb[MK][KT], vfb[MK][KT];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int ks = 0; ks < MK; ++ks) {
-        const int d0 = ks * 32 + lg * 8;
-        X8 z = {};
-        kfb[ks][kt] = d0 < M ? *(const X8*)(kb + (int64_t)ktok[kt] * p.k_st + d0) : z;
-        vfb[ks][kt] = d0 < M ? *(const X8*)(vb + (int64_t)ktok[kt] * p.v_st + d0) : z;
-      }
+    if constexpr (MD <= 2) load_own();
     f32x4 dk[MD][KT], dv[MD][KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
