@@ -79,6 +79,16 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_dgelu(DgParams p) {
 
   const int nkb = (p.K + 63) >> 6;
   issue(0, 0);
+  // the epilogue's h values: 16 eight-byte loads per lane, in flight during the whole K loop (the first version loaded
+  // them tile row by tile row in the epilogue: four dependent HBM round trips per workgroup)
+  const T_* hb = (const T_*)p.h;
+  X4 h4[4][4];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int t = min(t0 + wt * 64 + tt * 16 + lj, p.T - 1);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) h4[tt][nt] = *(const X4*)(hb + (int64_t)t * p.h_rs + n0 + wn * 64 + nt * 16 + lg * 4);
+  }
 
   int wtr[4], dnat[2][2];
 #pragma unroll
@@ -127,20 +137,17 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_dgelu(DgParams p) {
   }
 
   // ---- epilogue: dh = acc * gelu'(h); lane (j, g) of tile (nt, tt): row t = .. + 16 tt + j, columns n = .. + 16 nt + 4 g ..+3
-  const T_* hb = (const T_*)p.h;
+  // (h4 was requested before the K loop: the epilogue itself waits for nothing)
   T_* ob = (T_*)p.dh;
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt) {
     const int t = t0 + wt * 64 + tt * 16 + lj;
     if (t < p.T) {
-      X4 h4[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) h4[nt] = *(const X4*)(hb + (int64_t)t * p.h_rs + n0 + wn * 64 + nt * 16 + lg * 4);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         X4 o4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o4[r] = (T_)(acc[nt][tt][r] * gelu_grad((float)h4[nt][r]));
+        for (int r = 0; r < 4; ++r) o4[r] = (T_)(acc[nt][tt][r] * gelu_grad((float)h4[tt][nt][r]));
         *(X4*)(ob + (int64_t)t * p.dh_rs + n0 + wn * 64 + nt * 16 + lg * 4) = o4;
       }
     }

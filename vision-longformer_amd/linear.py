@@ -160,10 +160,10 @@ class _SplitKLinearFn(torch.autograd.Function):
 
 
 # The fused kernel re-streams its operands per 128 x 128 tile through a two-slot ring: where the GEMM is HBM-bound (the
-# stage-1 MLPs, K = C = 96: 256 vs 373 us at ViL-Small's 401 536 tokens, 176 vs 240 us at Medium-Deep's) it beats
-# library GEMM + gelu_backward; at K = 192 / 384 it ties (158 vs 164, 94 vs 92 us) and at K = 768 it loses (81 vs 66):
-# tools/mlp_bench.py.  The product takes it where it wins.
-_DGELU_MAX_K = 128
+# MLPs of stages 1-2) it beats library GEMM + gelu_backward -- K = C = 96: 237 vs 374 us at ViL-Small's 401 536 tokens,
+# 164 vs 245 us at Medium-Deep's; K = 192: 144 vs 168 us -- at K = 384 it ties (94 vs 95) and at K = 768 it loses
+# (78 vs 67): tools/mlp_bench.py.  The product takes it where it wins.
+_DGELU_MAX_K = 192
 _DGELU_FORCE = False          # tools / tests: run the fused kernel at every shape it accepts
 
 
