@@ -23,6 +23,10 @@ SHAPES = {  # H, M, W, nx, ny, G, mode, B
     "meddeep_s2_f12": (3, 64, 12, 48, 48, 1, 0, 32),
     "basedeep_s1_f6_rs": (3, 32, 6, 96, 96, 1, 3, 32),
     "basedeep_s2_f8_rs": (3, 64, 8, 48, 48, 1, 5, 32),
+    # the reference's operator benchmark protocol (tools/op_benchmark.py): B 2, H 12, M 64, W 8, no global tokens
+    "opbench_192": (12, 64, 8, 192, 192, 0, 0, 2),
+    "opbench_240": (12, 64, 8, 240, 240, 0, 0, 2),
+    "opbench_288": (12, 64, 8, 288, 288, 0, 0, 2),
     # dense s0 stages (one chunk = the whole grid, mode -1, (2W-1)^2 table): vil_dense_attention on fused qkv
     "small_s3_dense": (6, 64, 14, 14, 14, 1, -1, 128),
     "small_s4_dense": (12, 64, 7, 7, 7, 1, -1, 128),

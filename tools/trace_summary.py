@@ -12,7 +12,8 @@ def pretty(n):
     name = n[m.end():m.end() + int(m.group(1))]
     args = n[m.end() + int(m.group(1)):].split("Ev")[0].lstrip("I")
     args = args.replace("DF16b", "bf16,").replace("DF16_", "f16,")
-    args = re.sub(r"Li(\d+)E", r"\1,", args).rstrip("E,").rstrip(",")
+    args = re.sub(r"Li(\d+)E", r"\1,", args)
+    args = re.sub(r"Lb(\d)E", r"\1,", args).rstrip("E,").rstrip(",")
     return f"void {name}<{args}>"
 for r in rows:
     r["Kernel_Name"] = pretty(r["Kernel_Name"])
@@ -24,7 +25,10 @@ s0, s1 = idx[-1 - nsteps * per], idx[-1]
 t0, t1 = int(rows[s0]["Start_Timestamp"]), int(rows[s1]["Start_Timestamp"])
 def classify(n):
     if n.startswith("Cijk"): return "gemm(hipblaslt)"
-    if "k_mfma" in n or "k_delta" in n or "k_reduce" in n or "k_scalar" in n or "k_glo_" in n: return "vil hot path"
+    if "k_mfma" in n or "k_delta" in n or "k_reduce" in n or "k_scalar" in n or "k_glo_" in n or "k_dense_" in n: return "vil hot path"
+    if "k_wgrad" in n or "k_dgrad_dgelu" in n or "k_colsum" in n: return "vil weight-gradient / fused GEMM"
+    if "k_optim" in n: return "vil optimizer"
+    if "k_patchify" in n or "k_sc2d" in n: return "vil glue"
     if "k_ln_" in n: return "vil layernorm"
     if "layer_norm" in n or "cuCompute" in n: return "torch layernorm"
     if "attn_fwd" in n or "bwd_kernel" in n or "attn_bwd" in n: return "sdpa (dense attn)"
