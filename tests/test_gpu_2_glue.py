@@ -299,3 +299,32 @@ def test_mlp_block_fused_tail_matches_unfused(dev, B, N, C):
     close(x.grad, x64.grad, "dx")
     for (n, p), (_, p64) in zip(m.named_parameters(), m64.named_parameters()):
         close(p.grad, p64.grad, n)
+
+
+@pytest.mark.parametrize("T,K,N", [(401536, 96, 384), (100480, 192, 576), (100480, 192, 768), (50001, 96, 288), (4001, 96, 96),
+                                    (777, 192, 192), (130, 96, 200), (9, 192, 8)])
+def test_skinny_forward_gemm_vs_fp64(dev, T, K, N):
+    """vil_gemm_skinny_bf16 (weights in registers, LDS-DMA ring of activation tiles, csrc/vil_gemm_skinny.hip): the
+    forward of an nn.Linear with bias against fp64 on sampled rows; ragged last tile, N not a multiple of 96 / 32,
+    strided input rows"""
+    from vision_longformer_amd import linear
+    from vision_longformer_amd.linear import _gemm_skinny
+    linear._SKINNY_FORCE = True
+    try:
+        g = torch.Generator().manual_seed(31)
+        x = torch.randn(T, K, generator=g).bfloat16().to(dev)
+        w = (torch.randn(N, K, generator=g) * 0.1).bfloat16().to(dev)
+        b = torch.randn(N, generator=g).bfloat16().to(dev)
+        rows = torch.cat([torch.arange(0, min(T, 300)), torch.arange(max(T - 300, 0), T), torch.randint(0, T, (200,), generator=g)]).unique()
+        for bias in (b, None):
+            y = _gemm_skinny(x, w, bias)
+            assert y is not None and y.shape == (T, N)
+            want = x[rows].double() @ w.double().t() + (bias.double() if bias is not None else 0)
+            err = (y[rows].double() - want).abs().max().item()
+            assert err <= 1.2e-2 * max(1.0, want.abs().max().item()), err
+        wide = torch.randn(T, 2 * K, generator=g).bfloat16().to(dev)
+        y = _gemm_skinny(wide[:, K:], w, b)
+        want = wide[rows][:, K:].double() @ w.double().t() + b.double()
+        assert (y[rows].double() - want).abs().max().item() <= 1.2e-2 * max(1.0, want.abs().max().item())
+    finally:
+        linear._SKINNY_FORCE = False

@@ -1,0 +1,199 @@
+// vil_gemm_skinny.hip -- forward GEMM + bias of the projections whose contraction is short and whose token count is
+// huge (stages 1-2 of ViL: T = 100 000 ... 400 000 rows, K = C = 96 / 192, N <= 768):
+//     out[t][n] = sum_k in[t][k] * w[n][k] + bias[n]          (nn.Linear forward, bf16 in / out, fp32 accumulate)
+// These GEMMs are HBM-bound (read T*K, write T*N 16-bit values for 2*T*K*N flops: 30-70 flop/byte) and hipBLASLt's tiled
+// kernels run them at 2.0-2.9 TB/s because every 128/256-wide output tile re-streams its operands (tools/gemm_bench.py:
+// 140 us for the 385 MB of stage 1's fc1).  Here the whole weight matrix lives in REGISTERS for the lifetime of a
+// persistent workgroup -- wave (wn) holds the A fragments of its 96 output features for every k -- so the only traffic
+// is the activations in (LDS-DMA ring, one 128-row tile per slot) and the result out:
+//   * C^T orientation (D[n][t] = W rows x in rows): a lane ends up with 8 CONSECUTIVE output features of one token
+//     (the weight rows a 16-row MFMA tile covers are chosen so: rows {8g..8g+3} in the even tile of a pair,
+//     {8g+4..8g+7} in the odd one) -> one 16-byte store per lane and tile pair, bias added from registers;
+//   * the in-tile of a step is read from LDS by every wave (B fragments, ds_read_b128 from the XOR-swizzled 128-byte-row
+//     image of vil_attn_dense.hip, one image per 64 k);
+//   * no workgroup barrier except the one that publishes a landed tile.
+#include "vil_mfma_common.h"
+
+struct SkParams {
+  const void* in; const void* w; const void* bias; void* out;
+  int T, K, N;
+  int in_rs, out_rs;          // row strides (elements)
+  int wn, wt;                 // waves along n (32 * NP features each) x waves along t
+  int ntiles;                 // ceil(T / RT)
+};
+
+__device__ __forceinline__ int sk_off(int row, int colb) { return row * 128 + (colb ^ (((row >> 1) & 3) << 5)); }
+
+// KS = K / 32; NP = tile pairs (32 output features each) per wave; TT = 16-row column tiles per inner chunk; RT = token
+// rows per tile (ring slot); NSLOT ring slots.  Registers: weights 8 NP KS, accumulators 8 NP TT, (+ 4 TT, + 4 NP).
+template <int KS, int NP, int TT, int RT, int NSLOT>
+__global__ __launch_bounds__(512, 2) void k_skinny_nt(SkParams p) {
+  typedef __bf16 T_;
+  typedef typename V16<T_>::x8 X8;
+  constexpr int KB = (KS + 1) / 2;                 // 64-k images per tile
+  constexpr int IMG = RT * 128;                    // bytes of one image
+  constexpr int SLOT = KB * IMG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6;
+  const int lj = lane & 15, lg = lane >> 4;
+  const int wni = wave % p.wn, wti = wave / p.wn;
+  const int n_base = wni * (32 * NP);
+  const int rows_w = RT / p.wt;                    // token rows of a tile this wave computes
+  const int r_base = wti * rows_w;
+
+  // ---- this wave's weight fragments and bias: loaded once
+  const T_* wb = (const T_*)p.w;
+  X8 afr[NP][2][KS];
+  X8 bias8[NP];
+#pragma unroll
+  for (int pr = 0; pr < NP; ++pr) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int n = n_base + 32 * pr + 8 * (lj >> 2) + 4 * hf + (lj & 3);      // the feature MFMA row lj of this tile stands for
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        X8 z = {};
+        afr[pr][hf][ks] = n < p.N ? *(const X8*)(wb + (int64_t)n * p.K + ks * 32 + lg * 8) : z;
+      }
+    }
+    X8 z = {};
+    const int n8 = n_base + 32 * pr + 8 * lg;
+    bias8[pr] = (p.bias && n8 < p.N) ? *(const X8*)((const T_*)p.bias + n8) : z;
+  }
+
+  // ---- in-tile ring (LDS-DMA): piece = 8 rows x 128 bytes of one 64-k image
+  const __amdgpu_buffer_rsrc_t irs = make_rsrc_n(p.in, (unsigned)(((int64_t)(p.T - 1) * p.in_rs + p.K) * 2));
+  const int drow = lane >> 3, dslot = lane & 7, dchunk = dslot ^ (((drow >> 1) & 3) << 1);
+  const int in_v0 = drow * (p.in_rs * 2) + dchunk * 16;
+  auto issue = [&](int tile, int slot) {
+    char* base = smem + slot * SLOT;
+    const int t0 = tile * RT;
+    for (int pc = wave; pc < KB * (RT / 8); pc += nwaves) {
+      const int kb = pc / (RT / 8), pp = pc - kb * (RT / 8);
+      // (the last image of an odd KS holds 32 k: its upper four chunks per row are not requested)
+      if (kb * 2 + 1 < KS || dchunk < 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)(base + kb * IMG + pp * 1024),
+                                                 16, in_v0 + (t0 + pp * 8) * (p.in_rs * 2) + kb * 128, 0, 0, 0);
+    }
+  };
+  int bnat[2];
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2) bnat[k2] = sk_off(lj, k2 * 64 + lg * 16);
+
+  T_* ob = (T_*)p.out;
+  int it = 0;
+  const int first = blockIdx.x;
+  if (first < p.ntiles) issue(first, 0);
+  for (int tile = first; tile < p.ntiles; tile += gridDim.x, ++it) {
+    const int slot = it % NSLOT;
+    __syncthreads();                                      // (vmcnt(0) + barrier): this tile has landed, the slot of it+NSLOT-1 is free
+    const int nxt = tile + (NSLOT - 1) * gridDim.x;
+    if (NSLOT > 1) {
+      // keep NSLOT-1 tiles in flight: request tile it+NSLOT-1 into the slot that tile it-1 has just released
+      if (it == 0) {
+        for (int a = 1; a < NSLOT - 1; ++a)
+          if (tile + a * (int)gridDim.x < p.ntiles) issue(tile + a * gridDim.x, a);
+      }
+      if (nxt < p.ntiles) issue(nxt, (it + NSLOT - 1) % NSLOT);
+    }
+    const char* tb = smem + slot * SLOT;
+    const int t0 = tile * RT;
+    if (n_base < p.N) {
+      for (int r0 = r_base; r0 < r_base + rows_w; r0 += 16 * TT) {     // 16*TT token rows at a time
+        const int ntt = min(TT, (r_base + rows_w - r0) >> 4);
+        f32x4 acc[NP][2][TT];
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) acc[pr][hf][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          X8 bq[TT];
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt)
+            bq[tt] = *(const X8*)(tb + (ks >> 1) * IMG + (r0 + tt * 16) * 128 + bnat[ks & 1]);
+#pragma unroll
+          for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+              for (int tt = 0; tt < TT; ++tt) acc[pr][hf][tt] = mfma16(afr[pr][hf][ks], bq[tt], acc[pr][hf][tt]);
+        }
+        // epilogue: lane (j, g) of pair pr, column tile tt: token t0 + r0 + 16 tt + j, features n_base + 32 pr + 8 g .. +7
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          const int t = t0 + r0 + tt * 16 + lj;
+          if (tt < ntt && t < p.T) {
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) {
+              const int n8 = n_base + 32 * pr + 8 * lg;
+              if (n8 < p.N) {
+                X8 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  o[r] = (T_)(acc[pr][0][tt][r] + (float)bias8[pr][r]);
+                  o[4 + r] = (T_)(acc[pr][1][tt][r] + (float)bias8[pr][4 + r]);
+                }
+                *(X8*)(ob + (int64_t)t * p.out_rs + n8) = o;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// out[T][N] = in[T][K] . w[N][K]^T (+ bias[N]); bf16.  VIL_E_BACKEND outside the table below (the caller then uses the
+// library GEMM).
+//   K   features per wave   rows per tile   ring        workgroup
+//   96      96 (3 pairs)        128         2 x 32 KB   N/96 waves along n (x 4 / 2 along t for N = 96 / 192), 2 per CU
+//  192      96                  128         3 x 48 KB   N/96 waves along n (x 2 for N = 192), 1 per CU
+template <int KS, int NP, int TT, int RT, int NSLOT>
+static int sk_launch(SkParams& p, int ncu, hipStream_t s) {
+  p.wn = (p.N + 32 * NP - 1) / (32 * NP);
+  if (p.wn > 8) return VIL_E_BACKEND;
+  p.wt = p.wn == 1 ? 4 : (p.wn == 2 ? 2 : 1);
+  p.ntiles = (p.T + RT - 1) / RT;
+  const size_t lds = (size_t)NSLOT * ((KS + 1) / 2) * RT * 128;
+  const int wg_per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  int grid = ncu * wg_per_cu;
+  if (grid > p.ntiles) grid = p.ntiles;
+  if (int he = vil_ensure_dyn_lds((const void*)k_skinny_nt<KS, NP, TT, RT, NSLOT>, lds)) return he;
+  k_skinny_nt<KS, NP, TT, RT, NSLOT><<<dim3(grid), dim3(64 * p.wn * p.wt), lds, s>>>(p);
+  return (int)hipGetLastError();
+}
+
+// CU count of the current device, queried once per device (a device-attribute query is not a legal call while another
+// thread's stream capture is in global mode: the persistent grid size must not cost an API call per launch)
+static int sk_cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int v = 0;
+    cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return cached[dev];
+}
+
+extern "C" int vil_gemm_skinny_bf16(const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
+                                    int64_t in_row_stride, int64_t out_row_stride, void* stream) {
+  if (!in || !w || !out) return VIL_E_NULL;
+  if (T <= 0 || K <= 0 || N <= 0) return VIL_E_SHAPE;
+  if ((K != 96 && K != 192) || (N & 7)) return VIL_E_BACKEND;
+  if ((in_row_stride & 7) || (out_row_stride & 7) || (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out) & 15) ||
+      (bias && ((uintptr_t)bias & 15))) return VIL_E_ALIGN;
+  if ((T + 128) * in_row_stride * 2 >= (1ll << 31)) return VIL_E_BACKEND;
+  SkParams p;
+  p.in = in; p.w = w; p.bias = bias; p.out = out;
+  p.T = (int)T; p.K = K; p.N = N;
+  p.in_rs = (int)in_row_stride; p.out_rs = (int)out_row_stride;
+  const int ncu = sk_cu_count();
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 96) return sk_launch<3, 3, 4, 128, 2>(p, ncu, s);
+  return sk_launch<6, 3, 2, 128, 3>(p, ncu, s);
+}

@@ -396,9 +396,13 @@ class GraphedTrainStep:
         if settle:
             settle()
         self.graphs, self.opt_graph = [], None
+        # capture_error_mode "thread_local": with a process group alive, its watchdog thread polls events (hipEventQuery)
+        # at any time; under the default "global" mode such a call from ANOTHER thread invalidates the capture
+        # ("operation not permitted when stream is capturing") -- a race that depends on how long the capture takes
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
         if not self.segmented:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 self._segment(0, None)
                 self.opt.step()
             self.graphs.append(g)
@@ -406,13 +410,13 @@ class GraphedTrainStep:
             state, pool = None, None
             for k in range(len(self.seg_params)):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
                     state = self._segment(k, state)
                 pool = pool or g.pool()
                 self.graphs.append(g)
             del state
             self.opt_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.opt_graph, pool=pool):
+            with torch.cuda.graph(self.opt_graph, pool=pool, capture_error_mode=mode):
                 self.opt.step()
         self.graph = self.graphs[0]
         if settle:

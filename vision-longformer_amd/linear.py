@@ -79,6 +79,33 @@ def _wgrad(dy2, x2, want_db):
     return dw, db
 
 
+_SKINNY_MIN_T = 8192          # tokens from which the weights-in-registers forward kernel is taken (tools/gemm_bench.py)
+_SKINNY_FORCE = False
+
+
+def _gemm_skinny(inp2, w, bias):
+    """inp2 @ w.T (+ bias) through vil_gemm_skinny_bf16 (K in {96, 192}, huge T), or None outside its contract."""
+    T, K = inp2.shape
+    N = w.shape[0]
+    if not (K in (96, 192) and N % 8 == 0 and N <= 768 and (T >= _SKINNY_MIN_T or _SKINNY_FORCE)
+            and inp2.is_cuda and inp2.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.is_contiguous()
+            and w.shape[1] == K and inp2.stride(1) == 1 and inp2.stride(0) % 8 == 0 and inp2.data_ptr() % 16 == 0
+            and w.data_ptr() % 16 == 0 and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous()
+                                                             and bias.data_ptr() % 16 == 0))):
+        return None
+    import ctypes
+    from . import _lib
+    out = torch.empty(T, N, dtype=torch.bfloat16, device=inp2.device)
+    vp = ctypes.c_void_p
+    rc = _lib.lib().vil_gemm_skinny_bf16(vp(inp2.data_ptr()), vp(w.data_ptr()), vp(bias.data_ptr()) if bias is not None else None,
+                                         vp(out.data_ptr()), T, K, N, inp2.stride(0), N,
+                                         vp(torch.cuda.current_stream(inp2.device).cuda_stream))
+    if rc == _lib.VIL_E_BACKEND:
+        return None
+    _lib.check(rc)
+    return out
+
+
 _GEMM_WS = {}
 _GEMM_TUNED = set()
 
@@ -119,6 +146,13 @@ def _gemm(op, inp2, w, bias):
     return out
 
 
+def _fwd_gemm(x2, weight, bias):
+    """x2 @ weight.T (+ bias): the weights-in-registers kernel for the short-K / huge-T projections of stages 1-2
+    (csrc/vil_gemm_skinny.hip), the tuned library GEMM otherwise; None when neither takes the operands."""
+    y = _gemm_skinny(x2, weight, bias)
+    return y if y is not None else _gemm(0, x2, weight, bias)
+
+
 class _SplitKLinearFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
@@ -126,7 +160,7 @@ class _SplitKLinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         x2 = x.reshape(-1, x.shape[-1])
-        y = _gemm(0, x2, weight, bias) if x.is_cuda else None
+        y = _fwd_gemm(x2, weight, bias) if x.is_cuda else None
         if y is None:
             return F.linear(x, weight, bias)
         return y.view(*x.shape[:-1], weight.shape[0])
@@ -202,7 +236,7 @@ class _GeluLinearFn(torch.autograd.Function):
         ctx.save_for_backward(h, a, weight)
         ctx.has_bias = bias is not None
         a2 = a.reshape(-1, a.shape[-1])
-        y = _gemm(0, a2, weight, bias) if a.is_cuda else None
+        y = _fwd_gemm(a2, weight, bias) if a.is_cuda else None
         if y is None:
             return F.linear(a, weight, bias)
         return y.view(*a.shape[:-1], weight.shape[0])
@@ -283,7 +317,7 @@ class _PairLinearFn(torch.autograd.Function):
         b = b1.as_strided((co,), (1,)) if b1 is not None else None
         ctx.save_for_backward(x, w)
         ctx.co1, ctx.has_bias = co1, b is not None
-        y = _gemm(0, x.reshape(-1, ci), w, b)
+        y = _fwd_gemm(x.reshape(-1, ci), w, b)
         if y is None:
             y = F.linear(x.reshape(-1, ci), w, b)
         return y.view(*x.shape[:-1], co)
