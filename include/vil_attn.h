@@ -158,11 +158,13 @@ int vil_attn_bwd_full(const VilAttnDesc* d, const void* q_all, const void* k, co
 int vil_gemm_dgelu_bf16(const void* dy, const void* w, const void* h, void* dh, int64_t T, int K, int N,
                         int64_t dy_row_stride, int64_t h_row_stride, int64_t dh_row_stride, void* stream);
 
-/* ---- forward of an nn.Linear whose contraction is short and whose token count is huge (stages 1-2 of ViL; reference
- * msvit.py:17-34, 91-120, layers/longformer2d.py:47-62): out[t][n] = sum_k in[t][k] * w[n][k] + bias[n], bf16, fp32
- * accumulate, the weight matrix held in registers by a persistent workgroup (csrc/vil_gemm_skinny.hip).  K in {96, 192},
- * N % 8 == 0, N <= 768; VIL_E_BACKEND outside that contract.  Row strides in elements; bias may be NULL. */
-int vil_gemm_skinny_bf16(const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
+/* ---- nn.Linear forward (op 0) / input gradient (op 1) of the projections with a huge token count and a small weight
+ * matrix (stages 1-2 of ViL; reference msvit.py:17-34, 91-120, layers/longformer2d.py:47-62):
+ *   op 0: out[t][n] = sum_k in[t][k] * w[n][k] + bias[n];   op 1: out[t][n] = sum_k in[t][k] * w[k][n]  (w as stored)
+ * bf16, fp32 accumulate, the weight matrix held in registers by persistent workgroups, activations through an LDS-DMA
+ * ring (csrc/vil_gemm_skinny.hip).  K in {96, 192} with N <= 768, or K in {288, 384, 576, 768} with N <= 256; N % 8 == 0;
+ * VIL_E_BACKEND outside that contract.  Row strides in elements; bias may be NULL (and must be for op 1). */
+int vil_gemm_skinny_bf16(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
                          int64_t in_row_stride, int64_t out_row_stride, void* stream);
 
 /* ---- dense `Attention` of the s0 stages as its own kernel family (reference

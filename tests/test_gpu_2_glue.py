@@ -301,30 +301,34 @@ def test_mlp_block_fused_tail_matches_unfused(dev, B, N, C):
         close(p.grad, p64.grad, n)
 
 
-@pytest.mark.parametrize("T,K,N", [(401536, 96, 384), (100480, 192, 576), (100480, 192, 768), (50001, 96, 288), (4001, 96, 96),
-                                    (777, 192, 192), (130, 96, 200), (9, 192, 8)])
-def test_skinny_forward_gemm_vs_fp64(dev, T, K, N):
+@pytest.mark.parametrize("op,T,K,N", [(0, 401536, 96, 384), (0, 100480, 192, 576), (0, 100480, 192, 768), (0, 50001, 96, 288),
+                                       (0, 4001, 96, 96), (0, 777, 192, 192), (0, 130, 96, 200), (0, 9, 192, 8),
+                                       (0, 100003, 384, 96), (0, 50001, 768, 192), (1, 401536, 288, 96), (1, 100003, 384, 96),
+                                       (1, 100480, 576, 192), (1, 50001, 768, 192), (1, 4001, 96, 96), (1, 777, 192, 192),
+                                       (1, 130, 288, 72), (1, 33, 576, 136)])
+def test_skinny_gemm_vs_fp64(dev, op, T, K, N):
     """vil_gemm_skinny_bf16 (weights in registers, LDS-DMA ring of activation tiles, csrc/vil_gemm_skinny.hip): the
-    forward of an nn.Linear with bias against fp64 on sampled rows; ragged last tile, N not a multiple of 96 / 32,
-    strided input rows"""
+    forward of an nn.Linear with bias (op 0) and its input gradient (op 1: weight read k-strided through transposed LDS
+    reads) against fp64 on sampled rows; ragged last tile, N not a multiple of the 32-feature pair, strided input rows"""
     from vision_longformer_amd import linear
     from vision_longformer_amd.linear import _gemm_skinny
     linear._SKINNY_FORCE = True
     try:
         g = torch.Generator().manual_seed(31)
         x = torch.randn(T, K, generator=g).bfloat16().to(dev)
-        w = (torch.randn(N, K, generator=g) * 0.1).bfloat16().to(dev)
+        w = (torch.randn(*((N, K) if op == 0 else (K, N)), generator=g) * 0.1).bfloat16().to(dev)
         b = torch.randn(N, generator=g).bfloat16().to(dev)
+        wd = w.double().t() if op == 0 else w.double()
         rows = torch.cat([torch.arange(0, min(T, 300)), torch.arange(max(T - 300, 0), T), torch.randint(0, T, (200,), generator=g)]).unique()
-        for bias in (b, None):
-            y = _gemm_skinny(x, w, bias)
+        for bias in ((b, None) if op == 0 else (None,)):
+            y = _gemm_skinny(op, x, w, bias)
             assert y is not None and y.shape == (T, N)
-            want = x[rows].double() @ w.double().t() + (bias.double() if bias is not None else 0)
+            want = x[rows].double() @ wd + (bias.double() if bias is not None else 0)
             err = (y[rows].double() - want).abs().max().item()
             assert err <= 1.2e-2 * max(1.0, want.abs().max().item()), err
         wide = torch.randn(T, 2 * K, generator=g).bfloat16().to(dev)
-        y = _gemm_skinny(wide[:, K:], w, b)
-        want = wide[rows][:, K:].double() @ w.double().t() + b.double()
+        y = _gemm_skinny(op, wide[:, K:], w, b if op == 0 else None)
+        want = wide[rows][:, K:].double() @ wd + (b.double() if op == 0 else 0)
         assert (y[rows].double() - want).abs().max().item() <= 1.2e-2 * max(1.0, want.abs().max().item())
     finally:
         linear._SKINNY_FORCE = False

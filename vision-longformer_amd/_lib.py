@@ -114,8 +114,8 @@ def lib():
         L.vil_gemm_dgelu_bf16.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                           ctypes.c_int64, ctypes.c_int64, vp]
         L.vil_gemm_skinny_bf16.restype = ctypes.c_int
-        L.vil_gemm_skinny_bf16.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
-                                           ctypes.c_int64, vp]
+        L.vil_gemm_skinny_bf16.argtypes = [ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int64, ctypes.c_int64, vp]
         L.vil_dense_attn_supported.restype = ctypes.c_int
         L.vil_dense_attn_supported.argtypes = [dp]
         L.vil_dense_attn_workspace_bytes.restype = ctypes.c_size_t

@@ -26,8 +26,8 @@ __device__ __forceinline__ int sk_off(int row, int colb) { return row * 128 + (c
 
 // KS = K / 32; NP = tile pairs (32 output features each) per wave; TT = 16-row column tiles per inner chunk; RT = token
 // rows per tile (ring slot); NSLOT ring slots.  Registers: weights 8 NP KS, accumulators 8 NP TT, (+ 4 TT, + 4 NP).
-template <int KS, int NP, int TT, int RT, int NSLOT>
-__global__ __launch_bounds__(512, 2) void k_skinny_nt(SkParams p) {
+template <int KS, int NP, int TT, int RT, int NSLOT, bool NN>
+__global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
   typedef __bf16 T_;
   typedef typename V16<T_>::x8 X8;
   constexpr int KB = (KS + 1) / 2;                 // 64-k images per tile
@@ -46,17 +46,58 @@ __global__ __launch_bounds__(512, 2) void k_skinny_nt(SkParams p) {
   const T_* wb = (const T_*)p.w;
   X8 afr[NP][2][KS];
   X8 bias8[NP];
+  if (!NN) {
+    // w[n][k]: a fragment (row n, 8 consecutive k) is one 16-byte load
 #pragma unroll
-  for (int pr = 0; pr < NP; ++pr) {
+    for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const int n = n_base + 32 * pr + 8 * (lj >> 2) + 4 * hf + (lj & 3);      // the feature MFMA row lj of this tile stands for
+      for (int hf = 0; hf < 2; ++hf) {
+        const int n = n_base + 32 * pr + 8 * (lj >> 2) + 4 * hf + (lj & 3);      // the feature MFMA row lj of this tile stands for
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          X8 z = {};
+          afr[pr][hf][ks] = n < p.N ? *(const X8*)(wb + (int64_t)n * p.K + ks * 32 + lg * 8) : z;
+        }
+      }
+  } else {
+    // w[k][n] (the input gradient: w = weight as stored, K = its rows): fragments are k-strided.  The matrix passes
+    // through the (not yet used) ring area in chunks of whole 32-k groups, copied linearly by LDS-DMA, and is read
+    // with ds_read_b64_tr_b16: lane (g, 4e + q) points at row 8g + 4h + e, features 8q + 4hf .. +3 of its pair -- after
+    // the instruction's 4 x 4 exchange lane L holds rows 8g + 4h .. +3 of feature 8 (L/4) + 4hf + L%4, the A layout.
+    const int row_b = p.N * 2;
+    const int cap_rows = ((NSLOT * SLOT) / row_b - 2) & ~31;              // rows of w the ring area holds (one row of slack)
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc_n(p.w, (unsigned)((int64_t)p.K * row_b));
+    for (int k0 = 0; k0 < 32 * KS; k0 += cap_rows) {
+      const int rows = min(cap_rows, 32 * KS - k0);
+      const int bytes = rows * row_b;
+      __syncthreads();
+      for (int off = wave * 1024; off < bytes + row_b; off += nwaves * 1024)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(smem + off), 16,
+                                                 k0 * row_b + off + lane * 16, 0, 0, 0);
+      __syncthreads();
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        X8 z = {};
-        afr[pr][hf][ks] = n < p.N ? *(const X8*)(wb + (int64_t)n * p.K + ks * 32 + lg * 8) : z;
+        if (ks * 32 >= k0 && ks * 32 < k0 + rows) {
+#pragma unroll
+          for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+              for (int jh = 0; jh < 2; ++jh) {
+                const int row = ks * 32 - k0 + 8 * lg + 4 * jh + (lj >> 2);
+                const int n = n_base + 32 * pr + 8 * (lj & 3) + 4 * hf;
+                const typename V16<T_>::x4 t4 = __builtin_bit_cast(typename V16<T_>::x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(smem + row * row_b + min(n, p.N - 4) * 2)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) afr[pr][hf][ks][jh * 4 + e] = t4[e];
+              }
+        }
       }
     }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int pr = 0; pr < NP; ++pr) {
     X8 z = {};
     const int n8 = n_base + 32 * pr + 8 * lg;
     bias8[pr] = (p.bias && n8 < p.N) ? *(const X8*)((const T_*)p.bias + n8) : z;
@@ -147,23 +188,22 @@ __global__ __launch_bounds__(512, 2) void k_skinny_nt(SkParams p) {
   }
 }
 
-// out[T][N] = in[T][K] . w[N][K]^T (+ bias[N]); bf16.  VIL_E_BACKEND outside the table below (the caller then uses the
-// library GEMM).
-//   K   features per wave   rows per tile   ring        workgroup
-//   96      96 (3 pairs)        128         2 x 32 KB   N/96 waves along n (x 4 / 2 along t for N = 96 / 192), 2 per CU
-//  192      96                  128         3 x 48 KB   N/96 waves along n (x 2 for N = 192), 1 per CU
-template <int KS, int NP, int TT, int RT, int NSLOT>
+template <int KS, int NP, int TT, int RT, int NSLOT, bool NN>
 static int sk_launch(SkParams& p, int ncu, hipStream_t s) {
   p.wn = (p.N + 32 * NP - 1) / (32 * NP);
   if (p.wn > 8) return VIL_E_BACKEND;
-  p.wt = p.wn == 1 ? 4 : (p.wn == 2 ? 2 : 1);
+  // waves along t: as many as the tile's 16*TT-row chunks and the 8-wave workgroup allow (K <= 192: the shape the
+  // first version was tuned with -- 4 / 2 / 1 for 1 / 2 / >= 3 waves along n)
+  const int by_rows = RT / (16 * TT), by_waves = 8 / p.wn;
+  p.wt = KS <= 6 ? (p.wn == 1 ? 4 : (p.wn == 2 ? 2 : 1)) : (by_rows < by_waves ? by_rows : by_waves);
+  if (p.wt < 1) p.wt = 1;
   p.ntiles = (p.T + RT - 1) / RT;
   const size_t lds = (size_t)NSLOT * ((KS + 1) / 2) * RT * 128;
   const int wg_per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
   int grid = ncu * wg_per_cu;
   if (grid > p.ntiles) grid = p.ntiles;
-  if (int he = vil_ensure_dyn_lds((const void*)k_skinny_nt<KS, NP, TT, RT, NSLOT>, lds)) return he;
-  k_skinny_nt<KS, NP, TT, RT, NSLOT><<<dim3(grid), dim3(64 * p.wn * p.wt), lds, s>>>(p);
+  if (int he = vil_ensure_dyn_lds((const void*)k_skinny<KS, NP, TT, RT, NSLOT, NN>, lds)) return he;
+  k_skinny<KS, NP, TT, RT, NSLOT, NN><<<dim3(grid), dim3(64 * p.wn * p.wt), lds, s>>>(p);
   return (int)hipGetLastError();
 }
 
@@ -180,11 +220,21 @@ static int sk_cu_count() {
   return cached[dev];
 }
 
-extern "C" int vil_gemm_skinny_bf16(const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
+// op 0: out[T][N] = in[T][K] . w[N][K]^T (+ bias[N])   (nn.Linear forward)
+// op 1: out[T][N] = in[T][K] . w[K][N]                  (its input gradient: w = the weight as stored, K = out_features)
+// bf16, fp32 accumulate.  VIL_E_BACKEND outside the table below (the caller then uses the library GEMM).
+//   K     features / wave   rows / tile   ring        stages it serves (ViL: C = 96, 192)
+//   96      96                 128        2 x 32 KB   qkv / proj / fc1 forward and proj input gradient at C = 96
+//   192     96                 128        3 x 48 KB   the same at C = 192
+//   288     32                  64        3 x 40 KB   qkv input gradient at C = 96
+//   384     32                  64        3 x 48 KB   fc2 forward, fc1 input gradient at C = 96
+//   576     32                  32        3 x 36 KB   qkv input gradient at C = 192
+//   768     32                  32        3 x 48 KB   fc2 forward, fc1 input gradient at C = 192
+extern "C" int vil_gemm_skinny_bf16(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
                                     int64_t in_row_stride, int64_t out_row_stride, void* stream) {
   if (!in || !w || !out) return VIL_E_NULL;
-  if (T <= 0 || K <= 0 || N <= 0) return VIL_E_SHAPE;
-  if ((K != 96 && K != 192) || (N & 7)) return VIL_E_BACKEND;
+  if (T <= 0 || K <= 0 || N <= 0 || op < 0 || op > 1 || (op == 1 && bias)) return VIL_E_SHAPE;
+  if ((N & 7) || N > 768) return VIL_E_BACKEND;
   if ((in_row_stride & 7) || (out_row_stride & 7) || (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out) & 15) ||
       (bias && ((uintptr_t)bias & 15))) return VIL_E_ALIGN;
   if ((T + 128) * in_row_stride * 2 >= (1ll << 31)) return VIL_E_BACKEND;
@@ -194,6 +244,15 @@ extern "C" int vil_gemm_skinny_bf16(const void* in, const void* w, const void* b
   p.in_rs = (int)in_row_stride; p.out_rs = (int)out_row_stride;
   const int ncu = sk_cu_count();
   hipStream_t s = (hipStream_t)stream;
-  if (K == 96) return sk_launch<3, 3, 4, 128, 2>(p, ncu, s);
-  return sk_launch<6, 3, 2, 128, 3>(p, ncu, s);
+#define SK_CASE(KK, KS, NP, TT, RT, NSLOT)                                                   \
+  if (K == KK) return op ? sk_launch<KS, NP, TT, RT, NSLOT, true>(p, ncu, s) : sk_launch<KS, NP, TT, RT, NSLOT, false>(p, ncu, s);
+  SK_CASE(96, 3, 3, 4, 128, 2)
+  SK_CASE(192, 6, 3, 2, 128, 3)
+  if (N > 256) return VIL_E_BACKEND;              // (32 features per wave from here on)
+  SK_CASE(288, 9, 1, 2, 64, 3)
+  SK_CASE(384, 12, 1, 2, 64, 3)
+  SK_CASE(576, 18, 1, 2, 32, 3)
+  SK_CASE(768, 24, 1, 2, 32, 3)
+#undef SK_CASE
+  return VIL_E_BACKEND;
 }

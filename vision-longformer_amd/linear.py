@@ -83,21 +83,23 @@ _SKINNY_MIN_T = 8192          # tokens from which the weights-in-registers forwa
 _SKINNY_FORCE = False
 
 
-def _gemm_skinny(inp2, w, bias):
-    """inp2 @ w.T (+ bias) through vil_gemm_skinny_bf16 (K in {96, 192}, huge T), or None outside its contract."""
+def _gemm_skinny(op, inp2, w, bias):
+    """op 0: inp2 @ w.T (+ bias); op 1: inp2 @ w -- through vil_gemm_skinny_bf16 (small weight matrix, huge T), or None
+    outside its contract."""
     T, K = inp2.shape
-    N = w.shape[0]
-    if not (K in (96, 192) and N % 8 == 0 and N <= 768 and (T >= _SKINNY_MIN_T or _SKINNY_FORCE)
+    N = w.shape[0] if op == 0 else w.shape[1]
+    ok_shape = (K in (96, 192) and N <= 768) or (K in (288, 384, 576, 768) and N <= 256)
+    if not (ok_shape and N % 8 == 0 and (T >= _SKINNY_MIN_T or _SKINNY_FORCE)
             and inp2.is_cuda and inp2.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.is_contiguous()
-            and w.shape[1] == K and inp2.stride(1) == 1 and inp2.stride(0) % 8 == 0 and inp2.data_ptr() % 16 == 0
-            and w.data_ptr() % 16 == 0 and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous()
-                                                             and bias.data_ptr() % 16 == 0))):
+            and (w.shape[1] if op == 0 else w.shape[0]) == K and inp2.stride(1) == 1 and inp2.stride(0) % 8 == 0
+            and inp2.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and (bias is None or (op == 0 and bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.data_ptr() % 16 == 0))):
         return None
     import ctypes
     from . import _lib
     out = torch.empty(T, N, dtype=torch.bfloat16, device=inp2.device)
     vp = ctypes.c_void_p
-    rc = _lib.lib().vil_gemm_skinny_bf16(vp(inp2.data_ptr()), vp(w.data_ptr()), vp(bias.data_ptr()) if bias is not None else None,
+    rc = _lib.lib().vil_gemm_skinny_bf16(op, vp(inp2.data_ptr()), vp(w.data_ptr()), vp(bias.data_ptr()) if bias is not None else None,
                                          vp(out.data_ptr()), T, K, N, inp2.stride(0), N,
                                          vp(torch.cuda.current_stream(inp2.device).cuda_stream))
     if rc == _lib.VIL_E_BACKEND:
@@ -149,8 +151,14 @@ def _gemm(op, inp2, w, bias):
 def _fwd_gemm(x2, weight, bias):
     """x2 @ weight.T (+ bias): the weights-in-registers kernel for the short-K / huge-T projections of stages 1-2
     (csrc/vil_gemm_skinny.hip), the tuned library GEMM otherwise; None when neither takes the operands."""
-    y = _gemm_skinny(x2, weight, bias)
+    y = _gemm_skinny(0, x2, weight, bias)
     return y if y is not None else _gemm(0, x2, weight, bias)
+
+
+def _bwd_gemm(dy2, weight):
+    """dy2 @ weight (the input gradient): the weights-in-registers kernel where it applies, else the library GEMM"""
+    dx = _gemm_skinny(1, dy2, weight, None)
+    return dx if dx is not None else _gemm(1, dy2, weight, None)
 
 
 class _SplitKLinearFn(torch.autograd.Function):
@@ -175,7 +183,7 @@ class _SplitKLinearFn(torch.autograd.Function):
         T = x2.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _gemm(1, dy2, weight, None) if dy2.is_cuda else None
+            dx = _bwd_gemm(dy2, weight) if dy2.is_cuda else None
             dx = (dx if dx is not None else dy2 @ weight).view(x.shape)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
@@ -330,7 +338,7 @@ class _PairLinearFn(torch.autograd.Function):
         dy2, x2 = dy.reshape(-1, co), x.reshape(-1, ci)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _gemm(1, dy2, w, None)
+            dx = _bwd_gemm(dy2, w)
             dx = (dx if dx is not None else dy2 @ w).view(x.shape)
         fused = _wgrad(dy2, x2, ctx.has_bias)
         if fused is not None:
