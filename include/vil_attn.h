@@ -23,9 +23,10 @@
  * synchronise -- the two documented exceptions synchronise by design:
  * vil_gemm_tune and vil_attn_profile_end.  Process-global state: the
  * profiling sink, the GEMM plan cache (both described at their entry points) and the record of which kernels
- * already had their dynamic-LDS limit raised.  Two environment variables are read once, for measurements only:
- * VIL_WGRAD_WGS (workgroup target of vil_linear_wgrad's planner) and VIL_DEBUG_KV_LDS_PAD (unused LDS bytes added
- * to the dK/dV launch to lower its residency).  Return value: 0 = success, negative = argument error
+ * already had their dynamic-LDS limit raised.  Two environment variables are read, for measurements only:
+ * VIL_WGRAD2 (pins vil_linear_wgrad's plan: "0" = the 128 x 128 kernel, "m,mi,nj" = slices per XCD and tile of the
+ * second-generation kernel; read per call) and VIL_DEBUG_KV_LDS_PAD (unused LDS bytes added to the dK/dV launch to
+ * lower its residency; read once).  Return value: 0 = success, negative = argument error
  * (VIL_E_*), positive = hipError_t of the failing launch.
  *
  * Tensor layout: q is addressed as q[b*q_sb + i*q_st + h*q_sh + d] with
@@ -289,10 +290,18 @@ int vil_colsum_f32(const void* x, int64_t rows, int C, int64_t row_stride, void*
  * msvit.py:91-120, 236-255, longformer2d.py:47-62): dW[co][ci] = sum_t dy[t][co] x[t][ci] (row-major
  * (CO, CI), like nn.Linear.weight) and, when db != NULL, db[co] = sum_t dy[t][co].  dy is (T, CO) and x
  * (T, CI) bf16 with the given row strides (elements); CO, CI and the strides multiples of 8, 16-byte
- * aligned bases.  Outputs bf16 (out_bf16 = 1) or fp32.  Workspace: vil_linear_wgrad_workspace_bytes. */
+ * aligned bases.  Outputs bf16 (out_bf16 = 1) or fp32.  Workspace: vil_linear_wgrad_workspace_bytes (covers every
+ * plan the tuner may select).  Two kernel generations (csrc/vil_wgrad.hip): 128 x 128 tiles for any channel count,
+ * and -- channel counts that are multiples of 96 -- 96/192-wide tiles fed by an LDS-DMA ring; which one runs, with
+ * how many token slices, is the plan vil_linear_wgrad_tune measured for (T, CO, CI) (same arguments; times every
+ * candidate on the caller's operands, SYNCHRONISES, must be called outside stream capture, idempotent; the plan
+ * cache is process-global, mutex-guarded) or a cost model's choice when the problem was never tuned.  Partial sums
+ * are added in a fixed order: results are bit-reproducible for a given plan. */
 size_t vil_linear_wgrad_workspace_bytes(int64_t T, int CO, int CI);
 int vil_linear_wgrad(const void* dy, const void* x, int64_t T, int CO, int CI, int64_t dy_stride, int64_t x_stride,
                      void* dw, void* db, int out_bf16, void* workspace, void* stream);
+int vil_linear_wgrad_tune(const void* dy, const void* x, int64_t T, int CO, int CI, int64_t dy_stride, int64_t x_stride,
+                          void* dw, void* db, int out_bf16, void* workspace, void* stream);
 
 /* ---- fused residual add + LayerNorm on the fp32 residual stream (block glue of msvit.py:313-316,336-340:
  * `x = x + drop_path(branch)` of one block fused with `norm(x)` of the next).  Contiguous (rows, C) tensors.

@@ -103,6 +103,76 @@ def test_linear_wgrad_fused(dev, T, CO, CI):
     assert (got - want).abs().max().item() <= 6e-3 * want.abs().max().item()
 
 
+def _wgrad_f32(dy, x, want_db=True):
+    """vil_linear_wgrad with fp32 outputs, straight through the C ABI (the plan is whatever VIL_WGRAD2 / the cache says)."""
+    import ctypes
+    from vision_longformer_amd import _lib
+    L = _lib.lib()
+    T, co = dy.shape
+    ci = x.shape[1]
+    ws = torch.empty(L.vil_linear_wgrad_workspace_bytes(T, co, ci) // 4 + 64, dtype=torch.float32, device=dy.device)
+    dw = torch.empty(co, ci, dtype=torch.float32, device=dy.device)
+    db = torch.empty(co, dtype=torch.float32, device=dy.device)
+    vp = ctypes.c_void_p
+    _lib.check(L.vil_linear_wgrad(vp(dy.data_ptr()), vp(x.data_ptr()), T, co, ci, dy.stride(0), x.stride(0), vp(dw.data_ptr()),
+                                  vp(db.data_ptr()) if want_db else None, 0, vp(ws.data_ptr()),
+                                  vp(torch.cuda.current_stream(dy.device).cuda_stream)))
+    torch.cuda.synchronize()
+    return dw, db
+
+
+@pytest.mark.parametrize("T,CO,CI", [(20011, 384, 192), (9000, 192, 96), (5003, 96, 96), (12345, 96, 384), (3100, 768, 576), (1500, 288, 480)])
+def test_linear_wgrad_every_plan(dev, T, CO, CI, monkeypatch):
+    """Every plan of the second-generation weight-gradient kernel (tile 96/192 x 96/192, 1 .. max token slices per XCD:
+    LDS-DMA ring with out-of-range stages, swizzled transposed reads, accumulator-order partial records, the reduce
+    pass) and the 128 x 128 kernel: fp32 outputs against fp64 at fp32-accumulation tolerance, ragged last slice,
+    strided dY; the same plan twice is bit-identical."""
+    g = torch.Generator().manual_seed(13)
+    wide = (torch.randn(T, CO + 64, generator=g) * 0.1).bfloat16().to(dev)
+    dy = wide[:, 64:]
+    x = torch.randn(T, CI, generator=g).bfloat16().to(dev)
+    want = (dy.double().t() @ x.double()).cpu()
+    wdb = dy.double().sum(0).cpu()
+    scale, sdb = want.abs().max().item(), max(1.0, wdb.abs().max().item())
+    plans = ["0"] + [f"{m},{mi},{nj}" for mi in (3, 6) for nj in (3, 6) if CO % (32 * mi) == 0 and CI % (32 * nj) == 0
+                     for m in (1, 3, 64)]
+    assert len(plans) > 3
+    for plan in plans:
+        monkeypatch.setenv("VIL_WGRAD2", plan)
+        dw, db = _wgrad_f32(dy, x)
+        assert (dw.double().cpu() - want).abs().max().item() <= 2e-5 * scale, plan
+        assert (db.double().cpu() - wdb).abs().max().item() <= 2e-5 * sdb, plan
+        dw2, db2 = _wgrad_f32(dy, x)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2), plan
+        dw3, _ = _wgrad_f32(dy, x, want_db=False)
+        assert torch.equal(dw, dw3), plan
+
+
+def test_linear_wgrad_tune_selects_a_plan(dev):
+    """vil_linear_wgrad_tune measures the candidates on the caller's operands and the launch that follows runs the
+    selected plan: the result still matches fp64, and tuning twice is harmless"""
+    import ctypes
+    from vision_longformer_amd import _lib
+    L = _lib.lib()
+    T, co, ci = 30000, 384, 192
+    g = torch.Generator().manual_seed(2)
+    dy = (torch.randn(T, co, generator=g) * 0.1).bfloat16().to(dev)
+    x = torch.randn(T, ci, generator=g).bfloat16().to(dev)
+    ws = torch.empty(L.vil_linear_wgrad_workspace_bytes(T, co, ci) // 4 + 64, dtype=torch.float32, device=dev)
+    dw = torch.empty(co, ci, dtype=torch.float32, device=dev)
+    db = torch.empty(co, dtype=torch.float32, device=dev)
+    vp = ctypes.c_void_p
+    args = (vp(dy.data_ptr()), vp(x.data_ptr()), T, co, ci, co, ci, vp(dw.data_ptr()), vp(db.data_ptr()), 0, vp(ws.data_ptr()),
+            vp(torch.cuda.current_stream(dev).cuda_stream))
+    for _ in range(2):
+        _lib.check(L.vil_linear_wgrad_tune(*args))
+        _lib.check(L.vil_linear_wgrad(*args))
+        torch.cuda.synchronize()
+        want = dy.double().t() @ x.double()
+        assert (dw.double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+        assert (db.double() - dy.double().sum(0)).abs().max().item() <= 2e-5 * max(1.0, dy.double().sum(0).abs().max().item())
+
+
 @pytest.mark.parametrize("B,N,C,bdt", [(4, 197, 384, torch.bfloat16), (2, 50, 768, torch.bfloat16), (3, 785, 192, torch.float32),
                                         (2, 3137, 96, torch.bfloat16)])
 def test_residual_layernorm_fused(dev, B, N, C, bdt):

@@ -52,6 +52,7 @@ def _colsum(dy2):
 
 
 _WG_WS = {}
+_WG_TUNED = set()
 
 
 def _wgrad(dy2, x2, want_db):
@@ -73,9 +74,15 @@ def _wgrad(dy2, x2, want_db):
     dw = torch.empty(co, ci, dtype=torch.bfloat16, device=dy2.device)
     db = torch.empty(co, dtype=torch.bfloat16, device=dy2.device) if want_db else None
     vp = ctypes.c_void_p
-    _lib.check(L.vil_linear_wgrad(vp(dy2.data_ptr()), vp(x2.data_ptr()), T, co, ci, dy2.stride(0), x2.stride(0),
-                                  vp(dw.data_ptr()), vp(db.data_ptr()) if want_db else None, 1, vp(ws.data_ptr()),
-                                  vp(torch.cuda.current_stream(dy2.device).cuda_stream)))
+    args = (vp(dy2.data_ptr()), vp(x2.data_ptr()), T, co, ci, dy2.stride(0), x2.stride(0),
+            vp(dw.data_ptr()), vp(db.data_ptr()) if want_db else None, 1, vp(ws.data_ptr()),
+            vp(torch.cuda.current_stream(dy2.device).cuda_stream))
+    key = (dy2.device, T, co, ci)
+    if key not in _WG_TUNED and not torch.cuda.is_current_stream_capturing():
+        # one-off plan selection per problem by measurement (synchronises; never inside a captured region)
+        _WG_TUNED.add(key)
+        _lib.check(L.vil_linear_wgrad_tune(*args))
+    _lib.check(L.vil_linear_wgrad(*args))
     return dw, db
 
 
