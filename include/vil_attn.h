@@ -155,7 +155,8 @@ int vil_attn_bwd_full(const VilAttnDesc* d, const void* q_all, const void* k, co
  * row 3; reference src/models/msvit.py:17-34, fc1 -> nn.GELU -> fc2):
  *   dh[t][n] = (sum_k dy[t][k] * w[k][n]) * gelu'(h[t][n]),  gelu'(x) = Phi(x) + x phi(x)
  * bf16 in / out, fp32 accumulate; w = fc2.weight (K = out_features rows, N = hidden columns, row-major), h = fc1's
- * output.  Row strides in elements.  K % 32 == 0, N % 128 == 0; VIL_E_BACKEND outside that contract. */
+ * output.  Row strides in elements, multiples of 8; 16-byte aligned bases (VIL_E_ALIGN otherwise).  K % 32 == 0,
+ * N % 128 == 0; VIL_E_BACKEND outside that contract. */
 int vil_gemm_dgelu_bf16(const void* dy, const void* w, const void* h, void* dh, int64_t T, int K, int N,
                         int64_t dy_row_stride, int64_t h_row_stride, int64_t dh_row_stride, void* stream);
 

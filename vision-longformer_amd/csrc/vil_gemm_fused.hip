@@ -9,8 +9,8 @@
 // Shape of the problem: T (tokens) is 6 400 ... 400 000, K = C is 96 ... 768, N = 4C -- tall, with a short K loop and a
 // wide output: HBM / VALU(epilogue)-bound at stages 1-2, MFMA-bound at stages 3-4.
 // One workgroup (4 waves) = a 128 (t) x 128 (n) output tile, computed TRANSPOSED (C^T = W^T dY^T, the S^T orientation of
-// the attention kernels): lane j of a 16x16 accumulator tile holds 4 consecutive n of one row t -- 8-byte loads of h and
-// 8-byte stores of dh, no LDS transpose in the epilogue.  A operand = W^T tiles through ds_read_b64_tr_b16 from the
+// the attention kernels): a lane holds 8 consecutive n of one row t per pair of accumulator tiles -- 16-byte loads of h
+// and 16-byte stores of dh, no LDS transpose in the epilogue.  A operand = W^T tiles through ds_read_b64_tr_b16 from the
 // row-major [k][n] LDS image; B operand = dY rows (two 8-byte reads per fragment: the transposed read delivers k in the
 // order {4g + e, 16 + 4g + e}, so the other operand is read in that order too).  K streams in 64-deep blocks through a
 // two-slot LDS ring filled by LDS-DMA (the XOR-swizzled image of vil_attn_dense.hip).  Rows t >= T and k >= K read as
@@ -82,17 +82,22 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_dgelu(DgParams p) {
   // the epilogue's h values: 16 eight-byte loads per lane, in flight during the whole K loop (the first version loaded
   // them tile row by tile row in the epilogue: four dependent HBM round trips per workgroup)
   const T_* hb = (const T_*)p.h;
-  X4 h4[4][4];
+  X8 h8[4][2];
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt) {
     const int t = min(t0 + wt * 64 + tt * 16 + lj, p.T - 1);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) h4[tt][nt] = *(const X4*)(hb + (int64_t)t * p.h_rs + n0 + wn * 64 + nt * 16 + lg * 4);
+    for (int pr = 0; pr < 2; ++pr) h8[tt][pr] = *(const X8*)(hb + (int64_t)t * p.h_rs + n0 + wn * 64 + pr * 32 + lg * 8);
   }
 
+  // A tiles come in pairs (pr, hf) over 32 features: MFMA row j of tile (pr, hf) stands for feature 32 pr + 8 (j / 4) +
+  // 4 hf + j % 4, so accumulator rows 4 g .. 4 g + 3 of the pair's two tiles are features 8 g .. 8 g + 7 -- one 16-byte
+  // load of h and one 16-byte store of dh per lane and pair (8-byte accesses in 32-byte runs ran stage 1 at 2.9 TB/s).
+  // The transposed read allows it: the column a lane RECEIVES is (what lane 4 e + j / 4 pointed at) + j % 4, so the
+  // loader lane q = j % 4 ... points at feature 32 pr + 8 q + 4 hf instead of 16 nt + 4 q.
   int wtr[4], dnat[2][2];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) wtr[nt] = gf_off(lg * 4 + (lj >> 2), nt * 32 + (lj & 3) * 8);
+  for (int nt = 0; nt < 4; ++nt) wtr[nt] = gf_off(lg * 4 + (lj >> 2), ((nt >> 1) * 32 + (lj & 3) * 8 + (nt & 1) * 4) * 2);
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -110,16 +115,13 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_dgelu(DgParams p) {
     const char* wb = smem + (kb & 1) * GF_SLOT + 16 * 1024 + wn * (64 * 128);
     const int nks = min(2, (p.K - kb * 64) >> 5);
     for (int ks = 0; ks < nks; ++ks) {
+      // (transposed reads as inline assembly, lds_tr_issue in vil_mfma_common.h: through the builtin the first read of
+      // every K block waited for the NEXT block's LDS-DMA requests -- no prefetch at all from K = 384 on)
       X8 a[4], bq[4];
+      s16x4 ar[4][2];
+      const unsigned wa = lds_addr32(wb) + ks * (32 * 128);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const X4 t4 = __builtin_bit_cast(X4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(wb + wtr[nt] + ks * (32 * 128) + hf * (16 * 128))));
-#pragma unroll
-          for (int e = 0; e < 4; ++e) a[nt][hf * 4 + e] = t4[e];
-        }
+      for (int nt = 0; nt < 4; ++nt) { ar[nt][0] = lds_tr_issue<0>(wa + wtr[nt]); ar[nt][1] = lds_tr_issue<16 * 128>(wa + wtr[nt]); }
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -128,6 +130,9 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_dgelu(DgParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) bq[tt][hf * 4 + e] = d4[e];
         }
+      lds_tr_settle(ar[0][0], ar[0][1], ar[1][0], ar[1][1], ar[2][0], ar[2][1], ar[3][0], ar[3][1]);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) a[nt] = lds_tr_join<T_>(ar[nt][0], ar[nt][1]);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -144,26 +149,29 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_dgelu(DgParams p) {
     const int t = t0 + wt * 64 + tt * 16 + lj;
     if (t < p.T) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        X4 o4;
+      for (int pr = 0; pr < 2; ++pr) {
+        X8 o8;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o4[r] = (T_)(acc[nt][tt][r] * gelu_grad((float)h4[tt][nt][r]));
-        *(X4*)(ob + (int64_t)t * p.dh_rs + n0 + wn * 64 + nt * 16 + lg * 4) = o4;
+        for (int r = 0; r < 4; ++r) {
+          o8[r] = (T_)(acc[2 * pr][tt][r] * gelu_grad((float)h8[tt][pr][r]));
+          o8[4 + r] = (T_)(acc[2 * pr + 1][tt][r] * gelu_grad((float)h8[tt][pr][4 + r]));
+        }
+        *(X8*)(ob + (int64_t)t * p.dh_rs + n0 + wn * 64 + pr * 32 + lg * 8) = o8;
       }
     }
   }
 }
 
 // dh[T][N] = (dy[T][K] . w[K][N]) * gelu'(h[T][N]); bf16, row strides in elements.  K % 32 == 0, N % 128 == 0, 16-byte
-// aligned bases and 8-byte aligned rows; VIL_E_BACKEND when the problem is outside the kernel's contract (the caller
+// aligned bases and rows; VIL_E_BACKEND when the problem is outside the kernel's contract (the caller
 // then runs the GEMM and the GELU backward separately).
 extern "C" int vil_gemm_dgelu_bf16(const void* dy, const void* w, const void* h, void* dh, int64_t T, int K, int N,
                                    int64_t dy_row_stride, int64_t h_row_stride, int64_t dh_row_stride, void* stream) {
   if (!dy || !w || !h || !dh) return VIL_E_NULL;
   if (T <= 0 || K <= 0 || N <= 0) return VIL_E_SHAPE;
   if ((K & 31) || (N & 127)) return VIL_E_BACKEND;
-  if ((dy_row_stride & 7) || (h_row_stride & 3) || (dh_row_stride & 3) ||
-      (((uintptr_t)dy | (uintptr_t)w) & 15) || (((uintptr_t)h | (uintptr_t)dh) & 7)) return VIL_E_ALIGN;
+  if ((dy_row_stride & 7) || (h_row_stride & 7) || (dh_row_stride & 7) ||
+      (((uintptr_t)dy | (uintptr_t)w | (uintptr_t)h | (uintptr_t)dh) & 15)) return VIL_E_ALIGN;
   if (dy_row_stride < K || h_row_stride < N || dh_row_stride < N) return VIL_E_SHAPE;
   // 32-bit byte offsets inside the descriptors and the tile decode
   if ((T + 128) * dy_row_stride * 2 >= (1ll << 31) || (int64_t)K * N * 2 >= (1ll << 31) || T * (N / 128) >= (1ll << 30)) return VIL_E_BACKEND;

@@ -114,6 +114,32 @@ __device__ __forceinline__ typename V16<T>::x8 buf_load8(__amdgpu_buffer_rsrc_t 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
+// ---- transposed LDS reads next to LDS-DMA.  __builtin_amdgcn_ds_read_tr16_b64 is modelled as an LDS access that may
+// WRITE, so with buffer_load ... lds requests in flight the compiler puts s_waitcnt vmcnt(0) in front of it: the block
+// a kernel has just requested must land before the current one can be consumed, and the prefetch is gone (ordinary
+// ds_read_b128 loads get no such wait).  These helpers issue the read as inline assembly; completion is the caller's:
+// lds_tr_settle() = s_waitcnt lgkmcnt(0) carrying the destination registers as operands, so no consumer moves above it.
+// (lgkmcnt(0) and not a counted wait: scalar loads share the counter and return out of order.)
+__device__ __forceinline__ unsigned lds_addr32(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+template <int OFF> __device__ __forceinline__ s16x4 lds_tr_issue(unsigned addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ void lds_tr_settle(s16x4& a, s16x4& b, s16x4& c, s16x4& d, s16x4& e, s16x4& f, s16x4& g, s16x4& h) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+template <typename T> __device__ __forceinline__ typename V16<T>::x8 lds_tr_join(s16x4 lo, s16x4 hi) {
+  typedef typename V16<T>::x4 X4;
+  const X4 l = __builtin_bit_cast(X4, lo), h = __builtin_bit_cast(X4, hi);
+  typename V16<T>::x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = l[e]; r[4 + e] = h[e]; }
+  return r;
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

@@ -224,8 +224,8 @@ def _dgrad_dgelu(dy2, weight, h2):
         return None
     if not (dy2.is_cuda and dy2.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and h2.dtype == torch.bfloat16
             and weight.is_contiguous() and weight.shape[0] == K and h2.shape == (T, N) and K % 32 == 0 and N % 128 == 0
-            and dy2.stride(1) == 1 and h2.stride(1) == 1 and dy2.stride(0) % 8 == 0 and h2.stride(0) % 4 == 0
-            and dy2.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and h2.data_ptr() % 8 == 0):
+            and dy2.stride(1) == 1 and h2.stride(1) == 1 and dy2.stride(0) % 8 == 0 and h2.stride(0) % 8 == 0
+            and dy2.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and h2.data_ptr() % 16 == 0):
         return None
     import ctypes
     from . import _lib
