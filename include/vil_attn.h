@@ -168,6 +168,11 @@ int vil_gemm_dgelu_bf16(const void* dy, const void* w, const void* h, void* dh, 
  * VIL_E_BACKEND outside that contract.  Row strides in elements; bias may be NULL (and must be for op 1). */
 int vil_gemm_skinny_bf16(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
                          int64_t in_row_stride, int64_t out_row_stride, void* stream);
+/* The same forward GEMM with nn.GELU() (exact erf form, reference msvit.py:17-34: fc1 -> GELU) in its epilogue:
+ * out = in . w^T + bias, act = gelu(out) evaluated on the rounded bf16 out -- what the unfused Linear -> GELU pair
+ * computes -- both (T, N) with row stride out_row_stride.  K = 96 / 192, N <= 768 (VIL_E_BACKEND otherwise). */
+int vil_gemm_skinny_gelu_bf16(const void* in, const void* w, const void* bias, void* out, void* act, int64_t T, int K, int N,
+                              int64_t in_row_stride, int64_t out_row_stride, void* stream);
 
 /* ---- dense `Attention` of the s0 stages as its own kernel family (reference
  * src/models/msvit.py:91-120): every one of the N = G + nx*ny tokens attends every token,

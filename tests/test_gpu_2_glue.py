@@ -371,6 +371,60 @@ def test_mlp_block_fused_tail_matches_unfused(dev, B, N, C):
         close(p.grad, p64.grad, n)
 
 
+@pytest.mark.parametrize("T,K,N", [(401536, 96, 384), (100480, 192, 768), (50001, 96, 288), (777, 192, 200), (9, 96, 8)])
+def test_skinny_gemm_gelu_epilogue(dev, T, K, N):
+    """vil_gemm_skinny_gelu_bf16: h = x W^T + b and gelu(h) (exact erf form) in one launch.  h is bit-identical to the plain
+    kernel's output; the activation is the GELU of the ROUNDED h (what Linear -> nn.GELU computes) to bf16 rounding plus
+    the 4e-7 absolute error of the erfc approximation, and never has the wrong sign"""
+    from vision_longformer_amd import linear
+    from vision_longformer_amd.linear import _gemm_skinny, _gemm_skinny_gelu
+    linear._SKINNY_FORCE = True
+    cap, linear._GELU_EPILOGUE_MAX_K = linear._GELU_EPILOGUE_MAX_K, 192
+    try:
+        g = torch.Generator().manual_seed(37)
+        x = torch.randn(T, K, generator=g).bfloat16().to(dev)
+        w = (torch.randn(N, K, generator=g) * 0.25).bfloat16().to(dev)
+        b = torch.randn(N, generator=g).bfloat16().to(dev)
+        for bias in (b, None):
+            h, a = _gemm_skinny_gelu(x, w, bias)
+            assert torch.equal(h, _gemm_skinny(0, x, w, bias))
+            want = torch.nn.functional.gelu(h.double())
+            err = (a.double() - want).abs()
+            assert bool((err <= want.abs() * 2.0 ** -8 + 4e-7).all()), err.max().item()
+            assert bool((a.float() * h.float() >= 0).all())
+            assert (h.float().min().item() < -4.0 and h.float().max().item() > 4.0) or T < 1000     # both tails exercised
+    finally:
+        linear._SKINNY_FORCE = False
+        linear._GELU_EPILOGUE_MAX_K = cap
+
+
+@pytest.mark.parametrize("B,N,C", [(3, 3137, 96), (2, 785, 192)])
+def test_mlp_block_with_gelu_epilogue_matches_unfused(dev, B, N, C):
+    """msvit.Mlp with fc1 + GELU as ONE launch (vil_linear_gelu -> vil_gemm_skinny_gelu_bf16) against the same module
+    with the kernel family switched off: identical h, so outputs and gradients agree to the rounding of the activation"""
+    from vision_longformer_amd import linear
+    from vision_longformer_amd.msvit import Mlp
+    torch.manual_seed(6)
+    m = Mlp(C, 4 * C).to(dev)
+    x0 = torch.randn(B, N, C, device=dev)
+    dout = torch.randn(B, N, C, device=dev)
+    res = []
+    for force, min_t in ((True, linear._SKINNY_MIN_T), (False, 1 << 60)):
+        linear._SKINNY_FORCE, old, cap = force, linear._SKINNY_MIN_T, linear._GELU_EPILOGUE_MAX_K
+        linear._SKINNY_MIN_T, linear._GELU_EPILOGUE_MAX_K = min_t, 192
+        try:
+            x = x0.clone().requires_grad_(True)
+            m.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+            y.float().backward(dout)
+            res.append([y.detach().float(), x.grad.float()] + [p.grad.float() for p in m.parameters()])
+        finally:
+            linear._SKINNY_FORCE, linear._SKINNY_MIN_T, linear._GELU_EPILOGUE_MAX_K = False, old, cap
+    for a, b in zip(*res):
+        assert (a - b).abs().max().item() <= 2e-2 * max(b.abs().max().item(), 1e-3) + 0.05 * rms(b)
+
+
 @pytest.mark.parametrize("op,T,K,N", [(0, 401536, 96, 384), (0, 100480, 192, 576), (0, 100480, 192, 768), (0, 50001, 96, 288),
                                        (0, 4001, 96, 96), (0, 777, 192, 192), (0, 130, 96, 200), (0, 9, 192, 8),
                                        (0, 100003, 384, 96), (0, 50001, 768, 192), (1, 401536, 288, 96), (1, 100003, 384, 96),

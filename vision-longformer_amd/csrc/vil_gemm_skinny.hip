@@ -16,17 +16,32 @@
 
 struct SkParams {
   const void* in; const void* w; const void* bias; void* out;
+  void* out2;                 // GELU instantiations: gelu(out), same layout
   int T, K, N;
   int in_rs, out_rs;          // row strides (elements)
   int wn, wt;                 // waves along n (32 * NP features each) x waves along t
   int ntiles;                 // ceil(T / RT)
 };
 
+// exact (erf) GELU of nn.GELU() (reference msvit.py:21): x Phi(x), erfc by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7);
+// the negative side is x erfc(|z|) / 2 directly -- no 1 - erf cancellation, the sign of the result is the sign of x
+__device__ __forceinline__ float sk_gelu(float x) {
+  const float z = x * 0.70710678118654752f, az = __builtin_fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, az, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(-(z * z) * LOG2E);
+  float q = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  q = __builtin_fmaf(q, t, 1.421413741f);
+  q = __builtin_fmaf(q, t, -0.284496736f);
+  q = __builtin_fmaf(q, t, 0.254829592f);
+  const float hc = 0.5f * (q * t) * e;                    // erfc(|z|) / 2
+  return x * (x < 0.f ? hc : 1.0f - hc);
+}
+
 __device__ __forceinline__ int sk_off(int row, int colb) { return row * 128 + (colb ^ (((row >> 1) & 3) << 5)); }
 
 // KS = K / 32; NP = tile pairs (32 output features each) per wave; TT = 16-row column tiles per inner chunk; RT = token
 // rows per tile (ring slot); NSLOT ring slots.  Registers: weights 8 NP KS, accumulators 8 NP TT, (+ 4 TT, + 4 NP).
-template <int KS, int NP, int TT, int RT, int NSLOT, bool NN>
+template <int KS, int NP, int TT, int RT, int NSLOT, bool NN, bool GELU = false>
 __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
   typedef __bf16 T_;
   typedef typename V16<T_>::x8 X8;
@@ -179,6 +194,13 @@ __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
                   o[4 + r] = (T_)(acc[pr][1][tt][r] + (float)bias8[pr][4 + r]);
                 }
                 *(X8*)(ob + (int64_t)t * p.out_rs + n8) = o;
+                if (GELU) {
+                  // the activation of the ROUNDED pre-activation, as the unfused pair (bf16 Linear output -> nn.GELU) computes it
+                  X8 a;
+#pragma unroll
+                  for (int r = 0; r < 8; ++r) a[r] = (T_)sk_gelu((float)o[r]);
+                  *(X8*)((T_*)p.out2 + (int64_t)t * p.out_rs + n8) = a;
+                }
               }
             }
           }
@@ -188,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
   }
 }
 
-template <int KS, int NP, int TT, int RT, int NSLOT, bool NN>
+template <int KS, int NP, int TT, int RT, int NSLOT, bool NN, bool GELU = false>
 static int sk_launch(SkParams& p, int ncu, hipStream_t s) {
   p.wn = (p.N + 32 * NP - 1) / (32 * NP);
   if (p.wn > 8) return VIL_E_BACKEND;
@@ -202,8 +224,8 @@ static int sk_launch(SkParams& p, int ncu, hipStream_t s) {
   const int wg_per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
   int grid = ncu * wg_per_cu;
   if (grid > p.ntiles) grid = p.ntiles;
-  if (int he = vil_ensure_dyn_lds((const void*)k_skinny<KS, NP, TT, RT, NSLOT, NN>, lds)) return he;
-  k_skinny<KS, NP, TT, RT, NSLOT, NN><<<dim3(grid), dim3(64 * p.wn * p.wt), lds, s>>>(p);
+  if (int he = vil_ensure_dyn_lds((const void*)k_skinny<KS, NP, TT, RT, NSLOT, NN, GELU>, lds)) return he;
+  k_skinny<KS, NP, TT, RT, NSLOT, NN, GELU><<<dim3(grid), dim3(64 * p.wn * p.wt), lds, s>>>(p);
   return (int)hipGetLastError();
 }
 
@@ -239,7 +261,7 @@ extern "C" int vil_gemm_skinny_bf16(int op, const void* in, const void* w, const
       (bias && ((uintptr_t)bias & 15))) return VIL_E_ALIGN;
   if ((T + 128) * in_row_stride * 2 >= (1ll << 31)) return VIL_E_BACKEND;
   SkParams p;
-  p.in = in; p.w = w; p.bias = bias; p.out = out;
+  p.in = in; p.w = w; p.bias = bias; p.out = out; p.out2 = nullptr;
   p.T = (int)T; p.K = K; p.N = N;
   p.in_rs = (int)in_row_stride; p.out_rs = (int)out_row_stride;
   const int ncu = sk_cu_count();
@@ -255,4 +277,24 @@ extern "C" int vil_gemm_skinny_bf16(int op, const void* in, const void* w, const
   SK_CASE(768, 24, 1, 2, 32, 3)
 #undef SK_CASE
   return VIL_E_BACKEND;
+}
+
+// out[T][N] = in[T][K] . w[N][K]^T + bias[N] and act[T][N] = gelu(out) (exact erf form, of the rounded bf16 out) in ONE
+// launch: fc1 of the MLP block with nn.GELU in its epilogue (reference msvit.py:17-34).  K = 96 / 192 only (the stages
+// whose fc1 this kernel family serves); the two outputs share the row stride.
+extern "C" int vil_gemm_skinny_gelu_bf16(const void* in, const void* w, const void* bias, void* out, void* act, int64_t T, int K,
+                                         int N, int64_t in_row_stride, int64_t out_row_stride, void* stream) {
+  if (!in || !w || !out || !act) return VIL_E_NULL;
+  if (T <= 0 || K <= 0 || N <= 0) return VIL_E_SHAPE;
+  if ((N & 7) || N > 768 || (K != 96 && K != 192)) return VIL_E_BACKEND;
+  if ((in_row_stride & 7) || (out_row_stride & 7) || (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out | (uintptr_t)act) & 15) ||
+      (bias && ((uintptr_t)bias & 15))) return VIL_E_ALIGN;
+  if ((T + 128) * in_row_stride * 2 >= (1ll << 31)) return VIL_E_BACKEND;
+  SkParams p;
+  p.in = in; p.w = w; p.bias = bias; p.out = out; p.out2 = act;
+  p.T = (int)T; p.K = K; p.N = N;
+  p.in_rs = (int)in_row_stride; p.out_rs = (int)out_row_stride;
+  const int ncu = sk_cu_count();
+  hipStream_t s = (hipStream_t)stream;
+  return K == 96 ? sk_launch<3, 3, 4, 128, 2, false, true>(p, ncu, s) : sk_launch<6, 3, 2, 128, 3, false, true>(p, ncu, s);
 }

@@ -88,6 +88,8 @@ def _wgrad(dy2, x2, want_db):
 
 _SKINNY_MIN_T = 8192          # tokens from which the weights-in-registers forward kernel is taken (tools/gemm_bench.py)
 _SKINNY_FORCE = False
+_GELU_EPILOGUE_MAX_K = 96     # fc1 + GELU in one launch up to this K (0: never).  In-step A/B (tools/ab_bench.py, profiles/r03_ab_gelu_epilogue.txt):
+                              # K = 96 gains 0.04 (ViL-Small) / 0.1 ms (Medium-Deep) per step; with K = 192 included the step is 0.05 ms slower
 
 
 def _gemm_skinny(op, inp2, w, bias):
@@ -113,6 +115,30 @@ def _gemm_skinny(op, inp2, w, bias):
         return None
     _lib.check(rc)
     return out
+
+
+def _gemm_skinny_gelu(inp2, w, bias):
+    """(h, gelu(h)) with h = inp2 @ w.T + bias in one launch (vil_gemm_skinny_gelu_bf16: fc1 of the MLP block with the
+    exact GELU in its epilogue), or None outside the kernel's contract (K = 96 / 192, N <= 768, many tokens)."""
+    T, K = inp2.shape
+    N = w.shape[0]
+    if not (K <= _GELU_EPILOGUE_MAX_K and K in (96, 192) and N <= 768 and N % 8 == 0 and (T >= _SKINNY_MIN_T or _SKINNY_FORCE)
+            and inp2.is_cuda and inp2.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.is_contiguous()
+            and w.shape[1] == K and inp2.stride(1) == 1 and inp2.stride(0) % 8 == 0
+            and inp2.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.data_ptr() % 16 == 0))):
+        return None
+    import ctypes
+    from . import _lib
+    both = torch.empty(2, T, N, dtype=torch.bfloat16, device=inp2.device)
+    vp = ctypes.c_void_p
+    rc = _lib.lib().vil_gemm_skinny_gelu_bf16(vp(inp2.data_ptr()), vp(w.data_ptr()), vp(bias.data_ptr()) if bias is not None else None,
+                                              vp(both[0].data_ptr()), vp(both[1].data_ptr()), T, K, N, inp2.stride(0), N,
+                                              vp(torch.cuda.current_stream(inp2.device).cuda_stream))
+    if rc == _lib.VIL_E_BACKEND:
+        return None
+    _lib.check(rc)
+    return both[0], both[1]
 
 
 _GEMM_WS = {}
@@ -208,6 +234,33 @@ class _SplitKLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LinearGeluOutFn(torch.autograd.Function):
+    """(h, a) = (x W^T + b, gelu(h)): fc1 of the MLP block with nn.GELU() in the GEMM's epilogue where the
+    weights-in-registers kernel serves the shape (stages 1-2), Linear + F.gelu otherwise.  a is NOT differentiable here:
+    it feeds _GeluLinearFn, whose backward returns the gradient with respect to h (GELU derivative included)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        x2 = x.reshape(-1, x.shape[-1])
+        both = _gemm_skinny_gelu(x2, weight, bias) if x.is_cuda else None
+        if both is not None:
+            h, a = (t.view(*x.shape[:-1], weight.shape[0]) for t in both)
+        else:
+            h = _fwd_gemm(x2, weight, bias) if x.is_cuda else None
+            h = F.linear(x, weight, bias) if h is None else h.view(*x.shape[:-1], weight.shape[0])
+            a = F.gelu(h)
+        ctx.mark_non_differentiable(a)
+        return h, a
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dh, _da):
+        return _SplitKLinearFn.backward(ctx, dh)
+
+
 # The fused kernel re-streams its operands per 128 x 128 tile through a two-slot ring: where the GEMM is HBM-bound (the
 # MLPs of stages 1-2) it beats library GEMM + gelu_backward -- K = C = 96: 237 vs 374 us at ViL-Small's 401 536 tokens,
 # 164 vs 245 us at Medium-Deep's; K = 192: 144 vs 168 us -- at K = 384 it ties (94 vs 95) and at K = 768 it loses
@@ -246,8 +299,9 @@ class _GeluLinearFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, h, weight, bias):
-        a = F.gelu(h)
+    def forward(ctx, h, weight, bias, a=None):
+        if a is None:
+            a = F.gelu(h)
         ctx.save_for_backward(h, a, weight)
         ctx.has_bias = bias is not None
         a2 = a.reshape(-1, a.shape[-1])
@@ -275,25 +329,40 @@ class _GeluLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             fused = _wgrad(dy2, a2, want_db)
             if fused is not None:
-                return dh, fused[0].to(weight.dtype), (fused[1] if want_db else None)
+                return dh, fused[0].to(weight.dtype), (fused[1] if want_db else None), None
             dw = dy2.t() @ a2
         if want_db:
             db = _colsum(dy2)
-        return dh, dw, db
+        return dh, dw, db, None
 
 
-def vil_gelu_linear(h, weight, bias):
+def vil_gelu_linear(h, weight, bias, a=None):
     """F.linear(F.gelu(h), weight, bias) (exact GELU) whose backward fuses the GELU derivative into the input-gradient
-    GEMM; same autocast semantics as vil_linear."""
+    GEMM; same autocast semantics as vil_linear.  a: gelu(h) when the caller already has it (vil_linear_gelu)."""
     if h.is_cuda and torch.is_grad_enabled():
         if torch.is_autocast_enabled("cuda"):
             dt = torch.get_autocast_dtype("cuda")
             h, w = h.to(dt), weight.to(dt)
             b = bias.to(dt) if bias is not None else None
             with torch.autocast("cuda", enabled=False):
-                return _GeluLinearFn.apply(h, w, b)
-        return _GeluLinearFn.apply(h, weight, bias)
-    return F.linear(F.gelu(h), weight, bias)
+                return _GeluLinearFn.apply(h, w, b, a.to(dt) if a is not None else None)
+        return _GeluLinearFn.apply(h, weight, bias, a)
+    return F.linear(F.gelu(h) if a is None else a, weight, bias)
+
+
+def vil_linear_gelu(x, weight, bias):
+    """(h, gelu(h)) with h = F.linear(x, weight, bias): the head of the MLP block (reference msvit.py:29-31) as one
+    autograd node -- one launch where the weights-in-registers GEMM serves the shape.  Feed both to vil_gelu_linear."""
+    if x.is_cuda and torch.is_grad_enabled():
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            x, w = x.to(dt), weight.to(dt)
+            b = bias.to(dt) if bias is not None else None
+            with torch.autocast("cuda", enabled=False):
+                return _LinearGeluOutFn.apply(x, w, b)
+        return _LinearGeluOutFn.apply(x, weight, bias)
+    h = F.linear(x, weight, bias)
+    return h, F.gelu(h)
 
 
 def vil_linear(x, weight, bias):

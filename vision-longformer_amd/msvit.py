@@ -21,7 +21,7 @@ from .longformer2d import Long2DSCSelfAttention, _trunc_normal_
 from .ops import vil_dense_attention, dense_family_supported, FULL_MAX_G
 from .layernorm import (VilLayerNorm, res_layernorm, res_layernorm_ok, tokens_layernorm, tokens_layernorm_ok,
                         pass_layernorm, pass_layernorm_ok)
-from .linear import VilLinear, vil_linear, vil_gelu_linear, expand_rows
+from .linear import VilLinear, vil_linear, vil_gelu_linear, vil_linear_gelu, expand_rows
 
 
 class DropPath(nn.Module):
@@ -142,9 +142,11 @@ class Mlp(nn.Module):
 
     def forward(self, x):
         if isinstance(self.act, nn.GELU) and self.act.approximate == "none" and (self.drop.p == 0.0 or not self.training):
+            # fc1 with the GELU in its epilogue where the weights-in-registers GEMM serves the shape (csrc/vil_gemm_skinny.hip),
             # fc2 with the GELU in front of it as one autograd node: its input gradient is ONE launch (dgrad GEMM with the
             # erf-GELU backward in the epilogue, csrc/vil_gemm_fused.hip)
-            return vil_gelu_linear(self.fc1(x), self.fc2.weight, self.fc2.bias)
+            h, a = vil_linear_gelu(x, self.fc1.weight, self.fc1.bias)
+            return vil_gelu_linear(h, self.fc2.weight, self.fc2.bias, a)
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 
