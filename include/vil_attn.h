@@ -159,6 +159,12 @@ int vil_attn_bwd_full(const VilAttnDesc* d, const void* q_all, const void* k, co
  * N % 128 == 0; VIL_E_BACKEND outside that contract. */
 int vil_gemm_dgelu_bf16(const void* dy, const void* w, const void* h, void* dh, int64_t T, int K, int N,
                         int64_t dy_row_stride, int64_t h_row_stride, int64_t dh_row_stride, void* stream);
+/* The forward counterpart: fc1 with nn.GELU() in its epilogue (reference msvit.py:29-31),
+ *   h[t][n] = sum_k x[t][k] * w[n][k] + bias[n],   a[t][n] = gelu(h[t][n])  (exact erf form, of the rounded bf16 h)
+ * one launch that writes both (the unfused pair writes h, reads it again and writes a).  w = fc1.weight (N rows of K),
+ * bias may be NULL; h and a share out_row_stride.  Same contract as vil_gemm_dgelu_bf16. */
+int vil_gemm_gelu_bf16(const void* x, const void* w, const void* bias, void* h, void* a, int64_t T, int K, int N,
+                       int64_t x_row_stride, int64_t out_row_stride, void* stream);
 
 /* ---- nn.Linear forward (op 0) / input gradient (op 1) of the projections with a huge token count and a small weight
  * matrix (stages 1-2 of ViL; reference msvit.py:17-34, 91-120, layers/longformer2d.py:47-62):

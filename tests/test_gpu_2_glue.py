@@ -398,6 +398,32 @@ def test_skinny_gemm_gelu_epilogue(dev, T, K, N):
         linear._GELU_EPILOGUE_MAX_K = cap
 
 
+@pytest.mark.parametrize("T,K,N", [(25216, 384, 1536), (6400, 768, 3072), (100480, 192, 768), (40001, 96, 384), (1031, 160, 128)])
+def test_tile_gemm_gelu_epilogue_vs_fp64(dev, T, K, N):
+    """vil_gemm_gelu_bf16 (128 x 128 tiles, weight rows permuted by the DMA so that a lane owns 8 consecutive features):
+    h = x W^T + b against fp64 on sampled rows, a = gelu of the rounded h to bf16 rounding + the erfc approximation's
+    4e-7; ragged last tile, K not a multiple of the 64-deep ring block, strided x, no bias"""
+    from vision_longformer_amd import linear
+    from vision_longformer_amd.linear import _gemm_tile_gelu
+    old, linear._GELU_TILE_MIN_K = linear._GELU_TILE_MIN_K, 32
+    try:
+        g = torch.Generator().manual_seed(41)
+        wide = torch.randn(T, K + 40, generator=g).bfloat16().to(dev)
+        x = wide[:, 40:]
+        w = (torch.randn(N, K, generator=g) * 0.15).bfloat16().to(dev)
+        b = torch.randn(N, generator=g).bfloat16().to(dev)
+        rows = torch.cat([torch.arange(0, 300), torch.arange(T - 300, T), torch.randint(0, T, (200,), generator=g)]).unique()
+        for bias in (b, None):
+            h, a = _gemm_tile_gelu(x, w, bias)
+            want = x[rows].double() @ w.double().t() + (bias.double() if bias is not None else 0)
+            assert (h[rows].double() - want).abs().max().item() <= 1.2e-2 * max(1.0, want.abs().max().item())
+            ga = torch.nn.functional.gelu(h.double())
+            assert bool(((a.double() - ga).abs() <= ga.abs() * 2.0 ** -8 + 4e-7).all())
+            assert bool((a.float() * h.float() >= 0).all())
+    finally:
+        linear._GELU_TILE_MIN_K = old
+
+
 @pytest.mark.parametrize("B,N,C", [(3, 3137, 96), (2, 785, 192)])
 def test_mlp_block_with_gelu_epilogue_matches_unfused(dev, B, N, C):
     """msvit.Mlp with fc1 + GELU as ONE launch (vil_linear_gelu -> vil_gemm_skinny_gelu_bf16) against the same module

@@ -162,6 +162,153 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_dgelu(DgParams p) {
   }
 }
 
+// ---- fc1 with nn.GELU() in its epilogue (reference msvit.py:29-31): h = x W^T + b, a = gelu(h), both written once.
+// Same tiling and ring as k_dgrad_dgelu; here BOTH operands are k-contiguous (x[t][k], w[n][k]), so both are plain
+// 16-byte fragment reads of the swizzled image.  The 8-consecutive-features-per-lane mapping is made by the DMA: LDS row
+// 16 nt + j of a wave's 64-row half holds weight row 32 (nt / 2) + 8 (j / 4) + 4 (nt % 2) + j % 4.
+struct FgParams {
+  const void* x; const void* w; const void* bias; void* h; void* a;
+  int T, K, N;
+  int x_rs, o_rs;              // row strides, elements
+  int nn_tiles;                // N / 128
+};
+
+__device__ __forceinline__ float gelu_fwd(float x) {
+  const float z = x * 0.70710678118654752f, az = __builtin_fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, az, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(-(z * z) * LOG2E);
+  float q = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  q = __builtin_fmaf(q, t, 1.421413741f);
+  q = __builtin_fmaf(q, t, -0.284496736f);
+  q = __builtin_fmaf(q, t, 0.254829592f);
+  const float hc = 0.5f * (q * t) * e;                    // erfc(|z|) / 2: the negative side has no 1 - erf cancellation
+  return x * (x < 0.f ? hc : 1.0f - hc);
+}
+
+__global__ __launch_bounds__(256, 2) void k_fwd_gelu(FgParams p) {
+  typedef __bf16 T_;
+  typedef typename V16<T_>::x8 X8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lj = lane & 15, lg = lane >> 4;
+  const int wt = wave & 1, wn = wave >> 1;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_t = logical / p.nn_tiles, tile_n = logical - tile_t * p.nn_tiles;
+  const int t0 = tile_t * 128, n0 = tile_n * 128;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc_n(p.x, (unsigned)(((int64_t)(p.T - 1) * p.x_rs + p.K) * 2));
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc_n(p.w, (unsigned)((int64_t)p.N * p.K * 2));
+  const int drow = lane >> 3, dchunk = (lane & 7) ^ (((drow >> 1) & 3) << 1);
+  const int x_v0 = (t0 + drow) * (p.x_rs * 2) + dchunk * 16;
+  int w_v[2];                                              // weight row of LDS row 8 q + drow, q even / odd (see above)
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int j = par * 8 + drow;                          // row within a 16-row tile
+    w_v[par] = (n0 + 8 * (j >> 2) + (j & 3)) * (p.K * 2) + dchunk * 16;
+  }
+  auto issue = [&](int kb, int slot) {
+    char* base = smem + slot * GF_SLOT;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int pc = wave + 4 * u;                         // 32 one-kilobyte pieces, 8 per wave
+      if (pc < 16)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(base + pc * 1024), 16,
+                                                 x_v0 + pc * 8 * (p.x_rs * 2) + kb * 128, 0, 0, 0);
+      else {
+        const int q = pc - 16, nt = q >> 1;                // LDS rows 8 q .. 8 q + 7 = rows 8 (q & 1) .. of tile nt (0..7)
+        const int frow = (nt >> 2) * 64 + ((nt >> 1) & 1) * 32 + (nt & 1) * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(base + pc * 1024), 16,
+                                                 ((q & 1) ? w_v[1] : w_v[0]) + frow * (p.K * 2) + kb * 128, 0, 0, 0);
+      }
+    }
+  };
+
+  const int nkb = (p.K + 63) >> 6;
+  issue(0, 0);
+  X8 bias8[2];
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    X8 z = {};
+    bias8[pr] = p.bias ? *(const X8*)((const T_*)p.bias + n0 + wn * 64 + pr * 32 + lg * 8) : z;
+  }
+  int nat[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) nat[ks] = gf_off(lj, ks * 64 + lg * 16);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    if (kb + 1 < nkb) issue(kb + 1, (kb + 1) & 1);
+    const char* xb = smem + (kb & 1) * GF_SLOT + wt * (64 * 128);
+    const char* wb = smem + (kb & 1) * GF_SLOT + 16 * 1024 + wn * (64 * 128);
+    const int nks = min(2, (p.K - kb * 64) >> 5);
+    for (int ks = 0; ks < nks; ++ks) {
+      X8 a[4], bq[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) a[nt] = *(const X8*)(wb + nt * (16 * 128) + (ks ? nat[1] : nat[0]));
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) bq[tt] = *(const X8*)(xb + tt * (16 * 128) + (ks ? nat[1] : nat[0]));
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[nt][tt] = mfma16(a[nt], bq[tt], acc[nt][tt]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (j, g), pair pr, column tile tt: token t0 + 64 wt + 16 tt + j, features n0 + 64 wn + 32 pr + 8 g .. +7
+  T_* hb = (T_*)p.h;
+  T_* ab = (T_*)p.a;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int t = t0 + wt * 64 + tt * 16 + lj;
+    if (t < p.T) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        X8 o8, a8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o8[r] = (T_)(acc[2 * pr][tt][r] + (float)bias8[pr][r]);
+          o8[4 + r] = (T_)(acc[2 * pr + 1][tt][r] + (float)bias8[pr][4 + r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a8[r] = (T_)gelu_fwd((float)o8[r]);       // GELU of the rounded pre-activation
+        const int64_t o = (int64_t)t * p.o_rs + n0 + wn * 64 + pr * 32 + lg * 8;
+        *(X8*)(hb + o) = o8;
+        *(X8*)(ab + o) = a8;
+      }
+    }
+  }
+}
+
+// h[T][N] = x[T][K] . w[N][K]^T + bias[N], a = gelu(h) (exact erf form, of the rounded bf16 h); bf16, row strides in
+// elements (h and a share theirs).  K % 32 == 0, N % 128 == 0; VIL_E_BACKEND outside that contract.
+extern "C" int vil_gemm_gelu_bf16(const void* x, const void* w, const void* bias, void* h, void* a, int64_t T, int K, int N,
+                                  int64_t x_row_stride, int64_t out_row_stride, void* stream) {
+  if (!x || !w || !h || !a) return VIL_E_NULL;
+  if (T <= 0 || K <= 0 || N <= 0) return VIL_E_SHAPE;
+  if ((K & 31) || (N & 127)) return VIL_E_BACKEND;
+  if ((x_row_stride & 7) || (out_row_stride & 7) || (((uintptr_t)x | (uintptr_t)w | (uintptr_t)h | (uintptr_t)a) & 15) ||
+      (bias && ((uintptr_t)bias & 15))) return VIL_E_ALIGN;
+  if (x_row_stride < K || out_row_stride < N) return VIL_E_SHAPE;
+  if ((T + 128) * x_row_stride * 2 >= (1ll << 31) || (int64_t)K * N * 2 >= (1ll << 31) || T * (N / 128) >= (1ll << 30)) return VIL_E_BACKEND;
+  FgParams p;
+  p.x = x; p.w = w; p.bias = bias; p.h = h; p.a = a;
+  p.T = (int)T; p.K = K; p.N = N;
+  p.x_rs = (int)x_row_stride; p.o_rs = (int)out_row_stride;
+  p.nn_tiles = N / 128;
+  const unsigned grid = (unsigned)(((T + 127) / 128) * p.nn_tiles);
+  const size_t lds = 2 * GF_SLOT;
+  if (int he = vil_ensure_dyn_lds((const void*)k_fwd_gelu, lds)) return he;
+  k_fwd_gelu<<<dim3(grid), dim3(256), lds, (hipStream_t)stream>>>(p);
+  return (int)hipGetLastError();
+}
+
 // dh[T][N] = (dy[T][K] . w[K][N]) * gelu'(h[T][N]); bf16, row strides in elements.  K % 32 == 0, N % 128 == 0, 16-byte
 // aligned bases and rows; VIL_E_BACKEND when the problem is outside the kernel's contract (the caller
 // then runs the GEMM and the GELU backward separately).

@@ -141,6 +141,33 @@ def _gemm_skinny_gelu(inp2, w, bias):
     return both[0], both[1]
 
 
+_GELU_TILE_MIN_K = 192        # fc1 + GELU through the 128 x 128 tile kernel (vil_gemm_gelu_bf16) from this K on (0: never)
+
+
+def _gemm_tile_gelu(inp2, w, bias):
+    """(h, gelu(h)) with h = inp2 @ w.T + bias in one launch of the tiled kernel (vil_gemm_gelu_bf16, csrc/vil_gemm_fused.hip),
+    or None outside its contract."""
+    T, K = inp2.shape
+    N = w.shape[0]
+    if not (_GELU_TILE_MIN_K and K >= _GELU_TILE_MIN_K and K % 32 == 0 and N % 128 == 0 and T >= 1024
+            and inp2.is_cuda and inp2.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.is_contiguous()
+            and w.shape[1] == K and inp2.stride(1) == 1 and inp2.stride(0) % 8 == 0
+            and inp2.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and (bias is None or (bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.data_ptr() % 16 == 0))):
+        return None
+    import ctypes
+    from . import _lib
+    both = torch.empty(2, T, N, dtype=torch.bfloat16, device=inp2.device)
+    vp = ctypes.c_void_p
+    rc = _lib.lib().vil_gemm_gelu_bf16(vp(inp2.data_ptr()), vp(w.data_ptr()), vp(bias.data_ptr()) if bias is not None else None,
+                                       vp(both[0].data_ptr()), vp(both[1].data_ptr()), T, K, N, inp2.stride(0), N,
+                                       vp(torch.cuda.current_stream(inp2.device).cuda_stream))
+    if rc == _lib.VIL_E_BACKEND:
+        return None
+    _lib.check(rc)
+    return both[0], both[1]
+
+
 _GEMM_WS = {}
 _GEMM_TUNED = set()
 
@@ -246,6 +273,8 @@ class _LinearGeluOutFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         x2 = x.reshape(-1, x.shape[-1])
         both = _gemm_skinny_gelu(x2, weight, bias) if x.is_cuda else None
+        if both is None and x.is_cuda:
+            both = _gemm_tile_gelu(x2, weight, bias)
         if both is not None:
             h, a = (t.view(*x.shape[:-1], weight.shape[0]) for t in both)
         else:
@@ -265,7 +294,7 @@ class _LinearGeluOutFn(torch.autograd.Function):
 # MLPs of stages 1-2) it beats library GEMM + gelu_backward -- K = C = 96: 237 vs 374 us at ViL-Small's 401 536 tokens,
 # 164 vs 245 us at Medium-Deep's; K = 192: 144 vs 168 us -- at K = 384 it ties (94 vs 95) and at K = 768 it loses
 # (78 vs 67): tools/mlp_bench.py.  The product takes it where it wins.
-_DGELU_MAX_K = 192
+_DGELU_MAX_K = 384
 _DGELU_FORCE = False          # tools / tests: run the fused kernel at every shape it accepts
 
 
