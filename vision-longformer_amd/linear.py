@@ -141,7 +141,8 @@ def _gemm_skinny_gelu(inp2, w, bias):
     return both[0], both[1]
 
 
-_GELU_TILE_MIN_K = 192        # fc1 + GELU through the 128 x 128 tile kernel (vil_gemm_gelu_bf16) from this K on (0: never)
+_GELU_TILE_MIN_K = 384        # fc1 + GELU through the 128 x 128 tile kernel (vil_gemm_gelu_bf16) from this K on (0: never); in-step A/B:
+                              # profiles/r03_ab_gelu_epilogue.txt
 
 
 def _gemm_tile_gelu(inp2, w, bias):
@@ -290,11 +291,11 @@ class _LinearGeluOutFn(torch.autograd.Function):
         return _SplitKLinearFn.backward(ctx, dh)
 
 
-# The fused kernel re-streams its operands per 128 x 128 tile through a two-slot ring: where the GEMM is HBM-bound (the
-# MLPs of stages 1-2) it beats library GEMM + gelu_backward -- K = C = 96: 237 vs 374 us at ViL-Small's 401 536 tokens,
-# 164 vs 245 us at Medium-Deep's; K = 192: 144 vs 168 us -- at K = 384 it ties (94 vs 95) and at K = 768 it loses
-# (78 vs 67): tools/mlp_bench.py.  The product takes it where it wins.
-_DGELU_MAX_K = 384
+# The fused kernel re-streams its operands per 128 x 128 tile through a two-slot ring.  Kernels alone (tools/mlp_bench.py) it
+# beats library GEMM + gelu_backward at K = 96 / 192 (195 vs 371 us at ViL-Small's 401 536 tokens, 115 vs 161 us), is level
+# at K = 384 and behind at K = 768; INSIDE the training step it wins at every K (tools/ab_bench.py, same box, alternating:
+# -0.20 ms per ViL-Small step from K = 384, -0.05 ms more from K = 768; profiles/r03_ab_dgelu_k.txt).
+_DGELU_MAX_K = 768
 _DGELU_FORCE = False          # tools / tests: run the fused kernel at every shape it accepts
 
 
