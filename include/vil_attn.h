@@ -23,10 +23,8 @@
  * synchronise -- the two documented exceptions synchronise by design:
  * vil_gemm_tune and vil_attn_profile_end.  Process-global state: the
  * profiling sink, the GEMM plan cache (both described at their entry points) and the record of which kernels
- * already had their dynamic-LDS limit raised.  Two environment variables are read, for measurements only:
- * VIL_WGRAD2 (pins vil_linear_wgrad's plan: "0" = the 128 x 128 kernel, "m,mi,nj" = slices per XCD and tile of the
- * second-generation kernel; read per call) and VIL_DEBUG_KV_LDS_PAD (unused LDS bytes added to the dK/dV launch to
- * lower its residency; read once).  Return value: 0 = success, negative = argument error
+ * already had their dynamic-LDS limit raised.  One environment variable is read once, for measurements only:
+ * VIL_DEBUG_KV_LDS_PAD (unused LDS bytes added to the dK/dV launch to lower its residency).  Return value: 0 = success, negative = argument error
  * (VIL_E_*), positive = hipError_t of the failing launch.
  *
  * Tensor layout: q is addressed as q[b*q_sb + i*q_st + h*q_sh + d] with
@@ -314,6 +312,11 @@ int vil_linear_wgrad(const void* dy, const void* x, int64_t T, int CO, int CI, i
                      void* dw, void* db, int out_bf16, void* workspace, void* stream);
 int vil_linear_wgrad_tune(const void* dy, const void* x, int64_t T, int CO, int CI, int64_t dy_stride, int64_t x_stride,
                           void* dw, void* db, int out_bf16, void* workspace, void* stream);
+/* Writes the plan cache entry of a problem directly -- gen 1: the 128 x 128 kernel; gen 2: tile 32 mi x 32 nj (mi, nj in
+ * {3, 6}, dividing CO / CI), m token slices per XCD (clamped to what the workspace bound allows); gen 0: erase, back to
+ * the cost model.  For restoring an earlier selection, measurements and tests.  VIL_E_SHAPE for a plan that does not
+ * fit the problem. */
+int vil_linear_wgrad_set_plan(int64_t T, int CO, int CI, int gen, int mi, int nj, int m);
 
 /* ---- fused residual add + LayerNorm on the fp32 residual stream (block glue of msvit.py:313-316,336-340:
  * `x = x + drop_path(branch)` of one block fused with `norm(x)` of the next).  Contiguous (rows, C) tensors.

@@ -75,6 +75,8 @@ def test_glue_entry_points_validate_before_launching():
     assert L.vil_linear_wgrad(a16, vp(4100), 64, 8, 8, 8, 8, a16, None, 1, a16, None) == -8
     assert L.vil_linear_wgrad_workspace_bytes(25216, 1536, 384) > 1536 * 384 * 4
     assert L.vil_linear_wgrad_tune(None, a16, 64, 8, 8, 8, 8, a16, None, 1, a16, None) == -1
+    assert L.vil_linear_wgrad_set_plan(4096, 192, 96, 2, 6, 3, 4) == 0 and L.vil_linear_wgrad_set_plan(4096, 192, 96, 0, 0, 0, 0) == 0
+    assert L.vil_linear_wgrad_set_plan(4096, 192, 96, 2, 6, 6, 4) == L.vil_linear_wgrad_set_plan(4096, 192, 96, 3, 0, 0, 0) < 0
     assert L.vil_linear_wgrad_tune(a16, a16, 64, 8, 12, 8, 16, a16, None, 1, a16, None) == -8
     assert L.vil_gemm_bf16(0, None, a16, None, a16, 8, 8, 8, 8, 8, a16, 1 << 20, None) == -1
     assert L.vil_gemm_bf16(3, a16, a16, None, a16, 8, 8, 8, 8, 8, a16, 1 << 20, None) == -2

@@ -104,7 +104,7 @@ def test_linear_wgrad_fused(dev, T, CO, CI):
 
 
 def _wgrad_f32(dy, x, want_db=True):
-    """vil_linear_wgrad with fp32 outputs, straight through the C ABI (the plan is whatever VIL_WGRAD2 / the cache says)."""
+    """vil_linear_wgrad with fp32 outputs, straight through the C ABI (the plan is whatever the plan cache says)."""
     import ctypes
     from vision_longformer_amd import _lib
     L = _lib.lib()
@@ -122,7 +122,7 @@ def _wgrad_f32(dy, x, want_db=True):
 
 
 @pytest.mark.parametrize("T,CO,CI", [(20011, 384, 192), (9000, 192, 96), (5003, 96, 96), (12345, 96, 384), (3100, 768, 576), (1500, 288, 480)])
-def test_linear_wgrad_every_plan(dev, T, CO, CI, monkeypatch):
+def test_linear_wgrad_every_plan(dev, T, CO, CI):
     """Every plan of the second-generation weight-gradient kernel (tile 96/192 x 96/192, 1 .. max token slices per XCD:
     LDS-DMA ring with out-of-range stages, swizzled transposed reads, accumulator-order partial records, the reduce
     pass) and the 128 x 128 kernel: fp32 outputs against fp64 at fp32-accumulation tolerance, ragged last slice,
@@ -134,11 +134,14 @@ def test_linear_wgrad_every_plan(dev, T, CO, CI, monkeypatch):
     want = (dy.double().t() @ x.double()).cpu()
     wdb = dy.double().sum(0).cpu()
     scale, sdb = want.abs().max().item(), max(1.0, wdb.abs().max().item())
-    plans = ["0"] + [f"{m},{mi},{nj}" for mi in (3, 6) for nj in (3, 6) if CO % (32 * mi) == 0 and CI % (32 * nj) == 0
-                     for m in (1, 3, 64)]
+    from vision_longformer_amd import _lib
+    L = _lib.lib()
+    plans = [(1, 0, 0, 0)] + [(2, mi, nj, m) for mi in (3, 6) for nj in (3, 6) if CO % (32 * mi) == 0 and CI % (32 * nj) == 0
+                              for m in (1, 3, 64)]
     assert len(plans) > 3
+    assert L.vil_linear_wgrad_set_plan(T, CO, CI, 2, 5, 3, 1) == _lib.VIL_E_SHAPE
     for plan in plans:
-        monkeypatch.setenv("VIL_WGRAD2", plan)
+        _lib.check(L.vil_linear_wgrad_set_plan(T, CO, CI, *plan))
         dw, db = _wgrad_f32(dy, x)
         assert (dw.double().cpu() - want).abs().max().item() <= 2e-5 * scale, plan
         assert (db.double().cpu() - wdb).abs().max().item() <= 2e-5 * sdb, plan
@@ -146,6 +149,7 @@ def test_linear_wgrad_every_plan(dev, T, CO, CI, monkeypatch):
         assert torch.equal(dw, dw2) and torch.equal(db, db2), plan
         dw3, _ = _wgrad_f32(dy, x, want_db=False)
         assert torch.equal(dw, dw3), plan
+    _lib.check(L.vil_linear_wgrad_set_plan(T, CO, CI, 0, 0, 0, 0))
 
 
 def test_linear_wgrad_tune_selects_a_plan(dev):

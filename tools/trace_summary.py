@@ -26,7 +26,8 @@ t0, t1 = int(rows[s0]["Start_Timestamp"]), int(rows[s1]["Start_Timestamp"])
 def classify(n):
     if n.startswith("Cijk"): return "gemm(hipblaslt)"
     if "k_mfma" in n or "k_delta" in n or "k_reduce" in n or "k_scalar" in n or "k_glo_" in n or "k_dense_" in n: return "vil hot path"
-    if "k_wgrad" in n or "k_dgrad_dgelu" in n or "k_colsum" in n: return "vil weight-gradient / fused GEMM"
+    if "k_wgrad" in n or "k_colsum" in n: return "vil weight gradient"
+    if "k_dgrad_dgelu" in n or "k_fwd_gelu" in n or "k_skinny" in n: return "vil GEMM (fused epilogue / weights in registers)"
     if "k_optim" in n: return "vil optimizer"
     if "k_patchify" in n or "k_sc2d" in n: return "vil glue"
     if "k_ln_" in n: return "vil layernorm"

@@ -1,11 +1,13 @@
 """GPU micro-benchmark of vil_linear_wgrad on the layer shapes of ViL-Small / Medium-Deep: time per call (weight + bias
-gradient and the reduce pass) and the error against fp64 on a column sample.  VIL_WGRAD2=0 selects the 128 x 128
-first-generation kernel, VIL_WGRAD2=m,mi,nj pins a second-generation plan (slices per XCD, tile 32 mi x 32 nj);
---sweep times every plan per shape (kernel and reduce pass separately, from the library's hipEvent sink) next to the
+gradient and the reduce pass) and the error against fp64 on a column sample, with the plan vil_linear_wgrad_tune selects;
+--sweep pins every plan in turn (vil_linear_wgrad_set_plan: the 128 x 128 kernel, tile 32 mi x 32 nj with m slices per
+XCD) and times it per shape (kernel and reduce pass separately, from the library's hipEvent sink) next to the
 plan vil_linear_wgrad_tune selects."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import ctypes
+from vision_longformer_amd import linear
 from vision_longformer_amd.linear import _wgrad
 
 dev = torch.device("cuda:0")
@@ -52,7 +54,9 @@ if sweep:
         g = torch.Generator().manual_seed(5)
         x = torch.randn(T, ci, generator=g).bfloat16().to(dev)
         dy = torch.randn(T, co, generator=g).bfloat16().to(dev)
-        os.environ["VIL_WGRAD2"] = "0"
+        _wgrad(dy, x, True)                                     # (tunes this problem; the selection is restored below)
+        L = _lib.lib()
+        _lib.check(L.vil_linear_wgrad_set_plan(T, co, ci, 1, 0, 0, 0))
         ref = _wgrad(dy, x, True)
         t0 = bench(lambda: _wgrad(dy, x, True))
         k0, r0 = split_times(lambda: _wgrad(dy, x, True))
@@ -65,7 +69,7 @@ if sweep:
                 for m in sorted({max(1, m0 // 4), max(1, m0 // 2), m0, m0 * 2}):
                     if 8 * m * co * ci * 4 > (96 << 20) or T // (8 * m * 32) < 4 or m > 64:
                         continue
-                    os.environ["VIL_WGRAD2"] = f"{m},{mi},{nj}"
+                    _lib.check(L.vil_linear_wgrad_set_plan(T, co, ci, 2, mi, nj, m))
                     out = _wgrad(dy, x, True)
                     err = float((out[0].float() - ref[0].float()).abs().max() / ref[0].float().abs().max())
                     t = bench(lambda: _wgrad(dy, x, True), n=10)
@@ -74,12 +78,14 @@ if sweep:
         res.sort()
         for t, m, mi, nj, k, r, err in res[:4]:
             print(f"           m {m:3d} tile {32*mi:3d}x{32*nj:3d}  {t:6.1f} us (kernel {k:5.1f} + reduce {r:4.1f})  diff {err:.1e}")
-        del os.environ["VIL_WGRAD2"]
-        t = bench(lambda: _wgrad(dy, x, True), n=10)       # (_wgrad tuned this problem at its first call above: the selected plan)
+        _lib.check(L.vil_linear_wgrad_tune(ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(x.data_ptr()), T, co, ci, co, ci,
+                                           ctypes.c_void_p(ref[0].data_ptr()), ctypes.c_void_p(ref[1].data_ptr()), 1,
+                                           ctypes.c_void_p(linear._WG_WS[dy.device].data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        t = bench(lambda: _wgrad(dy, x, True), n=10)
         print(f"           tuned plan                {t:6.1f} us")
     sys.exit(0)
 
-print("VIL_WGRAD2 =", os.environ.get("VIL_WGRAD2"))
 tot = 0.0
 for name, (T, ci, co) in shapes.items():
     if only and not any(name.startswith(o) for o in only):

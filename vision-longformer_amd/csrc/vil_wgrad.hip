@@ -11,7 +11,6 @@
 // A fragments already in registers.
 #include "vil_internal.h"
 #include <stdlib.h>
-#include <stdio.h>
 
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
@@ -528,24 +527,28 @@ static WgPlan wg2_default(int64_t T, int CO, int CI) {
 static std::mutex g_wg_mu;
 static std::map<std::tuple<int64_t, int, int>, WgPlan> g_wg_plans;      // problems vil_linear_wgrad_tune has measured
 
-// VIL_WGRAD2 (measurements only): "0" = gen 1 everywhere; "m,mi,nj" pins a gen-2 plan
 static WgPlan wgrad_choose(int64_t T, int CO, int CI, int64_t sdy, int64_t sx) {
   if (!wg2_ok(T, CO, CI, sdy, sx)) return WgPlan{1, 0, 0, 0};
-  if (const char* e = getenv("VIL_WGRAD2")) {
-    int m = 0, mi = 0, nj = 0;
-    const int k = sscanf(e, "%d,%d,%d", &m, &mi, &nj);
-    if (k >= 1 && m == 0) return WgPlan{1, 0, 0, 0};
-    if (k == 3 && (mi == 3 || mi == 6) && (nj == 3 || nj == 6) && CO % (32 * mi) == 0 && CI % (32 * nj) == 0 && m >= 1) {
-      const int mx = wg2_max_m(T, CO, CI);
-      return WgPlan{2, mi, nj, m > mx ? mx : m};
-    }
-  }
   {
     std::lock_guard<std::mutex> lk(g_wg_mu);
     auto it = g_wg_plans.find(std::make_tuple(T, CO, CI));
     if (it != g_wg_plans.end()) return it->second;
   }
   return wg2_default(T, CO, CI);
+}
+
+// Writes (gen 1 / 2) or erases (gen 0) the cached plan of a problem: what vil_linear_wgrad_tune stores.  For restoring
+// a selection made earlier, for measurements (tools/wgrad2_probe.py) and for the tests that walk every plan.
+extern "C" int vil_linear_wgrad_set_plan(int64_t T, int CO, int CI, int gen, int mi, int nj, int m) {
+  if (T <= 0 || CO <= 0 || CI <= 0 || gen < 0 || gen > 2) return VIL_E_SHAPE;
+  std::lock_guard<std::mutex> lk(g_wg_mu);
+  const auto key = std::make_tuple(T, CO, CI);
+  if (gen == 0) { g_wg_plans.erase(key); return 0; }
+  if (gen == 1) { g_wg_plans[key] = WgPlan{1, 0, 0, 0}; return 0; }
+  if ((mi != 3 && mi != 6) || (nj != 3 && nj != 6) || CO % (32 * mi) || CI % (32 * nj) || m < 1) return VIL_E_SHAPE;
+  const int mx = wg2_max_m(T, CO, CI);
+  g_wg_plans[key] = WgPlan{2, mi, nj, m > mx ? mx : m};
+  return 0;
 }
 
 template <int MI, int NJ>
