@@ -20,12 +20,13 @@
  * Conventions: plain pointers and sizes only; all device buffers (inputs,
  * outputs, workspace) are caller-owned; calls are asynchronous on `stream`
  * (a hipStream_t passed as void*), never allocate device memory and never
- * synchronise -- the two documented exceptions synchronise by design:
- * vil_gemm_tune and vil_attn_profile_end.  Process-global state: the
- * profiling sink, the GEMM plan cache (both described at their entry points) and the record of which kernels
- * already had their dynamic-LDS limit raised.  One environment variable is read once, for measurements only:
- * VIL_DEBUG_KV_LDS_PAD (unused LDS bytes added to the dK/dV launch to lower its residency).  Return value: 0 = success, negative = argument error
- * (VIL_E_*), positive = hipError_t of the failing launch.
+ * synchronise -- the documented exceptions synchronise by design:
+ * vil_gemm_tune, vil_linear_wgrad_tune and vil_attn_profile_end.  Process-global
+ * state: the profiling sink, the GEMM and weight-gradient plan caches (described
+ * at their entry points) and the record of which kernels already had their
+ * dynamic-LDS limit raised.  The library reads no environment variable.
+ * Return value: 0 = success, negative = argument error (VIL_E_*), positive =
+ * hipError_t of the failing launch.
  *
  * Tensor layout: q is addressed as q[b*q_sb + i*q_st + h*q_sh + d] with
  * i in [0, nx*ny) the local token (row-major r*ny+c), d in [0, M) contiguous.
