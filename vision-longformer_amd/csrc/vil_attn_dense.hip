@@ -249,6 +249,7 @@ __global__ __launch_bounds__(64 * DN_MAXW_F, DN_OCC_F) void k_dense_fwd(VilParam
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  lds_dma_wait();                                      // this wave's LDS-DMA requests (vil_mfma_common.h)
   __syncthreads();
 
   // one step = 32 keys of the block in ring slot `slot`.  (One instantiation for the wave that owns the global-token
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(64 * DN_MAXW_F, DN_OCC_F) void k_dense_fwd(VilParam
 #pragma unroll 1
         for (int st = 2 * j; st < min(2 * j + 2, nsteps); ++st) step(glo_, st, j & 1);
       }
+      lds_dma_wait();                                      // this wave's LDS-DMA requests (vil_mfma_common.h)
       __syncthreads();
     }
   };
@@ -486,6 +488,7 @@ __global__ __launch_bounds__(QT == 1 ? 64 * DN_MAXW_Q : 64 * DN_MAXW_Q2, QT == 1
     if (HIST) { n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64); domax = fmaxf(domax, n2); }
     if (qtok[qt] < N && lg == 0) c.delta[(int64_t)bh * N + qtok[qt]] = dl;
   }
+  lds_dma_wait();                                      // this wave's LDS-DMA requests (vil_mfma_common.h)
   __syncthreads();                                     // misc / hist zeroed, tables written
   if (HIST) {
 #pragma unroll
@@ -619,6 +622,7 @@ __global__ __launch_bounds__(QT == 1 ? 64 * DN_MAXW_Q : 64 * DN_MAXW_Q2, QT == 1
 #pragma unroll 1
         for (int st = 2 * j; st < min(2 * j + 2, nsteps); ++st) step(glo_, st, j & 1);
       }
+      lds_dma_wait();                                      // this wave's LDS-DMA requests (vil_mfma_common.h)
       __syncthreads();
     }
   };
@@ -753,6 +757,7 @@ __global__ __launch_bounds__(64 * DN_MAXW_K, DN_OCC_K) void k_dense_bwd_dkdv(Vil
       dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+  lds_dma_wait();                                      // this wave's LDS-DMA requests (vil_mfma_common.h)
   __syncthreads();
 
   auto step = [&](auto first_, int st, int slot) {
@@ -842,6 +847,7 @@ __global__ __launch_bounds__(64 * DN_MAXW_K, DN_OCC_K) void k_dense_bwd_dkdv(Vil
         for (int st = 2 * j; st < min(2 * j + 2, nsteps); ++st) step(std::false_type{}, st, j & 1);
       }
     }
+    lds_dma_wait();                                      // this wave's LDS-DMA requests (vil_mfma_common.h)
     __syncthreads();
   }
   if (!active) return;

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_dgelu(DgParams p) {
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) acc[nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  lds_dma_wait<8>();                                      // block 0 has landed; the 8 h loads issued after it stay in flight
   __syncthreads();
 
   for (int kb = 0; kb < nkb; ++kb) {
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_dgelu(DgParams p) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) acc[nt][tt] = mfma16(a[nt], bq[tt], acc[nt][tt]);
     }
+    lds_dma_wait();                                       // the next block's requests (lds_dma_wait, vil_mfma_common.h)
     __syncthreads();
   }
 
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_gelu(FgParams p) {
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) acc[nt][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  lds_dma_wait();                                         // block 0 (and the two bias loads)
   __syncthreads();
 
   for (int kb = 0; kb < nkb; ++kb) {
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_gelu(FgParams p) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) acc[nt][tt] = mfma16(a[nt], bq[tt], acc[nt][tt]);
     }
+    lds_dma_wait();                                       // the next block's requests (lds_dma_wait, vil_mfma_common.h)
     __syncthreads();
   }
 

@@ -11,7 +11,8 @@
 //     {8g+4..8g+7} in the odd one) -> one 16-byte store per lane and tile pair, bias added from registers;
 //   * the in-tile of a step is read from LDS by every wave (B fragments, ds_read_b128 from the XOR-swizzled 128-byte-row
 //     image of vil_attn_dense.hip, one image per 64 k);
-//   * no workgroup barrier except the one that publishes a landed tile.
+//   * no workgroup barrier except the one that publishes a landed tile (each wave waits for its own LDS-DMA requests
+//     before the tile's first store: lds_dma_wait, vil_mfma_common.h).
 #include "vil_mfma_common.h"
 
 struct SkParams {
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
       for (int off = wave * 1024; off < bytes + row_b; off += nwaves * 1024)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(smem + off), 16,
                                                  k0 * row_b + off + lane * 16, 0, 0, 0);
+      lds_dma_wait();
       __syncthreads();
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -141,9 +143,12 @@ __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
   int it = 0;
   const int first = blockIdx.x;
   if (first < p.ntiles) issue(first, 0);
+  lds_dma_wait();                                         // the first tile (and the weight / bias loads)
   for (int tile = first; tile < p.ntiles; tile += gridDim.x, ++it) {
     const int slot = it % NSLOT;
-    __syncthreads();                                      // (vmcnt(0) + barrier): this tile has landed, the slot of it+NSLOT-1 is free
+    // every wave has waited for its own requests of the tiles up to it + NSLOT - 2 (before the loop, or below before the
+    // first store of the previous tile): this tile has landed; the slot of it + NSLOT - 1 is free
+    __syncthreads();
     const int nxt = tile + (NSLOT - 1) * gridDim.x;
     if (NSLOT > 1) {
       // keep NSLOT-1 tiles in flight: request tile it+NSLOT-1 into the slot that tile it-1 has just released
@@ -178,6 +183,9 @@ __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
 #pragma unroll
               for (int tt = 0; tt < TT; ++tt) acc[pr][hf][tt] = mfma16(afr[pr][hf][ks], bq[tt], acc[pr][hf][tt]);
         }
+        // the requests for the tiles ahead have had the MFMA phase to land: wait for them HERE, before the tile's first
+        // store (stores share vmcnt and must not be waited for at the next barrier)
+        if (r0 == r_base) lds_dma_wait();
         // epilogue: lane (j, g) of pair pr, column tile tt: token t0 + r0 + 16 tt + j, features n_base + 32 pr + 8 g .. +7
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
           }
         }
       }
-    }
+    } else lds_dma_wait();                                // (a wave without output features still owns requests)
   }
 }
 

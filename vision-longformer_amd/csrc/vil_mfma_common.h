@@ -140,6 +140,15 @@ template <typename T> __device__ __forceinline__ typename V16<T>::x8 lds_tr_join
   return r;
 }
 
+// Completion of this wave's LDS-DMA requests (buffer_load ... lds) is counted by vmcnt like any vector load, but the
+// workgroup-scope fence inside __syncthreads() does not wait for it (hipcc 7.2 puts s_waitcnt vmcnt(0) in front of
+// s_barrier only where another dependency happens to ask for it -- k_skinny's K = 384 instantiation had none in its tile
+// loop and read a slot whose requests were, once in ~10^3 runs, still in flight).  Every barrier that publishes DMA'd
+// data is therefore preceded by an explicit wait: N = requests that may stay in flight (issued AFTER the ones needed;
+// loads return in order).  Not valid with stores in flight (they share vmcnt and return out of order with loads): place
+// the wait before the first store.
+template <int N = 0> __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

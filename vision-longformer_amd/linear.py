@@ -283,6 +283,7 @@ class _LinearGeluOutFn(torch.autograd.Function):
             h = F.linear(x, weight, bias) if h is None else h.view(*x.shape[:-1], weight.shape[0])
             a = F.gelu(h)
         ctx.mark_non_differentiable(a)
+        ctx.set_materialize_grads(False)      # (otherwise autograd hands backward a zero tensor the size of a: a fill kernel per block)
         return h, a
 
     @staticmethod
