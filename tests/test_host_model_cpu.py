@@ -220,3 +220,33 @@ def test_attn_drop_in_training_takes_the_materialised_path_not_the_fused_one():
     a.train()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         a(torch.zeros(1, 1 + 16, 32), 4, 4)
+
+
+def test_mlp_autograd_nodes_match_plain_torch_on_cpu():
+    """The two autograd nodes of the MLP block -- (h, gelu(h)) = fc1 with its activation as a NON-differentiable second
+    output, then gelu + fc2 as one node whose backward returns the gradient with respect to h -- against plain torch on
+    CPU tensors (the host logic only: on CPU both nodes take their torch fallbacks).  Checks that the activation handed
+    over is not differentiated twice, that no gradient is materialised for it, and every parameter gradient."""
+    from vision_longformer_amd.linear import _LinearGeluOutFn, _GeluLinearFn
+    torch.manual_seed(3)
+    x = torch.randn(5, 7, 16, dtype=torch.float64, requires_grad=True)
+    w1 = torch.randn(64, 16, dtype=torch.float64, requires_grad=True)
+    b1 = torch.randn(64, dtype=torch.float64, requires_grad=True)
+    w2 = torch.randn(16, 64, dtype=torch.float64, requires_grad=True)
+    b2 = torch.randn(16, dtype=torch.float64, requires_grad=True)
+    h, a = _LinearGeluOutFn.apply(x, w1, b1)
+    assert h.requires_grad and not a.requires_grad
+    y = _GeluLinearFn.apply(h, w2, b2, a)
+    g = torch.randn_like(y)
+    y.backward(g)
+    got = [t.grad.clone() for t in (x, w1, b1, w2, b2)]
+    for t in (x, w1, b1, w2, b2):
+        t.grad = None
+    ref = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(x, w1, b1)), w2, b2)
+    ref.backward(g)
+    assert torch.allclose(y, ref, rtol=1e-12, atol=1e-12)
+    for a_, t in zip(got, (x, w1, b1, w2, b2)):
+        assert torch.allclose(a_, t.grad, rtol=1e-10, atol=1e-10)
+    # without the pre-computed activation the second node computes it itself: same result
+    h2, _ = _LinearGeluOutFn.apply(x.detach(), w1.detach(), b1.detach())
+    assert torch.equal(_GeluLinearFn.apply(h2, w2.detach(), b2.detach()), _GeluLinearFn.apply(h2, w2.detach(), b2.detach(), _))
