@@ -2,7 +2,7 @@
 vil_local_attention at a BASELINE shape, per-kernel times from the library's
 hipEvent profiling sink.  Used under rocprofv3 for PMC counters.
 
-    python tools/kernel_bench.py small_s1 [--reps 20] [--fwd-only] [--backend mfma]
+    python tools/kernel_bench.py small_s1[,small_s2,...] [--reps 20] [--fwd-only] [--backend mfma]
 """
 import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,7 +42,12 @@ def main():
     ap.add_argument("--backend", default="auto")
     ap.add_argument("--batch", type=int, default=0)
     a = ap.parse_args()
-    H, M, W, nx, ny, G, mode, B = SHAPES[a.shape]
+    for shape in a.shape.split(","):
+        run(a, shape)
+
+
+def run(a, shape):
+    H, M, W, nx, ny, G, mode, B = SHAPES[shape]
     B = a.batch or B
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(300)
@@ -53,7 +58,7 @@ def main():
     g2l = (torch.randn(H, G, generator=g) * 0.02).to(dev).requires_grad_(not a.fwd_only)
     dout = torch.randn(B, nx * ny, C, generator=g).to(dev, torch.bfloat16)
     kw = dict(nx=nx, ny=ny, w=W, nglo=G, num_heads=H, mode=mode, backend=a.backend)
-    dense = a.shape.endswith("_dense")
+    dense = shape.endswith("_dense")
     if dense:
         rg = not a.fwd_only
         qkv = torch.randn(B, G + nx * ny, 3 * C, generator=g).to(dev, torch.bfloat16).requires_grad_(rg)
@@ -81,7 +86,7 @@ def main():
         x = agg.setdefault(n, [0, 0.0, 0.0, 0.0]); x[0] += 1; x[1] += ms; x[2] += by; x[3] += fl
     res = {n: dict(avg_ms=round(x[1] / x[0], 5), GBps=round(x[2] / x[1] / 1e6, 1), TFLOPs=round(x[3] / x[1] / 1e9, 2))
            for n, x in agg.items()}
-    print(json.dumps({"shape": a.shape, "B": B, "kernels": res}))
+    print(json.dumps({"shape": shape, "B": B, "kernels": res}))
 
 if __name__ == "__main__":
     main()

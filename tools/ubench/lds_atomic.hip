@@ -1,4 +1,4 @@
-// microbenchmark: LDS atomic add throughput (f32 vs u32) under several address patterns
+// microbenchmark: LDS atomic add throughput (f32 vs u32 vs u64) under several address patterns
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
       const int a = (base + u * 61 + it) & 4095;
       if (MODE == 0) atomicAdd(&h[a], v);
       else if (MODE == 1) atomicAdd((unsigned*)&h[a], (unsigned)v);
+      else if (MODE == 3) atomicAdd((unsigned long long*)&h[(a & 2047) * 2], (unsigned long long)v);   // ds_add_u64 (round 4)
       else h[a] = v;
     }
   }
@@ -51,6 +52,9 @@ int main() {
   run<0, 0>("add_f32 conflict-free");
   run<1, 0>("add_u32 conflict-free");
   run<2, 0>("write_b32 conflict-free");
+  run<3, 0>("add_u64 conflict-free");
+  run<3, 1>("add_u64 dq-pattern");
+  run<3, 3>("add_u64 8-way same addr");
   run<0, 1>("add_f32 dq-pattern");
   run<1, 1>("add_u32 dq-pattern");
   run<0, 3>("add_f32 8-way same addr");

@@ -2,6 +2,7 @@
 // argument validation, kernel-family dispatch, and the host-side geometry
 // helpers the CPU tests use to pin the kernels' mask / bias-index logic.
 #include "vil_internal.h"
+#include "vil_mfma_common.h"
 #include <string.h>
 #include <vector>
 
@@ -188,6 +189,7 @@ extern "C" int vil_geom_bias_index(int W, int mode, int32_t* rel) {
 
 // ------------------------------------------------------------ dynamic-LDS limits
 #include <map>
+#include <tuple>
 #include <mutex>
 int vil_ensure_dyn_lds(const void* kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return 0;
@@ -202,6 +204,32 @@ int vil_ensure_dyn_lds(const void* kernel, size_t bytes) {
   if (he != hipSuccess) return (int)he;
   have = bytes;
   return 0;
+}
+
+int vil_persistent_grid(int waves_per_simd, int waves_per_wg, size_t lds, int H, int64_t units_total) {
+  // resident workgroups per CU from the kernel's own launch bounds (waves per SIMD the register allocation was held
+  // to: 4 SIMDs per CU) and its LDS footprint (160 KB per CU) -- deterministic, so that workspace layouts and the
+  // fixed-point scale of the dQ histogram do not depend on a driver query; the CU count is the device's
+  static int cus_of[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int cus = (dev >= 0 && dev < 64) ? cus_of[dev] : 0;
+  if (cus <= 0) {
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    if (dev >= 0 && dev < 64) cus_of[dev] = cus;
+  }
+  int per_cu = waves_per_simd * 4 / (waves_per_wg > 0 ? waves_per_wg : 1);
+  const int by_lds = lds > 0 ? (int)((160 * 1024) / lds) : per_cu;
+  if (per_cu > by_lds) per_cu = by_lds;
+  if (per_cu < 1) per_cu = 1;
+  const int step = 8 * (H > 0 ? H : 1);
+  int64_t need = (units_total + waves_per_wg - 1) / waves_per_wg;
+  need = (need + step - 1) / step * step;
+  int64_t n = (int64_t)per_cu * cus / step * step;
+  if (n < step) n = step;
+  if (n > need) n = need;
+  if (n > VIL_MAX_PERSISTENT_WGS / step * step && VIL_MAX_PERSISTENT_WGS >= step) n = VIL_MAX_PERSISTENT_WGS / step * step;
+  return (int)n;
 }
 
 // ------------------------------------------------------------ profiling sink

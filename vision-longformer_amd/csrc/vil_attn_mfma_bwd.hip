@@ -54,20 +54,22 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, lg = lane >> 4;
 
-  // (image, workgroup-of-chunks, head) order: see k_mfma_fwd
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = fdiv(logical, bc.m_dq_wgbh), rem_ = logical - b * (bc.dq_wg_per_bh * p.H);
-  const int wgi = fdiv(rem_, c.m_H), h = rem_ - wgi * p.H;
-  const int bh = b * p.H + h;
+  // persistent workgroup bound to one head and one XCD's unit queue: every wave walks its own list of (image, query
+  // chunk) units (UnitList, vil_mfma_common.h); the workgroup leaves ONE histogram partial (64-bit bins)
+  const int h = (int)(blockIdx.x >> 3) % p.H;
+  __shared__ int s_started;                                   // units started by the workgroup's waves (histogram drain trigger)
+  if (tid == 0) s_started = 0;
 
   float* tab = (float*)smem;
   int* hist = (int*)(tab + c.tabsize);
+  long long* hist64 = (long long*)(hist + c.tabsize);        // (tabsize is a multiple of 4 floats: 8-byte aligned)
   const unsigned tab_lds = lds_addr(smem);
   const unsigned hist_off = (unsigned)c.tabsize * 4u;        // histogram bin = table entry + hist_off (bytes)
   {
     const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
     for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
-    for (int i = tid; i < c.tabsize; i += blockDim.x) hist[i] = 0;
+    if (bc.do_hist)
+      for (int i = tid; i < c.tabsize; i += blockDim.x) { hist[i] = 0; hist64[i] = 0; }
   }
   __syncthreads();
   // Fixed-point scale of the bias-gradient histogram.  ds_add_f32 runs ~40x slower than
@@ -95,19 +97,14 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
   const float hscale = FOLD ? 1.0f : __builtin_amdgcn_exp2f((float)lfx);
   const float unscale = FOLD ? p.scale * __builtin_amdgcn_exp2f((float)-lfx) : p.scale;
 
-  char* wbase = smem + (size_t)c.tabsize * 8 + (size_t)wave * bc.dq_wave_lds;
+  char* wbase = smem + (size_t)c.tabsize * 16 + (size_t)wave * bc.dq_wave_lds;
   int* s_koff = (int*)wbase;
   int* s_akey = s_koff + c.NSP;
   char* s_k = (char*)(s_akey + c.NSP);              // [32][M] bf16 K tile of the current step
 
-  const T* qb = (const T*)p.q + b * p.q_sb + h * p.q_sh;
   const int Nloc = g.nx * g.ny;
   const int kstride_b = (int)p.k_st * 2;
   const unsigned kv_bytes = (unsigned)(p.G + Nloc - 1) * (unsigned)kstride_b + M * 2;    // (zero keys of cyclic padding: vil_mfma_common.h)
-  const __amdgpu_buffer_rsrc_t krs = make_rsrc_n((const T*)p.k + b * p.k_sb + h * p.k_sh, kv_bytes);
-  const __amdgpu_buffer_rsrc_t vrs = make_rsrc_n((const T*)p.v + b * p.v_sb + h * p.v_sh, kv_bytes);
-  const T* dob = (const T*)p.dout + b * p.do_sb + h * p.do_sh;
-  T* dqb = (T*)p.dq + b * p.dq_sb + h * p.dq_sh;
   const float c1 = p.scale * LOG2E;
   const int W = g.W;
 
@@ -132,10 +129,38 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
   }
   const int lgo = lg * 16;
 
-  for (int gi = 0; gi < bc.dq_gpw; ++gi) {
-    const int unit = (wgi * bc.dq_gpw + gi) * bc.dq_wpw + wave;
-    if (unit < bc.dq_units_bh) {
-      const int ch = fdiv(unit, bc.m_dq_NWP), wp = unit - ch * bc.dq_NWP;
+  const bool lpt = g.nact == 9 && g.exact != -1;
+  UnitList list;
+  list.init(bc.uq_dq, p.B, p.H, wave, bc.dq_wpw);
+  for (int k = 0;; ++k) {
+    const int cur = list.entry(k);
+    if (cur < 0) break;
+    int started = 0;
+    if (bc.do_hist) {
+      if (lane == 0) started = __hip_atomic_fetch_add(&s_started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      started = __builtin_amdgcn_readfirstlane(started);
+    }
+    if (bc.do_hist && started > 0 && started % bc.hist_flush == 0) {
+      // Every hist_flush units the workgroup starts, the wave that starts that unit first drains the 32-bit bins into the
+      // workgroup's 64-bit bins: an atomic exchange per bin, so the other waves keep adding meanwhile and nothing is lost.
+      // A bin therefore receives at most (hist_flush + 2 * waves) units' worth of contributions between two exchanges --
+      // the bound the fixed-point scale is derived from (hist_nmax) -- however long the workgroup lives.
+      for (int i = lane; i < c.tabsize; i += 64) {
+        const int v = __hip_atomic_exchange(hist + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v) __hip_atomic_fetch_add(hist64 + i, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    const int b = fdiv(cur, bc.uq_dq.m_units_bh), urank = cur - b * bc.uq_dq.units_bh;
+    const int bh = b * p.H + h;
+    const T* qb = (const T*)p.q + b * p.q_sb + h * p.q_sh;
+    const __amdgpu_buffer_rsrc_t krs = make_rsrc_n((const T*)p.k + b * p.k_sb + h * p.k_sh, kv_bytes);
+    const __amdgpu_buffer_rsrc_t vrs = make_rsrc_n((const T*)p.v + b * p.v_sb + h * p.v_sh, kv_bytes);
+    const T* dob = (const T*)p.dout + b * p.do_sb + h * p.do_sh;
+    T* dqb = (T*)p.dq + b * p.dq_sb + h * p.dq_sh;
+    {
+      const int rk = fdiv(urank, bc.m_dq_NWP), wp = urank - rk * bc.dq_NWP;
+      const int ch = lpt ? chunk_of_rank(rk, g.mx, g.my) : rk;
+      const int unit = ch * bc.dq_NWP + wp;
       const int cm = fdiv(ch, c.m_my), cn = ch - cm * g.my;
       const int jj = wp * 16 + lj;
       const int qx = fdiv(jj, bc.m_dq_HQ), qhq = jj - qx * bc.dq_HQ;
@@ -395,9 +420,11 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
   }
   if (bc.do_hist) {
     __syncthreads();
-    int* out = (int*)bc.hist_parts + ((int64_t)bh * bc.dq_wg_per_bh + wgi) * c.tabsize;   // layout reduce_hist_block reads
-    for (int i = tid; i < c.tabsize; i += blockDim.x) out[i] = hist[i];
-    if (logical == 0 && tid == 0) ((int*)bc.norm2)[2] = lfx;      // the reduce needs the scale
+    // record w of head h (w = 0 .. dq_nwg / H - 1): layout reduce_hist_block reads
+    const int per = bc.dq_nwg / p.H, w = (int)((blockIdx.x >> 3) / p.H) * 8 + (int)(blockIdx.x & 7);
+    long long* out = (long long*)bc.hist_parts + ((int64_t)h * per + w) * c.tabsize;
+    for (int i = tid; i < c.tabsize; i += blockDim.x) out[i] = hist64[i] + (long long)hist[i];
+    if (blockIdx.x == 0 && tid == 0) ((int*)bc.norm2)[2] = lfx;      // the reduce needs the scale
   }
 }
 
@@ -409,24 +436,17 @@ __device__ __forceinline__ void reduce_hist_block(const VilParams& p, const Mfma
   const int bin = bx * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
   long long si = 0;
   if (bin < c.tabsize) {
-    // workgroups of head h: logical = (b*H + h)*wg_per_bh + w
-    const int per = bc.dq_wg_per_bh;
-    const int* parts = (const int*)bc.hist_parts;
-    const int n = p.B * per;
+    // the records of head h's (persistent) workgroups: (h * n + w) * tabsize, n = dq_nwg / H
+    const int n = bc.dq_nwg / p.H;
+    const long long* parts = (const long long*)bc.hist_parts + (int64_t)h * n * c.tabsize + bin;
     int i = grp;
     for (; i + 48 < n; i += 64) {
-      int v[4];
+      long long v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = i + 16 * u, b = j / per, w = j % per;
-        v[u] = parts[((int64_t)(b * p.H + h) * per + w) * c.tabsize + bin];
-      }
-      si += (long long)v[0] + v[1] + v[2] + v[3];
+      for (int u = 0; u < 4; ++u) v[u] = parts[(int64_t)(i + 16 * u) * c.tabsize];
+      si += (v[0] + v[1]) + (v[2] + v[3]);
     }
-    for (; i < n; i += 16) {
-      const int b = i / per, w = i % per;
-      si += parts[((int64_t)(b * p.H + h) * per + w) * c.tabsize + bin];
-    }
+    for (; i < n; i += 16) si += parts[(int64_t)i * c.tabsize];
   }
   red[grp][threadIdx.x & 63] = si;
   __syncthreads();
@@ -600,11 +620,9 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, lg = lane >> 4;
 
-  // (image, workgroup-of-chunks, head) order: see k_mfma_fwd
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = fdiv(logical, bc.m_kv_wgbh), rem_ = logical - b * (bc.kv_wg_per_bh * p.H);
-  const int wgi = fdiv(rem_, c.m_H), h = rem_ - wgi * p.H;
-  const int bh = b * p.H + h;
+  // persistent workgroup bound to one head and one XCD's unit queue: every wave walks its own list of (image, key chunk)
+  // units -- the global-key owner units, the longest, first in every image (UnitList, vil_mfma_common.h)
+  const int h = (int)(blockIdx.x >> 3) % p.H;
   const unsigned tab_lds = lds_addr(smem);
 
   float* tab = (float*)smem;
@@ -622,19 +640,11 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   char* s_q = (char*)(s_dlt + bc.nqs);            // [32][M] bf16 Q tile, then the [32][M] dO tile (PIPE: two such pairs)
   char* s_gq = s_q + (PIPE ? 4 : 2) * 32 * M * 2;   // [G][3][M] bf16: q, dO, out rows of the global queries
 
-  const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const T*)p.q + b * p.q_sb + h * p.q_sh);
-  const __amdgpu_buffer_rsrc_t drs = make_rsrc((const T*)p.dout + b * p.do_sb + h * p.do_sh);
-  const T* kb = (const T*)p.k + b * p.k_sb + h * p.k_sh;
-  const T* vb = (const T*)p.v + b * p.v_sb + h * p.v_sh;
-  T* dkb = (T*)p.dk + b * p.dk_sb + h * p.dk_sh;
-  T* dvb = (T*)p.dv + b * p.dv_sb + h * p.dv_sh;
   const int Nloc = g.nx * g.ny;
   const int qstride_b = (int)p.q_st * 2, dostride_b = (int)p.do_st * 2;
   const float c1 = p.scale * LOG2E;
   const int W = g.W, W2 = g.W2;
   const int nown = bc.nch * bc.kv_NWP;
-  const float* lse_bh = p.lse + (int64_t)bh * Nloc;
-  const float* dlt_bh = p.delta + (int64_t)bh * Nloc;
 
   int st_off[MD], ld_off[MD], tr_off[2][MD], row_off[2][MK];
 #pragma unroll
@@ -656,9 +666,30 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       row_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ (SWZ * (((row2 >> 2) & 1) << 5)));
   }
 
-  for (int gi = 0; gi < bc.kv_gpw; ++gi) {
-    const int unit = (wgi * bc.kv_gpw + gi) * bc.kv_wpw + wave;
-    if (unit >= bc.units_kv_bh) break;
+  const bool lpt = g.nact == 9 && g.exact != -1;
+  UnitList list;
+  list.init(bc.uq_kv, p.B, p.H, wave, bc.kv_wpw);
+  for (int k = 0;; ++k) {
+    const int cur = list.entry(k);
+    if (cur < 0) break;
+    const int b = fdiv(cur, bc.uq_kv.m_units_bh), urank = cur - b * bc.uq_kv.units_bh;
+    const int bh = b * p.H + h;
+    const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const T*)p.q + b * p.q_sb + h * p.q_sh);
+    const __amdgpu_buffer_rsrc_t drs = make_rsrc((const T*)p.dout + b * p.do_sb + h * p.do_sh);
+    const T* kb = (const T*)p.k + b * p.k_sb + h * p.k_sh;
+    const T* vb = (const T*)p.v + b * p.v_sb + h * p.v_sh;
+    T* dkb = (T*)p.dk + b * p.dk_sb + h * p.dk_sh;
+    T* dvb = (T*)p.dv + b * p.dv_sb + h * p.dv_sh;
+    const float* lse_bh = p.lse + (int64_t)bh * Nloc;
+    const float* dlt_bh = p.delta + (int64_t)bh * Nloc;
+    // ranks [0, nsplit): the global-key owner units; then the key chunks in order of decreasing work
+    int unit;
+    if (urank < bc.nsplit) unit = nown + urank;
+    else {
+      const int r2 = urank - bc.nsplit;
+      const int rk = fdiv(r2, bc.m_kv_NWP), wp_ = r2 - rk * bc.kv_NWP;
+      unit = (lpt ? chunk_of_rank(rk, g.mx, g.my) : rk) * bc.kv_NWP + wp_;
+    }
     const bool glo = unit >= nown;                 // global-key owner unit
     const int split = unit - nown;
     const int ch = glo ? 0 : fdiv(unit, bc.m_kv_NWP), wp = glo ? 0 : unit - ch * bc.kv_NWP;
@@ -1249,7 +1280,7 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   bc.dq_units_bh = bc.nch * bc.dq_NWP;
   bc.glo_nrec = bc.glo_from_dq ? bc.dq_units_bh + 1 : bc.nsplit;
   bc.dq_wpw = 4;
-  while (bc.dq_wpw > 1 && (size_t)c.tabsize * 8 + (size_t)bc.dq_wpw * bc.dq_wave_lds > 160 * 1024) bc.dq_wpw >>= 1;
+  while (bc.dq_wpw > 1 && (size_t)c.tabsize * 16 + (size_t)bc.dq_wpw * bc.dq_wave_lds > 160 * 1024) bc.dq_wpw >>= 1;
   {
     const int dgroups = (bc.dq_units_bh + bc.dq_wpw - 1) / bc.dq_wpw;
 #ifndef VIL_DQ_WGS
@@ -1261,14 +1292,28 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
     bc.dq_gpw = dgpw;
     bc.dq_wg_per_bh = (dgroups + dgpw - 1) / dgpw;
   }
-  bc.dq_nwg = d->B * d->H * bc.dq_wg_per_bh;
+  // persistent launches (UnitQueue): the workspace is laid out for the largest grid a launch may take; vil_mfma_bwd
+  // sets dq_nwg / kv_nwg to the resident number before it launches
+  {
+    const int step = 8 * d->H;
+    const int64_t need_q = (((int64_t)d->B * d->H * bc.dq_units_bh + bc.dq_wpw - 1) / bc.dq_wpw + step - 1) / step * step;
+    const int64_t need_k = (((int64_t)d->B * d->H * bc.units_kv_bh + bc.kv_wpw - 1) / bc.kv_wpw + step - 1) / step * step;
+    const int64_t cap_wgs = VIL_MAX_PERSISTENT_WGS / step * step > 0 ? VIL_MAX_PERSISTENT_WGS / step * step : step;
+    bc.dq_nwg = (int)(need_q < cap_wgs ? need_q : cap_wgs);
+    bc.kv_nwg = (int)(need_k < cap_wgs ? need_k : cap_wgs);
+  }
+  bc.uq_dq.units_bh = bc.dq_units_bh; bc.uq_dq.m_units_bh = vil_magic((unsigned)bc.dq_units_bh);
+  bc.uq_kv.units_bh = bc.units_kv_bh; bc.uq_kv.m_units_bh = vil_magic((unsigned)bc.units_kv_bh);
+  // dQ histogram: drained every hist_flush list entries; a bin gets at most one contribution per real query of a unit
+  bc.hist_flush = 12;
+  bc.hist_nmax = (16 * bc.dq_QT < g.W2 ? 16 * bc.dq_QT : g.W2) * (bc.hist_flush + 2 * bc.dq_wpw);
   bc.m_dq_wgbh = vil_magic((unsigned)(bc.dq_wg_per_bh * d->H)); bc.m_dq_NWP = vil_magic((unsigned)bc.dq_NWP);
   bc.m_dq_HQ = vil_magic((unsigned)bc.dq_HQ);
   bc.m_kv_wgbh = vil_magic((unsigned)(bc.kv_wg_per_bh * d->H)); bc.m_kv_NWP = vil_magic((unsigned)bc.kv_NWP);
   bc.m_kv_HQ = vil_magic((unsigned)bc.kv_HQ);
 }
 
-static size_t dq_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.tabsize * 8 + (size_t)bc.dq_wpw * bc.dq_wave_lds; }
+static size_t dq_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.tabsize * 16 + (size_t)bc.dq_wpw * bc.dq_wave_lds; }   // table, 32-bit bins, 64-bit bins, waves
 static size_t kv_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds; }
 
 int vil_mfma_bwd_supported(const VilAttnDesc* d) {
@@ -1280,8 +1325,8 @@ int vil_mfma_bwd_supported(const VilAttnDesc* d) {
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   BwdCfg bc; bwd_cfg(d, c, bc);
   if (dq_lds(c, bc) > 160 * 1024 || kv_lds(c, bc) > 160 * 1024) return VIL_E_BACKEND;
-  for (uint64_t w : {(uint64_t)bc.dq_wg_per_bh, (uint64_t)bc.kv_wg_per_bh})      // fdiv exactness, see vil_mfma_supported
-    if ((uint64_t)d->B * d->H * w * (w * d->H) >= (1ull << 32)) return VIL_E_BACKEND;
+  for (uint64_t u : {(uint64_t)bc.dq_units_bh, (uint64_t)bc.units_kv_bh})        // fdiv exactness, see vil_mfma_supported
+    if ((uint64_t)d->B * u * u >= (1ull << 32)) return VIL_E_BACKEND;
   return VIL_OK;
 }
 
@@ -1291,7 +1336,7 @@ static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& 
   off[0] = 0;
   off[1] = ((rows + 3) & ~(size_t)3) + 32 * VIL_NORM_SLOTS;      // + norm-maxima slots and the histogram scale
   off[2] = off[1] + (size_t)d->H * c.tabsize;
-  off[3] = off[2] + (size_t)bc.dq_nwg * c.tabsize;
+  off[3] = off[2] + (size_t)bc.dq_nwg * c.tabsize * 2;                              // 64-bit histogram records
   off[4] = off[3] + (size_t)d->B * d->H * bc.glo_nrec * d->G * 2 * d->M;
   off[5] = (off[4] + (size_t)d->B * d->H * (bc.nch * bc.kv_NWP + 1) * d->G * (d->M + 4) + 3) & ~(size_t)3;
   off[6] = off[5] + (size_t)(bc.nch + bc.nsplit) * bc.nqs * 2;                    // dK/dV slot tables (int2)
@@ -1327,7 +1372,6 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   c.key_nslots = (int*)(c.key_slots + (size_t)bc.nch * c.NSP);
   bc.do_hist = (p.dtable != nullptr) || (p.dg2l != nullptr);
   bc.norm2 = (unsigned*)(ws + off[1] - 32 * VIL_NORM_SLOTS);
-  bc.hist_nmax = p.g.W2 * bc.dq_gpw * bc.dq_wpw;
   const VilWork w(d);
   int e;
 #define BWD_SWITCH_T(T_, ...)                    \
@@ -1367,9 +1411,13 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   if ((e = (int)hipGetLastError())) return e;
   {
     const size_t lds = dq_lds(c, bc);
+    const int64_t units_total = (int64_t)p.B * p.H * bc.dq_units_bh;
     vil_prof_begin(VIL_K_MFMA_DQ, s, w.dq_bytes(), w.dq_flops());
     BWD_SWITCH({
-      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dq<TT_, MD_, (MD_ >= 2 ? 2 : 4)>, lds)) return he;
+      const void* kf_ = (const void*)k_mfma_bwd_dq<TT_, MD_, (MD_ >= 2 ? 2 : 4)>;
+      if (int he = vil_ensure_dyn_lds(kf_, lds)) return he;
+      const int grid = vil_persistent_grid(dq_waves(MD_), bc.dq_wpw, lds, p.H, units_total);
+      if (grid < bc.dq_nwg) bc.dq_nwg = grid;              // (never above the grid the workspace was laid out for)
       k_mfma_bwd_dq<TT_, MD_, (MD_ >= 2 ? 2 : 4)><<<dim3((unsigned)bc.dq_nwg), dim3(64 * bc.dq_wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);
@@ -1377,11 +1425,14 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   }
   {
     const size_t lds = kv_lds(c, bc);
-    const unsigned grid = (unsigned)(p.B * p.H * bc.kv_wg_per_bh);
+    const int64_t units_total = (int64_t)p.B * p.H * bc.units_kv_bh;
     vil_prof_begin(VIL_K_MFMA_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
     BWD_SWITCH({
-      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dkdv<TT_, MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))>, lds)) return he;
-      k_mfma_bwd_dkdv<TT_, MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
+      const void* kf_ = (const void*)k_mfma_bwd_dkdv<TT_, MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))>;
+      if (int he = vil_ensure_dyn_lds(kf_, lds)) return he;
+      const int grid = vil_persistent_grid(kv_waves(MD_), bc.kv_wpw, lds, p.H, units_total);
+      if (grid < bc.kv_nwg) bc.kv_nwg = grid;
+      k_mfma_bwd_dkdv<TT_, MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))><<<dim3((unsigned)bc.kv_nwg), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;

@@ -41,6 +41,34 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 //   Aq - Ak + aconst,  Aq = xq*P + yq,  Ak = X*P + Y,  aconst = tcen*(P+1) + CPAD,
 // so a lane gathers it with one v_sub (per key) and an immediate offset (per query of its quad).
 // P == 11 (mod 32) spreads the 16 query columns of a wave (x*P + 4*hq) over distinct banks.
+// ---- persistent workgroups (round 4).  The sliding-chunk passes used to launch one short-lived workgroup per group of
+// four chunks: waves of a workgroup walk 7 .. 14 key steps depending on where their chunk sits, the workgroup's slots
+// stay occupied until its slowest wave ends, each workgroup pays the table load + barrier, and B*H*chunks/4 workgroups on
+// 512 .. 768 resident slots quantise into rounds -- rocprofv3 counters (profiles/r04_pipe_utilisation.txt) showed 1.06
+// (48x48, M 64) to 2.4 (56x56, M 32) resident waves per SIMD of the 2 / 3 the registers allow.  Now a pass launches
+// exactly as many workgroups as are resident at once and every WAVE walks its own list of (image, chunk) units:
+//   * a workgroup is bound to one head (the bias-table image it holds in LDS: head = (blockIdx / 8) % H) and to the
+//     XCD the hardware places it on (blockIdx % 8), whose queue covers the images [B x / 8, B (x + 1) / 8) -- the H
+//     workgroups that walk the same images run on the same L2, as the (image, chunk group, head) launch order of round 2
+//     arranged;
+//   * entry k of wave w's list (w = the wave's index among the nw waves that serve the queue) is unit
+//     k * nw + (w + 37 k) mod nw: at any time the waves of an XCD work inside a window of ~nw units (two images: the L2
+//     footprint of round 2), the four waves of a workgroup are on ADJACENT chunks (their 3x3 neighbourhoods overlap:
+//     the CU's L1 serves part of their K / V reads -- dealing a workgroup's waves unrelated chunks cost 13 % at 48x48), and
+//     the rotation gives every wave a mix of interior, edge and corner chunks over its entries;
+//   * inside an image the chunks come in order of decreasing work (chunk_of_rank), so the last entries are short units.
+// Measured first, not kept (profiles/r04_queue_ablation.txt): (1) ONE atomic ticket counter per (XCD, head) in global
+// memory -- a returning global atomic in flight next to a wave's K / V load stream made the forward 2.6 - 3.6x slower
+// even with its result unused (loads return in order behind it, ~128 waves per counter queue up at the L2); (2) a
+// workgroup-level list drawn through an LDS counter: balances the four waves, but they no longer sit on adjacent chunks
+// (forward at 48x48: 74 us against 64.5 us for the per-wave lists, 72 - 74 us for round 3's short-lived workgroups).
+struct UnitQueue {
+  int units_bh;          // units per (image, head)
+  unsigned m_units_bh;   // vil_magic(units_bh)
+};
+#define VIL_POOL_ROT 37
+#define VIL_MAX_PERSISTENT_WGS 2048     // bound of a persistent grid (the dQ pass's histogram partials are laid out for it)
+
 struct MfmaCfg {
   int trows, tcen;   // rows (= columns) of the LDS bias image and its centre: 4W-1 / 2W-1, or 2W-1 / W-1 when the
                      // chunk attends only itself (mode -1: |dx|,|dy| <= W-1 -- a 5x smaller image for the dense stages)
@@ -63,6 +91,7 @@ struct MfmaCfg {
   const float* tabws;  // (H, tabsize) prepared bias tables
   int2* key_slots;     // (mx*my, NSP): key-slot table of every query chunk (key_slots_block), .x = K/V row byte offset, .y = bias term
   int* key_nslots;     // (mx*my): padded slot count of each
+  UnitQueue uq;        // forward pass units (query chunks x NWP)
 };
 
 // n / d for a run-time divisor without the ~25-instruction integer division sequence: magic = floor(2^32 / d) + 1
@@ -94,6 +123,40 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return __bui
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+}
+
+__device__ __forceinline__ int uq_img0(int B, int x) { return (B * x) >> 3; }
+// The unit list of one wave.  entry(k) returns the k-th unit as an index into head h's image-major unit list, or -1 when
+// the list is exhausted (entries grow: once one is beyond the queue, all later ones are).
+struct UnitList {
+  int q0, nq, w, nw;     // the (XCD, head) queue: first unit, units; this wave's index among the queue's nw waves
+  __device__ __forceinline__ void init(const UnitQueue& q, int B, int H, int wave, int waves_per_wg) {
+    const int xcd = blockIdx.x & 7;
+    const int i0 = uq_img0(B, xcd);
+    q0 = i0 * q.units_bh; nq = (uq_img0(B, xcd + 1) - i0) * q.units_bh;
+    w = ((int)(blockIdx.x >> 3) / H) * waves_per_wg + wave; nw = ((int)gridDim.x / (8 * H)) * waves_per_wg;
+  }
+  __device__ __forceinline__ int entry(int k) const {
+    const int u = k * nw + (w + VIL_POOL_ROT * k) % nw;
+    return u < nq ? q0 + u : -1;
+  }
+};
+// chunk of rank r when the chunks of an (mx, my) grid are ordered by decreasing work: with the full 3x3 neighbourhood an
+// interior chunk sees 9 chunks of keys (and is seen by 9 query chunks), an edge chunk 6, a corner chunk 4
+__device__ __forceinline__ int chunk_of_rank(int r, int mx, int my) {
+  if (mx < 3 || my < 3) return r;
+  const int iy = my - 2, ix = mx - 2, ni = ix * iy;
+  if (r < ni) { const int a = r / iy; return (1 + a) * my + 1 + (r - a * iy); }
+  r -= ni;
+  if (r < iy) return 1 + r;
+  r -= iy;
+  if (r < iy) return (mx - 1) * my + 1 + r;
+  r -= iy;
+  if (r < ix) return (1 + r) * my;
+  r -= ix;
+  if (r < ix) return (1 + r) * my + my - 1;
+  r -= ix;
+  return (r >> 1) * (mx - 1) * my + (r & 1) * (my - 1);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
@@ -309,6 +372,10 @@ __global__ void k_mfma_prep(VilParams p, MfmaCfg c, int row_stride_b, int ntx);
 static inline size_t vil_key_slots_floats(const MfmaCfg& c, int nch) {
   return (size_t)nch * c.NSP * 2 + (((size_t)nch + 3) & ~(size_t)3);
 }
+// workgroups of a persistent launch: as many as are resident at once (waves per SIMD of the kernel's launch bounds, its
+// LDS footprint), a multiple of 8 * H so that every (XCD, head) queue is served by the same number of workgroups, and no
+// more than the units can feed
+int vil_persistent_grid(int waves_per_simd, int waves_per_wg, size_t lds, int H, int64_t units_total);
 
 // host: fills the launch configuration for a descriptor
 bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c);
@@ -337,6 +404,9 @@ struct BwdCfg {
   unsigned m_dq_wgbh, m_dq_NWP, m_dq_HQ, m_kv_wgbh, m_kv_NWP, m_kv_HQ;   // magic reciprocals (vil_magic, fdiv)
   int2* kv_slots;     // (nch + nsplit, nqs): streamed-query slot tables of the dK/dV pass (kv_slots_block)
   int* kv_nchunks;    // (nch + nsplit)
+  UnitQueue uq_dq, uq_kv;   // units of the two passes (persistent workgroups, see UnitQueue)
+  int kv_nwg;         // workgroups of the dK/dV launch
+  int hist_flush;     // dQ pass: the LDS histogram is drained into the workgroup's 64-bit bins every hist_flush started units
 };
 
 struct PrepZero { unsigned* ptr[5]; int n[5]; int total; };

@@ -102,6 +102,9 @@ def set_lr(optimizer, lr):
             g["lr"].fill_(float(lr))
         else:
             g["lr"] = float(lr)
+    for o in (optimizer, getattr(optimizer, "opt", None)):
+        if hasattr(o, "sync_lr"):
+            o.sync_lr()                  # Python-float lr: refresh the device scalar the (captured) HIP step reads
 
 
 # The reference's recipes (src/config/msvit.yaml:32-47: AdamW lr 5e-4, wd 0.05, betas (0.9, 0.999), eps 1e-8 through
@@ -271,7 +274,7 @@ class SyntheticBatches:
     """ImageNet-shape batches resident on the device: N(0,1) images, label-smoothed
     one-hot soft targets (what the reference's mixup path feeds the loss)."""
 
-    def __init__(self, batch, img_size, device, rank=0, num_classes=1000, n_distinct=2, smoothing=0.1):
+    def __init__(self, batch, img_size, device, rank=0, num_classes=1000, n_distinct=8, smoothing=0.1):
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         self.items = []
         for _ in range(n_distinct):

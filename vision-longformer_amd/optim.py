@@ -13,7 +13,15 @@ autograd produced) as the gradient of the fp32 `master` and write the updated va
 hipGraph capture: the step is one kernel launch reading a device-resident plan (tensor addresses); when `step()` runs
 under stream capture the plan of the captured addresses is uploaded on a side stream, and `after_capture()` must be
 called once the capture has ended (engine.GraphedTrainStep does).  `lr` may be a device tensor updated in place by the
-schedule (`engine.set_lr`).
+schedule (`engine.set_lr`); a Python-float `lr` is mirrored into a device scalar the optimizer owns, so a per-iteration
+schedule never rebuilds the plan and a captured step follows `group["lr"]` assignments made between replays only
+through `sync_lr()` (GraphedTrainStep calls it before every replay).
+
+Step count: the reference keeps `state[p]["step"]` per parameter (optimization.py:155-165); here ONE device counter per
+launch bucket is advanced by the kernel.  The two agree whenever every parameter of a bucket has a gradient at every
+step (always, in this model).  `state_dict()` writes the bucket's count into every `state[p]["step"]`, so a checkpoint
+loads into the reference AdamW and vice versa (`load_state_dict` takes the largest per-parameter `step` when the
+`vil_steps` entry is absent).
 """
 import ctypes
 
@@ -40,6 +48,7 @@ class _Plan:
         self.key, self.nblocks = None, 0
         self.side = torch.cuda.Stream(device=device)
         self.pending = None
+        self.captured = False       # a captured launch reads this plan at every replay: its addresses are frozen
 
 
 class _Bucket:
@@ -56,11 +65,13 @@ class _Bucket:
 
 class _VilOptimizer(Optimizer):
     _ALGO = None
+    _HAS_STEP = False          # the reference class keeps a per-parameter `step` in its state (AdamW: yes, QHM: no)
 
     def __init__(self, params, defaults):
         super().__init__(params, defaults)
         self._bound = {}           # id(master) -> low parameter (gradient source + 16-bit working copy)
         self._plans = {}
+        self._lr_dev = {}          # id(param group) -> [device scalar mirroring a Python-float lr, its last value]
 
     # ---- mixed precision
     def bind_working_copy(self, master, low_param):
@@ -92,14 +103,55 @@ class _VilOptimizer(Optimizer):
         return buckets
 
     def allocate(self):
-        """allocates the plan buffers of every launch bucket (done by the first step otherwise); call before capturing
-        a step that was never run eagerly"""
+        """Creates, eagerly, everything a step needs that must not be created inside a stream capture: the plan buffers
+        of every launch bucket, every parameter's state tensors (zero moments) and the device mirrors of Python-float
+        learning rates.  Call before capturing a step that was never run eagerly (GraphedTrainStep(warmup=0))."""
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("optimizer.allocate() inside a stream capture")
         for key, groups in self._buckets().items():
+            ps = [p for gr in groups for p in gr["params"]]
+            if not ps:
+                continue
             if key not in self._plans:
-                ps = [p for gr in groups for p in gr["params"]]
-                if ps:
-                    self._plans[key] = _Bucket(ps[0].device, len(ps), [p.numel() for p in ps])
-                    self._new_plan_steps(self._plans[key])
+                self._plans[key] = _Bucket(ps[0].device, len(ps), [p.numel() for p in ps])
+                self._new_plan_steps(self._plans[key])
+            for gr in groups:
+                self._lr_mirror(gr, ps[0].device)
+                for p in gr["params"]:
+                    if p.requires_grad:
+                        self._state_for(p, gr)
+
+    def _new_state(self, p):
+        """zero state tensor of a parameter; never inside a capture (the zero-fill would become a graph node that
+        re-zeroes the moments at every replay while the device step counter keeps advancing)"""
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("optimizer state would be created inside a stream capture: call optimizer.allocate() "
+                               "(or run one eager step) before capturing the step")
+        return torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    def _lr_mirror(self, group, device):
+        """device scalar that carries a Python-float lr of a param group (refreshed by sync_lr); a tensor lr is its own"""
+        lr = group["lr"]
+        if torch.is_tensor(lr):
+            return lr
+        m = self._lr_dev.get(id(group))
+        if m is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("call optimizer.allocate() (or run one eager step) before capturing the step")
+            m = self._lr_dev[id(group)] = [torch.full((), float(lr), dtype=torch.float32, device=device), float(lr)]
+        return m[0]
+
+    def sync_lr(self):
+        """writes changed Python-float learning rates into their device mirrors (one tiny fill per changed group; no host
+        synchronisation, no plan rebuild).  step() calls it; under graph replay call it before the replay."""
+        for group in self.param_groups:
+            lr = group["lr"]
+            m = self._lr_dev.get(id(group))
+            if m is not None and not torch.is_tensor(lr) and float(lr) != m[1]:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("learning rate changed inside a stream capture")
+                m[0].fill_(float(lr))
+                m[1] = float(lr)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -122,12 +174,14 @@ class _VilOptimizer(Optimizer):
                     if p.dtype != torch.float32 or not p.is_contiguous() or not g.is_contiguous() or g.dtype not in _DT:
                         raise RuntimeError("optimizer tensors must be contiguous; parameters fp32, gradients fp32/bf16/fp16")
                     s1, s2 = self._state_for(p, group)
-                    entries.append((p, g, s1, s2, low, float(group["weight_decay"]), group["lr"]))
+                    entries.append((p, g, s1, s2, low, float(group["weight_decay"]), self._lr_mirror(group, p.device)))
             if not entries:
                 continue
             dev = entries[0][0].device
             bucket = self._plans.get(key)
             capturing = torch.cuda.is_current_stream_capturing()
+            if not capturing:
+                self.sync_lr()
             if bucket is None:
                 if capturing:
                     raise RuntimeError("call optimizer.allocate() (or run one eager step) before capturing the step: "
@@ -144,8 +198,16 @@ class _VilOptimizer(Optimizer):
 
     def _refresh(self, plan, entries):
         """(re)build and upload the plan when a tensor address changed (eager autograd reallocates gradients)"""
-        key = tuple((p.data_ptr(), g.data_ptr(), low.data_ptr() if low is not None else 0, wd,
-                     ("dev", lr.data_ptr()) if torch.is_tensor(lr) else float(lr)) for p, g, _, _, low, wd, lr in entries)
+        key = tuple((p.data_ptr(), g.data_ptr(), low.data_ptr() if low is not None else 0, wd, lr.data_ptr())
+                    for p, g, _, _, low, wd, lr in entries)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if plan.captured and key != plan.key:
+            # an earlier captured launch replays from this plan buffer (nblocks is baked into its node): overwriting it
+            # would silently retarget that graph to the new addresses
+            raise RuntimeError("this optimizer's step was already captured with other tensor addresses; a second capture "
+                               "(another GraphedTrainStep, another batch shape) needs its own optimizer instance")
+        if capturing:
+            plan.captured = True
         if key == plan.key:
             return
         L = _lib.lib()
@@ -158,7 +220,7 @@ class _VilOptimizer(Optimizer):
             a.n, a.grad_dtype = p.numel(), _DT[g.dtype]
             a.low_dtype = _DT[low.dtype] if low is not None else 0
             a.weight_decay = wd
-            a.lr, a.lr_dev = (0.0, lr.data_ptr()) if torch.is_tensor(lr) else (float(lr), None)
+            a.lr, a.lr_dev = 0.0, lr.data_ptr()        # always a device scalar: the group's tensor lr or its mirror
         if plan.pending is not None:
             plan.pending.synchronize()                 # the previous upload still reads the pinned buffer
             plan.pending = None
@@ -192,21 +254,37 @@ class _VilOptimizer(Optimizer):
 
     # ---- checkpointing: loaded moments are copied INTO the existing state tensors (a captured step keeps reading
     # the same addresses) and the lr objects (possibly device tensors a graph reads) are kept
+    def _bucket_of(self, group):
+        return self._plans.get(self._bucket_key(group))
+
     def state_dict(self):
+        # the reference's per-parameter `step` (optimization.py:155-165) = the launch bucket's device counter
+        if self._HAS_STEP:
+            for group in self.param_groups:
+                b = self._bucket_of(group)
+                if b is None:
+                    continue
+                n = int(b.steps[0].item())
+                for p in group["params"]:
+                    if p in self.state and len(self.state[p]):
+                        self.state[p]["step"] = n
         sd = super().state_dict()
         sd["vil_steps"] = [int(b.steps[0].item()) for b in self._plans.values()]     # completed steps per launch bucket
         return sd
 
     @torch.no_grad()
     def load_state_dict(self, state_dict):
-        steps = list(state_dict.get("vil_steps", []))
+        steps = state_dict.get("vil_steps")
         old_state = {id(p): dict(self.state[p]) for g in self.param_groups for p in g["params"] if p in self.state}
         lrs = [g["lr"] for g in self.param_groups]
+        old_gids = [id(g) for g in self.param_groups]
         super().load_state_dict({k: v for k, v in state_dict.items() if k != "vil_steps"})
         for g, lr in zip(self.param_groups, lrs):
             if torch.is_tensor(lr):
                 lr.fill_(float(g["lr"]))
                 g["lr"] = lr
+        # (Optimizer.load_state_dict replaces the param-group dicts: carry the lr mirrors over by position)
+        self._lr_dev = {id(g): self._lr_dev[k] for g, k in zip(self.param_groups, old_gids) if k in self._lr_dev}
         for g in self.param_groups:
             for p in g["params"]:
                 old, new = old_state.get(id(p)), self.state.get(p)
@@ -216,13 +294,38 @@ class _VilOptimizer(Optimizer):
                     if torch.is_tensor(v) and torch.is_tensor(old.get(k)) and old[k].shape == v.shape:
                         old[k].copy_(v)
                         new[k] = old[k]
-        self._loaded_steps = steps
-        for bucket, s in zip(self._plans.values(), steps):
-            bucket.steps[0] = int(s)
-            bucket.steps[1] = 0
+        if steps is None:
+            # a checkpoint of the reference optimizer: per-parameter `step` -> the bucket's counter (the largest one; they
+            # are equal unless some parameter had no gradient on some steps)
+            per_bucket = {}
+            for g in self.param_groups:
+                k = self._bucket_key(g)
+                for p in g["params"]:
+                    st = self.state.get(p)
+                    if st and "step" in st:
+                        per_bucket[k] = max(per_bucket.get(k, 0), int(st["step"]))
+            self._loaded_steps_by_key = per_bucket
+            self._loaded_steps = None
+            for k, bucket in self._plans.items():
+                bucket.steps[0] = int(per_bucket.get(k, 0))
+                bucket.steps[1] = 0
+        else:
+            steps = list(steps)
+            self._loaded_steps, self._loaded_steps_by_key = steps, None
+            for bucket, s_ in zip(self._plans.values(), steps):
+                bucket.steps[0] = int(s_)
+                bucket.steps[1] = 0
+        self.sync_lr()
 
     def _new_plan_steps(self, bucket):
-        """a bucket created after load_state_dict starts from the loaded step count (creation order)"""
+        """a bucket created after load_state_dict starts from the loaded step count (creation order, or -- for a
+        checkpoint of the reference optimizer -- the bucket's key)"""
+        by_key = getattr(self, "_loaded_steps_by_key", None)
+        if by_key:
+            for k, b in self._plans.items():
+                if b is bucket:
+                    bucket.steps[0] = int(by_key.get(k, 0))
+            return
         loaded = getattr(self, "_loaded_steps", None)
         idx = len(self._plans) - 1
         if loaded and idx < len(loaded):
@@ -232,6 +335,8 @@ class _VilOptimizer(Optimizer):
 class AdamW(_VilOptimizer):
     """Adam with the reference's weight-decay fix (src/optim/optimization.py:111-193): `denom = sqrt(v) + eps`, eps
     outside the bias correction (default 1e-6), decoupled decay `p -= lr * wd * p` after the Adam update."""
+
+    _HAS_STEP = True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
         if not torch.is_tensor(lr) and lr < 0.0:
@@ -250,8 +355,8 @@ class AdamW(_VilOptimizer):
     def _state_for(self, p, group):
         st = self.state[p]
         if "exp_avg" not in st:
-            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg"] = self._new_state(p)
+            st["exp_avg_sq"] = self._new_state(p)
         return st["exp_avg"], st["exp_avg_sq"]
 
     def _launch(self, plan, group, stream):
@@ -283,7 +388,7 @@ class QHM(_VilOptimizer):
         if abs(group["momentum"]) < 1e-12 or abs(group["qhm_nu"]) < 1e-12:      # plain SGD: no buffer (reference)
             return p, None          # (state1 must be a valid address; never touched by the kernel in this case)
         if "momentum_buffer" not in st:
-            st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["momentum_buffer"] = self._new_state(p)
         return st["momentum_buffer"], None
 
     def _launch(self, plan, group, stream):
