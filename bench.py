@@ -2,8 +2,11 @@
 """bench.py -- training throughput of ViL with the MI355X-native longformerhand path.
 
     python bench.py --gpus 1 --steps K --warmup W                      (single GPU)
+    python bench.py --gpus N --steps K --warmup W                      (starts N ranks itself: re-executes under
+                                                                        torch.distributed.run on 127.0.0.1; exits non-zero
+                                                                        when fewer than N devices are visible)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W      (one rank per GPU, RCCL)
+           --master-port P bench.py --gpus N --steps K --warmup W      (one rank per GPU, RCCL: what the above runs)
 
 One "step" = forward + backward + the optimizer step of the reference's recipe (AdamW for the 224 training recipe,
 QHM for the 384 fine-tuning recipe; the reference's update rules on the HIP multi-tensor kernel) of the named ViL on
@@ -20,7 +23,7 @@ Extra objects on the same line:
                 tagged with its problem shape); achieved = ALGORITHMIC bytes of the launch /
                 its average duration.  `traffic` = PMC HBM bytes per launch of
                 that kernel at that shape, collected inside the real step (tools/pmc_step.sh ->
-                profiles/r03_pmc_traffic.json) and attached ONLY when the kernel sources'
+                profiles/r04_pmc_traffic.json) and attached ONLY when the kernel sources'
                 fingerprint matches the build that is running.
   roofline_by_shape   the same for fwd / dQ / dK+dV / delta at every hot-path shape of the
                 workload, plus `backward_unit`: SURVEY 8(d)'s whole-backward definition
@@ -29,8 +32,16 @@ Extra objects on the same line:
   kernels       aggregated statistics of every library kernel.
   secondary     the other half of BASELINE's metric, ViL-Medium-Deep@384 (B=32/GPU), measured in
                 the same run with the same method (fewer steps): value, ms_per_step, roofline.
+  tertiary      the 384 recipe the reference fine-tunes with (ViL-Medium-Deep f8 / f12, README.md:296-301) and the
+                stress configuration (ViL-Base-Deep f6 / f8 with random shift, README.md:236): short runs, same method,
+                per-shape rooflines (W 12 / M 64 is the one MFMA-bound shape: its entries carry bound = "mfma").
+  eval          forward-only images/s of ViL-Tiny and ViL-Small at 224 (the reference's only published figures for this
+                path are evaluation costs: README.md:211-221, metric of src/engine.py:273,285), one hipGraph replay per batch.
   cpu_baseline  the oracle (CPU restatement of the reference path) inside the same host
                 model, timed on this box's host cores on a bounded sample (rank 0, N=1).
+Every roofline entry carries three roofs: hbm (8.0 TB/s), mfma (2.5 PFLOP/s bf16 dense) and valu -- scores per second
+against the vector pipes' rate for the minimum per-score work (one quarter-rate v_exp_f32 + the multiply-adds, packing and
+row maximum around it: VALU_SLOTS_PER_SCORE below), the practical limiter at head_dim 32.
 """
 import argparse
 import json
@@ -48,6 +59,18 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy rate)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 F32_VALU_PEAK_TFLOPS = 157.3
+# VALU roof of the attention kernels: lane-slots per second of the vector pipes (256 CUs x 4 SIMD-32 x 2.4 GHz =
+# F32_VALU_PEAK / 2 flops per FMA) over the MINIMUM lane-slots one score costs: v_exp_f32 at quarter rate = 4, plus
+#   forward  fma (scale, -max) 1 + cvt_pk 1/2 + v_max3 1/3                                       -> ~5.8
+#   dQ       fma 1 + mul (P * (dP - delta)) 1 + cvt_pk 1/2 + cvt_i32 + ds_add (histogram) 1      -> ~7.5
+#   dK/dV    fma 1 + mul 1 + 2 x cvt_pk 1/2                                                      -> ~7.0
+VALU_LANE_SLOTS_PER_S = F32_VALU_PEAK_TFLOPS * 1e12 / 2
+VALU_SLOTS_PER_SCORE = {"k_mfma_fwd": 5.8, "k_dense_fwd": 5.8, "k_mfma_bwd_dq": 7.5, "k_dense_bwd_dq": 7.5,
+                        "k_mfma_bwd_dkdv": 7.0, "k_dense_bwd_dkdv": 7.0}
+FLOPS_PER_SCORE = {"k_mfma_fwd": 4, "k_dense_fwd": 4, "k_mfma_bwd_dq": 6, "k_dense_bwd_dq": 6, "k_mfma_bwd_dkdv": 8,
+                   "k_dense_bwd_dkdv": 8}       # x head_dim: the library's algorithmic flops are 4 / 6 / 8 * scores * M
+# the reference's published evaluation costs (README.md:211-221; unstated GPU, fp16 AMP): seconds per image
+REFERENCE_EVAL_S_PER_IMAGE = {"vil_tiny_224": 0.0022, "vil_small_224": 0.0029}
 
 
 def _host_cpu():
@@ -196,6 +219,11 @@ def per_shape_stats(recs):
                         "frac_hbm": round(by / n / t / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else 0.0,
                         "TFLOPs": round(fl / n / t / 1e12, 1) if t > 0 else 0.0,
                         "frac_mfma": round(fl / n / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if t > 0 else 0.0}
+            if name in VALU_SLOTS_PER_SCORE and t > 0 and fl > 0:
+                scores = fl / n / (FLOPS_PER_SCORE[name] * M)            # (query, key) pairs per launch
+                peak = VALU_LANE_SLOTS_PER_S / VALU_SLOTS_PER_SCORE[name]
+                ks[name].update({"Gscores_per_s": round(scores / t / 1e9, 1), "frac_valu": round(scores / t / peak, 4),
+                                 "bound": "mfma" if fl / by > MFMA_BF16_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm"})
         bw = [k for k in ("k_delta", "k_mfma_bwd_dq", "k_mfma_bwd_dkdv", "k_reduce_glo", "k_reduce_bias", "k_glo_bwd",
                           "k_dense_bwd_dq", "k_dense_bwd_dkdv", "k_dense_reduce") if k in ks]
         if "k_mfma_bwd_dkdv" in ks or "k_dense_bwd_dkdv" in ks:
@@ -225,7 +253,7 @@ def pmc_traffic(config, B, kernel, label):
     tools/pmc_step.sh; only for the build whose kernel sources it was collected on."""
     from vision_longformer_amd import _lib
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
         if pm.get("source_fingerprint") != _lib.source_fingerprint():
             return None
         e = pm["configs"][config]
@@ -243,6 +271,10 @@ def roofline_of(config, B, shapes, tags, kernel="k_mfma_bwd_dkdv"):
     k = shapes[lab][kernel]
     return {"kernel": kernel, "shape": lab, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": k["frac_hbm"], "traffic": pmc_traffic(config, B, kernel, lab),
+            "mfma": {"achieved": k["TFLOPs"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": k["frac_mfma"]},
+            "valu": {"achieved": k.get("Gscores_per_s"), "unit": "Gscores/s", "frac": k.get("frac_valu"),
+                     "peak": round(VALU_LANE_SLOTS_PER_S / VALU_SLOTS_PER_SCORE[kernel] / 1e9, 1),
+                     "model": f"{VALU_SLOTS_PER_SCORE[kernel]} vector lane-slots per score (v_exp_f32 at quarter rate = 4)"},
             "algorithmic_bytes_per_launch": k["bytes_per_launch"], "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
             "achieved_tflops": k["TFLOPs"], "frac_of_bf16_mfma_peak": k["frac_mfma"],
             "backward_unit_frac": shapes[lab].get("backward_unit", {}).get("frac_hbm")}
@@ -355,9 +387,55 @@ def measure(args, config, B, steps, warmup, rank, world, device):
         elapsed = float(t.item())
     loss_val = float(loss.item())
     comm = gstep.comm_summary() if (use_graph and gstep.segmented) else None
+    if comm is not None:
+        comm["allreduce_alone_ms_per_segment"] = gstep.measure_allreduce()
+        comm["ranks_in_communicator"] = dist.get_world_size() if dist.is_initialized() else 1
     del step_fn
     return dict(elapsed=elapsed, recs=recs, nprof=nprof, loss=loss_val, use_graph=use_graph, use_master=use_master, optimizer=kind,
                 fam=fam, img=img, f1=f1, f2=f2, mode=mode, comm=comm)
+
+
+def measure_eval(config, B, steps, warmup, device):
+    """Forward-only throughput of `config` at 224: model.eval(), no_grad, bf16 working weights, one hipGraph replay per
+    batch of B synthetic images resident in HBM (the reference's `validate` loop, src/engine.py:198-327)."""
+    from vision_longformer_amd.engine import CONFIGS, build_vil, to_working_precision, GraphedEvalStep, SyntheticBatches
+    torch.manual_seed(0)
+    model = to_working_precision(build_vil(config, drop_path_rate=0.0).to(device)).eval()
+    data = SyntheticBatches(B, CONFIGS[config][1], device, 0, n_distinct=4)
+    step = GraphedEvalStep(model, data.next()[0])
+    for _ in range(warmup):
+        step(data.next()[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step(data.next()[0])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ok = bool(torch.isfinite(out.float()).all().item())
+    ref = REFERENCE_EVAL_S_PER_IMAGE.get(config)
+    res = {"images_per_s": round(B * steps / el, 1), "s_per_image": round(el / (B * steps), 7), "batch": B, "steps": steps,
+           "ms_per_batch": round(el / steps * 1e3, 3), "finite_logits": ok, "dtype": "bf16",
+           "launch": "hipGraph replay of model.eval() forward, no_grad",
+           "reference_published_s_per_image": ref,
+           "reference_note": "README.md:211-221: sum of rank wall time / images over the ImageNet val set, fp16 AMP, "
+                             "unstated GPU -- context, not a like-for-like baseline (vs_baseline stays null)"}
+    del step, model, data
+    torch.cuda.empty_cache()
+    return res
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` outside torchrun: start N ranks on this node (one per GPU) and pass their output through."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -380,15 +458,48 @@ def main():
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="run the step as hipGraphs (auto = on; random-shift neighbours are device-side words refreshed per replay); "
                          "off = eager step under DDP (bucketed all-reduce overlapped with backward)")
+    ap.add_argument("--no-eval", action="store_true", help="skip the forward-only (evaluation) throughput leg")
+    ap.add_argument("--no-tertiary", action="store_true",
+                    help="skip the short runs of ViL-Medium-Deep@384 f8/f12 and ViL-Base-Deep@384 random shift")
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="start the ranks, join the process group, all-reduce a one per rank, print {n_gpus} and exit "
+                         "(works without a GPU over gloo: the CPU test of the --gpus N launcher)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torchrun: start the N ranks ourselves (reference: python -m torch.distributed.launch
+        # --nproc_per_node=N run_experiment.py, README.md:280, src/run_experiment.py:70-82)
+        if not args.dry_run_ranks and torch.cuda.device_count() < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible", file=sys.stderr)
+            raise SystemExit(2)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    if args.dry_run_ranks:
+        from vision_longformer_amd.engine import init_distributed
+        rank, local_rank, world, device = init_distributed(single_rank_group=True)
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)
+        joined = int(one.item())
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"n_gpus": joined, "world_size_env": world, "device": device.type, "requested": args.gpus}), flush=True)
+        raise SystemExit(0 if joined == args.gpus else 3)
 
     from vision_longformer_amd import _lib, ops
     from vision_longformer_amd.engine import CONFIGS, init_distributed
     rank, local_rank, world, device = init_distributed(single_rank_group=args.force_segments)
     if device.type != "cuda":
         raise SystemExit("bench.py needs a GPU: the product path is HIP-only (no CPU fallback)")
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree", file=sys.stderr)
+        raise SystemExit(2)
+    if world > 1 and dist.is_initialized():       # n_gpus of the line = ranks that actually joined the communicator
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)
+        if int(one.item()) != world:
+            raise SystemExit(f"bench.py: {int(one.item())} of {world} ranks joined the process group")
     _lib.lib()                                  # fail loudly if the extension is missing
     ops.DEFAULT_BACKEND = args.backend
     B = args.batch or CONFIGS[args.config][2]
@@ -445,6 +556,27 @@ def main():
             out["secondary"] = sec
         del m2
         torch.cuda.empty_cache()
+
+    # ---- the 384 recipe the reference actually fine-tunes with, and the stress configuration: short runs, same method
+    if args.config == "vil_small_224" and not args.no_tertiary and not args.batch:
+        ter = []
+        for cfg3 in ("vil_medium_deep_384_f8f12", "vil_base_deep_384_rs"):
+            B3, steps3, warm3 = CONFIGS[cfg3][2], max(4, args.steps // 4), 2
+            m3 = measure(args, cfg3, B3, steps3, warm3, rank, world, device)
+            if rank == 0:
+                t3 = line(cfg3, B3, steps3, warm3, m3)
+                t3["metric"] = f"images/sec (train) {cfg3}"
+                t3.pop("kernels")
+                ter.append(t3)
+            del m3
+            torch.cuda.empty_cache()
+        if rank == 0:
+            out["tertiary"] = ter
+
+    # ---- forward-only (evaluation) throughput: the only figures the reference publishes for this path
+    if args.config == "vil_small_224" and not args.no_eval and world == 1 and rank == 0:
+        out["eval"] = {cfg: measure_eval(cfg, 128, max(10, args.steps), max(3, args.warmup), device)
+                       for cfg in ("vil_tiny_224", "vil_small_224")}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)

@@ -175,3 +175,144 @@ def test_optimizer_rejects_cpu_tensors():
         optim.AdamW([p], lr=-1.0)
     with pytest.raises(ValueError):
         optim.QHM([p], lr=0.1, momentum=1.5)
+
+
+def test_capture_without_an_eager_step_keeps_the_moments(dev):
+    """allocate() must create the optimizer state eagerly.  A step captured with NO eager step before
+    (GraphedTrainStep(warmup=0)) used to create exp_avg / exp_avg_sq inside the capture -- the zero-fill became a graph
+    node and re-zeroed the moments at every replay while the device step counter kept advancing.  Here nothing runs
+    before allocate() + capture, and the replays must reproduce the reference fixtures."""
+    from vision_longformer_amd import optim
+    gold = np.load(GOLD)
+    kind, hyper, wds = OC.CASES["adamw_recipe"]
+    params, grads = OC.make_inputs()
+    ps = [torch.nn.Parameter(p.clone().to(dev)) for p in params]
+    opt = optim.AdamW([{"params": ps[0::2], "weight_decay": wds[0]}, {"params": ps[1::2], "weight_decay": wds[1]}], **hyper)
+    static = [torch.zeros_like(p) for p in ps]
+    for p, s in zip(ps, static):
+        p.grad = s
+    opt.allocate()                                   # BEFORE any capture attempt, no eager step
+    assert all("exp_avg" in opt.state[p] for p in ps)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        opt.step()
+    opt.after_capture()
+    for k in range(OC.NSTEPS):
+        for s, g in zip(static, grads[k]):
+            s.copy_(g)
+        graph.replay()
+    torch.cuda.synchronize()
+    for i, p in enumerate(ps):
+        _close(p.detach().float().cpu(), torch.from_numpy(gold[f"adamw_recipe/step{OC.NSTEPS}/p{i}"]), f"tensor {i}")
+
+
+def test_state_created_inside_a_capture_raises(dev):
+    from vision_longformer_amd import optim
+    p = torch.nn.Parameter(torch.zeros(64, device=dev))
+    p.grad = torch.ones(64, device=dev)
+    opt = optim.AdamW([p], lr=1e-3)
+    with pytest.raises(RuntimeError, match="allocate"):
+        with torch.cuda.graph(torch.cuda.CUDAGraph()):
+            opt.step()
+    torch.cuda.synchronize()
+    assert "exp_avg" not in opt.state[p]             # nothing was created in the aborted capture's pool
+
+
+def test_checkpoint_is_interchangeable_with_the_reference_adamw(dev):
+    """the reference keeps state[p]['step'] per parameter (optimization.py:155-165).  Our state_dict
+    carries it, and a checkpoint WITHOUT 'vil_steps' (one written by the reference class) restores the bias-correction
+    step from the per-parameter values instead of restarting at t = 1 on warm moments."""
+    from vision_longformer_amd import optim
+    kind, hyper, wds = OC.CASES["adamw_defaults"]
+    params, grads = OC.make_inputs()
+
+    def make():
+        ps = [torch.nn.Parameter(p.clone().to(dev)) for p in params]
+        return ps, optim.AdamW([{"params": ps[0::2], "weight_decay": wds[0]}, {"params": ps[1::2], "weight_decay": wds[1]}], **hyper)
+
+    pa, oa = make()
+    for k in range(3):
+        for p, g in zip(pa, grads[k]):
+            p.grad = g.to(dev)
+        oa.step()
+    sd = oa.state_dict()
+    assert all(st["step"] == 3 for st in sd["state"].values())          # what the reference's step() will increment
+    import copy
+    ref_style = copy.deepcopy({"state": sd["state"], "param_groups": sd["param_groups"]})   # no 'vil_steps': a reference checkpoint (as read from disk)
+    pb, ob = make()
+    with torch.no_grad():
+        for a, b in zip(pa, pb):
+            b.copy_(a)
+    ob.load_state_dict(ref_style)                    # before any step of `ob`: its launch bucket does not exist yet
+    for k in range(3, OC.NSTEPS):
+        for p, q, g in zip(pa, pb, grads[k]):
+            p.grad = g.to(dev); q.grad = g.to(dev)
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert torch.equal(a.detach(), b.detach())
+    assert ob.state_dict()["vil_steps"] == [OC.NSTEPS]
+
+
+def test_python_float_lr_schedule_needs_no_plan_rebuild_and_reaches_a_captured_step(dev):
+    """A per-iteration schedule that assigns Python floats to group['lr'] (the reference's engine does): the lr lives in
+    a device scalar the optimizer owns, so the plan key does not change from step to step, and a CAPTURED step follows
+    the schedule through sync_lr() / engine.set_lr -- it used to bake the float of capture time into the graph."""
+    from vision_longformer_amd import optim
+    from vision_longformer_amd.engine import set_lr
+    kind, hyper, wds = OC.CASES["adamw_recipe"]
+    params, grads = OC.make_inputs()
+    lrs = [5e-4, 4e-4, 3e-4, 2e-4, 1e-4]
+
+    def make():
+        ps = [torch.nn.Parameter(p.clone().to(dev)) for p in params]
+        return ps, optim.AdamW([{"params": ps[0::2], "weight_decay": wds[0]}, {"params": ps[1::2], "weight_decay": wds[1]}], **hyper)
+
+    pe, oe = make()
+    static_e = [torch.zeros_like(p) for p in pe]
+    for p, s in zip(pe, static_e):
+        p.grad = s
+    keys = []
+    for k in range(OC.NSTEPS):
+        for g_ in oe.param_groups:
+            g_["lr"] = lrs[k]
+        for s, g in zip(static_e, grads[k]):
+            s.copy_(g)
+        oe.step()
+        keys.append(next(iter(oe._plans.values())).eager.key)
+    assert all(k_ == keys[0] for k_ in keys)         # same addresses, same plan: no rebuild, no host synchronisation
+    pg, og = make()
+    static = [torch.zeros_like(p) for p in pg]
+    for p, s in zip(pg, static):
+        p.grad = s
+    og.allocate()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        og.step()
+    og.after_capture()
+    for k in range(OC.NSTEPS):
+        set_lr(og, lrs[k])
+        for s, g in zip(static, grads[k]):
+            s.copy_(g)
+        graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(pe, pg):
+        assert torch.equal(a.detach(), b.detach())
+
+
+def test_second_capture_with_other_addresses_raises(dev):
+    """every capture reads the bucket's one graph plan (nblocks baked into the node): re-capturing with other gradient
+    addresses would silently retarget the first graph -- it raises instead"""
+    from vision_longformer_amd import optim
+    p = torch.nn.Parameter(torch.zeros(4096, device=dev))
+    opt = optim.AdamW([p], lr=torch.tensor(1e-3, device=dev))
+    p.grad = torch.ones(4096, device=dev)
+    opt.allocate()
+    g1 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1):
+        opt.step()
+    opt.after_capture()
+    p.grad = torch.ones(4096, device=dev)            # another gradient tensor: another address
+    with pytest.raises(RuntimeError, match="already captured"):
+        with torch.cuda.graph(torch.cuda.CUDAGraph()):
+            opt.step()
+    torch.cuda.synchronize()

@@ -258,6 +258,49 @@ class MasterWeightOptimizer:
             p.copy_(m)
 
 
+def to_working_precision(model, low_dtype=torch.bfloat16):
+    """16-bit working copies of every GEMM / conv weight, in place -- what MasterWeightOptimizer does to a model it
+    trains -- for an inference-only model (no masters kept): the forward then runs without per-call autocast casts."""
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Linear, torch.nn.Conv2d)):
+            for p in m.parameters(recurse=False):
+                if p.dtype == torch.float32:
+                    p.data = p.data.to(low_dtype)
+    return model
+
+
+class GraphedEvalStep:
+    """The evaluation forward of the reference's `validate` loop (src/engine.py:198-327: model.eval(), no_grad, AMP
+    autocast, logits out) as ONE hipGraph replay on a static batch: `logits = step(images)`.  model.eval() puts the
+    random-shift layers into mode 0 (longformer2d.py:114-123), so nothing is drawn per replay."""
+
+    def __init__(self, model, images, amp_dtype=torch.bfloat16, warmup=2):
+        self.model, self.amp = model.eval(), amp_dtype
+        dev = images.device
+        self.x = torch.empty_like(images)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self.x.copy_(images)
+            for _ in range(warmup):
+                self._fwd()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
+            self.out = self._fwd()
+
+    def _fwd(self):
+        with torch.no_grad(), torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
+            return self.model(self.x)
+
+    def __call__(self, images):
+        self.x.copy_(images, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
 def MasterWeightAdamW(model, **kw):
     return MasterWeightOptimizer(model, kind="adamw", **kw)
 
@@ -497,6 +540,25 @@ class GraphedTrainStep:
         return {"collective": "all-reduce (mean) of one flat gradient buffer per (backward segment, dtype)",
                 "segments_bytes": seg, "total_bytes": sum(seg), "exposed_bytes": seg[-1] if seg else 0,
                 "overlap": "segment k's all-reduce runs on the process group's stream under segment k+1's graph replay"}
+
+    def measure_allreduce(self, reps=5):
+        """milliseconds of one segment's all-reduce ALONE (nothing else on the device), per segment: the cost the
+        overlap has to hide.  Leaves the flat buffers averaged `reps` times over (gradients are rewritten every step)."""
+        if not (self.segmented and dist.is_available() and dist.is_initialized()):
+            return None
+        out = []
+        for fl in self.seg_flats:
+            self._allreduce(fl)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+            for _ in range(reps):
+                self._allreduce(fl)
+            t1.record()
+            torch.cuda.synchronize()
+            out.append(round(t0.elapsed_time(t1) / reps, 4))
+        return out
 
     def _body(self, eager):
         """the same step launched op by op (warm-up, and the per-kernel profile of bench.py)"""

@@ -288,6 +288,12 @@ class _VilOptimizer(Optimizer):
         for g in self.param_groups:
             for p in g["params"]:
                 old, new = old_state.get(id(p)), self.state.get(p)
+                if new and not old:
+                    # no state tensors of our own yet: take copies (Optimizer.load_state_dict keeps the checkpoint's
+                    # tensor objects when device and dtype already match -- two optimizers would share moments)
+                    for k, v in list(new.items()):
+                        if torch.is_tensor(v):
+                            new[k] = v.clone()
                 if not old or not new:
                     continue
                 for k, v in list(new.items()):
