@@ -71,9 +71,9 @@ F32_MFMA_CASES = [c for c in SMALL if c["M"] in (16, 32, 48, 64)] + [
 
 @pytest.mark.parametrize("c", F32_MFMA_CASES, ids=cid)
 def test_f32_matrix_core_family_vs_oracle(c, dev):
-    """fp32 I/O on v_mfma_f32_16x16x4_f32 (exact fp32 products): forward for every case (bias table, masks, modes, cyclic
-    padding, global keys); backward on the matrix cores where no bias-table gradient is requested, and -- in AUTO mode
-    with a bias table -- the VALU family's backward on the matrix-core forward's output / lse.  fp32 tolerances."""
+    """fp32 I/O on v_mfma_f32_16x16x4_f32 (exact fp32 products): forward and backward for every case (bias table, masks,
+    modes, cyclic padding, global keys) on the matrix cores -- round 4: including d(bias table) / d(g2l), from the dQ
+    pass's fixed-point histogram (no k_scalar_* launch any more).  fp32 tolerances."""
     from vision_longformer_amd import _lib
     q, kv, table, g2l, dout = make_inputs(c, torch.float32)
     ref = run_oracle(c, q, kv, table, g2l, dout)
@@ -85,14 +85,16 @@ def test_f32_matrix_core_family_vs_oracle(c, dev):
     names = [r[0] for r in _lib.profile_end(64)]
     assert "k_mfma_fwd" in names and "k_mfma_bwd_dq" in names and "k_mfma_bwd_dkdv" in names, names
     compare("f32 matrix-core fwd+bwd (no bias) " + cid(c0), got0, ref0, F32_TOL)
-    # (2) AUTO with the case's bias parameters: matrix-core forward, backward wherever the library routes it
+    # (2) AUTO with the case's bias parameters: the matrix-core family end to end, bias gradients included
     _lib.profile_begin(64)
     got = run_hip(c, q, kv, table, g2l, dout, torch.float32, "auto", dev)
     names = [r[0] for r in _lib.profile_end(64)]
-    assert "k_mfma_fwd" in names, names
+    assert "k_mfma_fwd" in names and "k_mfma_bwd_dq" in names and "k_mfma_bwd_dkdv" in names, names
+    assert not any(n.startswith("k_scalar") for n in names), names
+    compare("f32 matrix-core fwd+bwd with bias gradients " + cid(c), got, ref, F32_TOL)
     if c["rpe"]:
-        assert "k_scalar_bwd_dq" in names, names            # bias-table gradients: the VALU family
-    compare("f32 matrix-core forward, auto backward " + cid(c), got, ref, F32_TOL)
+        again = run_hip(c, q, kv, table, g2l, dout, torch.float32, "auto", dev)
+        assert torch.equal(got["dtable"], again["dtable"]), "fp32 d(table) is not bit-reproducible"
 
 
 def test_fp16_backward_propagates_non_finite_gradients(dev):
@@ -625,16 +627,30 @@ def test_model_vil_tiny_vs_reference_logits(dev, golden_dir):
             if "relative_position" in n:
                 p_.normal_(0, 0.3)
     model = model.float().to(dev).train()
-    for m in model.modules():
-        if hasattr(m, "backend"):
-            m.backend = "scalar"
     g = torch.Generator().manual_seed(GC.SEED)
     img = torch.randn(2, 3, 224, 224, generator=g, dtype=torch.float64).float().to(dev)
     tgt = torch.tensor([3, 977], device=dev)
-    logits = model(img)
-    loss = torch.nn.functional.cross_entropy(logits, tgt)
-    loss.backward()
-    torch.cuda.synchronize()
+    # fp32 end to end on the matrix-core family (round 4): the sliding-chunk stages INCLUDING their bias-table / g2l
+    # gradients (no k_scalar_* launch), the dense stages as the one-chunk case of the same kernels (no
+    # scaled_dot_product_attention with a materialised (H, N, N) bias)
+    from vision_longformer_amd import _lib
+    import torch.nn.functional as F_
+    sdpa = F_.scaled_dot_product_attention
+
+    def no_sdpa(*a, **k):
+        raise AssertionError("fp32 dense Attention fell back to scaled_dot_product_attention")
+    F_.scaled_dot_product_attention = no_sdpa
+    try:
+        _lib.profile_begin(4096)
+        logits = model(img)
+        loss = torch.nn.functional.cross_entropy(logits, tgt)
+        loss.backward()
+        torch.cuda.synchronize()
+        names = {r[0] for r in _lib.profile_end(4096)}
+    finally:
+        F_.scaled_dot_product_attention = sdpa
+    assert not any(n.startswith("k_scalar") for n in names), names
+    assert {"k_mfma_fwd", "k_mfma_bwd_dq", "k_mfma_bwd_dkdv"} <= names, names
     ref = torch.from_numpy(gold["logits"])
     err = (logits.detach().double().cpu() - ref).abs().max().item()
     report(f"     model ViL-Tiny fp32: max|logit err| = {err:.3e}, loss {loss.item():.6f} vs {float(gold['loss']):.6f}")

@@ -101,10 +101,7 @@ extern "C" int vil_attn_bwd(const VilAttnDesc* d, const void* q, const void* k, 
   if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv) return VIL_E_NULL;
   if (bias_table && !dbias_table) return VIL_E_NULL;
   if (g2l && d->G > 0 && !dg2l) return VIL_E_NULL;
-  int be = pick_backend(d, 1);
-  // fp32: the matrix-core family has no bias-gradient histogram; gradients of the bias table / g2l run on the VALU family
-  if (be == VIL_BACKEND_MFMA && d->dtype == VIL_DTYPE_F32 && (dbias_table || (dg2l && d->G > 0)))
-    be = (d->backend == VIL_BACKEND_AUTO && vil_scalar_supported(d) == VIL_OK) ? VIL_BACKEND_SCALAR : 0;
+  const int be = pick_backend(d, 1);
   if (!be) return d->backend == VIL_BACKEND_AUTO ? vil_scalar_supported(d) : VIL_E_BACKEND;
   if (!workspace && vil_attn_workspace_bytes(d, 1) > 0) return VIL_E_WORKSPACE;
   VilParams p; memset(&p, 0, sizeof(p));

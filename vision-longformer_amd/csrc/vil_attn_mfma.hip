@@ -75,9 +75,13 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, lg = lane >> 4;
 
-  // persistent workgroup: bound to one head (its bias-table image sits in LDS) and to the unit queue of the XCD the
-  // hardware placed it on; every wave walks its own list of (image, chunk) units (UnitList, vil_mfma_common.h)
-  const int h = (int)(blockIdx.x >> 3) % p.H;
+  // logical order (image, workgroup-of-chunks, head): the H workgroups that walk the same chunks of one image run
+  // back to back on one XCD, so both 64-byte halves (two heads) of every K / V cache line are consumed while the
+  // line is L2-resident, and the in-flight K/V footprint of an XCD is H times smaller than with (image, head, ...)
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = fdiv(logical, c.m_wgbh), rem_ = logical - b * (c.wg_per_bh * p.H);
+  const int wgi = fdiv(rem_, c.m_H), h = rem_ - wgi * p.H;
+  const int bh = b * p.H + h;
 
   float* tab = (float*)smem;
   {
@@ -95,6 +99,10 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   const int Nloc = g.nx * g.ny;
   const int kstride_b = (int)p.k_st * 2;
   const unsigned kv_bytes = (unsigned)(p.G + Nloc - 1) * (unsigned)kstride_b + M * 2;    // K / V rows of this (image, head)
+  const __amdgpu_buffer_rsrc_t krs = make_rsrc_n((const T*)p.k + b * p.k_sb + h * p.k_sh, kv_bytes);
+  const __amdgpu_buffer_rsrc_t vrs = make_rsrc_n((const T*)p.v + b * p.v_sb + h * p.v_sh, kv_bytes);
+  const T* qb = (const T*)p.q + b * p.q_sb + h * p.q_sh;
+  T* ob = (T*)p.o + b * p.o_sb + h * p.o_sh;
   const float c1 = p.scale * LOG2E;               // scores are kept unscaled: s*c1 is log2-domain
   const float thr = 8.0f / p.scale;               // deferred-max threshold (8 nats)
   const int W = g.W;
@@ -122,20 +130,10 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   }
   const int lgo = lg * 16;
 
-  const bool lpt = g.nact == 9 && g.exact != -1;     // full neighbourhoods, zero padding: chunk work depends on position
-  UnitList list;
-  list.init(c.uq, p.B, p.H, wave, c.wpw);
-  for (int k = 0;; ++k) {
-    const int cur = list.entry(k);
-    if (cur < 0) break;
-    const int b = fdiv(cur, c.uq.m_units_bh), unit = cur - b * c.uq.units_bh;
-    const int bh = b * p.H + h;
-    const __amdgpu_buffer_rsrc_t krs = make_rsrc_n((const T*)p.k + b * p.k_sb + h * p.k_sh, kv_bytes);
-    const __amdgpu_buffer_rsrc_t vrs = make_rsrc_n((const T*)p.v + b * p.v_sb + h * p.v_sh, kv_bytes);
-    const T* qb = (const T*)p.q + b * p.q_sb + h * p.q_sh;
-    T* ob = (T*)p.o + b * p.o_sb + h * p.o_sh;
-    const int rk = fdiv(unit, c.m_NWP), wp = unit - rk * c.NWP;
-    const int ch = lpt ? chunk_of_rank(rk, g.mx, g.my) : rk;
+  for (int gi = 0; gi < c.gpw; ++gi) {
+    const int unit = (wgi * c.gpw + gi) * c.wpw + wave;
+    if (unit >= c.units_bh) break;
+    const int ch = fdiv(unit, c.m_NWP), wp = unit - ch * c.NWP;
     const int cm = fdiv(ch, c.m_my), cn = ch - cm * g.my;
 
     // ---- query slots of this lane: column j of q-tile qt is query (x, y = 4*hq + qt)
@@ -382,7 +380,6 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   if (gpw > groups) gpw = groups;
   c.gpw = gpw;
   c.wg_per_bh = (groups + gpw - 1) / gpw;
-  c.uq.units_bh = c.units_bh; c.uq.m_units_bh = vil_magic((unsigned)c.units_bh);
   c.m_wgbh = vil_magic((unsigned)(c.wg_per_bh * d->H)); c.m_H = vil_magic((unsigned)d->H);
   c.m_NWP = vil_magic((unsigned)c.NWP); c.m_my = vil_magic((unsigned)g.my); c.m_HQ = vil_magic((unsigned)c.HQ);
   return true;
@@ -415,8 +412,8 @@ int vil_mfma_supported(const VilAttnDesc* d, int pass) {
     return VIL_E_BACKEND;
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   if (mfma_lds_bytes(c) > 160 * 1024) return VIL_E_BACKEND;
-  // unit indices are decoded with magic-number divisions, exact for index * divisor < 2^32 (fdiv)
-  if ((uint64_t)d->B * c.units_bh * (uint64_t)c.units_bh >= (1ull << 32)) return VIL_E_BACKEND;
+  // the workgroup index is decoded with magic-number divisions, exact for index * divisor < 2^32 (fdiv)
+  if ((uint64_t)d->B * d->H * c.wg_per_bh * ((uint64_t)c.wg_per_bh * d->H) >= (1ull << 32)) return VIL_E_BACKEND;
   return pass == 0 ? VIL_OK : vil_mfma_bwd_supported(d);
 }
 
@@ -449,19 +446,17 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   int e = (int)hipGetLastError();
   if (e) return e;
   vil_prof_begin(VIL_K_MFMA_FWD, s, w.fwd_bytes(), w.fwd_flops());
+  const unsigned grid = (unsigned)(p.B * p.H * c.wg_per_bh);
   const size_t lds = mfma_lds_bytes(c);
-  const int64_t units_total = (int64_t)p.B * p.H * c.units_bh;
-#define LAUNCH_FWD_T(T_, MD_)                                                                        \
-  {                                                                                                  \
-    const void* kf_ = (const void*)k_mfma_fwd<T_, MD_>;                                              \
-    if (int he = vil_ensure_dyn_lds(kf_, lds)) return he;                                            \
-    const int grid = vil_persistent_grid(fwd_waves(MD_), c.wpw, lds, p.H, units_total);              \
-    k_mfma_fwd<T_, MD_><<<dim3((unsigned)grid), dim3(64 * c.wpw), lds, s>>>(p, c);                    \
-  }
 #define LAUNCH_FWD(MD_)                                                                              \
   {                                                                                                  \
-    if (d->dtype == VIL_DTYPE_F16) LAUNCH_FWD_T(_Float16, MD_)                                       \
-    else LAUNCH_FWD_T(__bf16, MD_)                                                                   \
+    if (d->dtype == VIL_DTYPE_F16) {                                                                 \
+      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_fwd<_Float16, MD_>, lds)) return he;        \
+      k_mfma_fwd<_Float16, MD_><<<dim3(grid), dim3(64 * c.wpw), lds, s>>>(p, c);                      \
+    } else {                                                                                         \
+      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_fwd<__bf16, MD_>, lds)) return he;          \
+      k_mfma_fwd<__bf16, MD_><<<dim3(grid), dim3(64 * c.wpw), lds, s>>>(p, c);                        \
+    }                                                                                                \
   }
   switch (d->M) {
     case 16: LAUNCH_FWD(1); break;

@@ -620,9 +620,12 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, lg = lane >> 4;
 
-  // persistent workgroup bound to one head and one XCD's unit queue: every wave walks its own list of (image, key chunk)
-  // units -- the global-key owner units, the longest, first in every image (UnitList, vil_mfma_common.h)
-  const int h = (int)(blockIdx.x >> 3) % p.H;
+  // (image, workgroup-of-chunks, head) order: see k_mfma_fwd.  (Round 4 tried persistent workgroups here as in the dQ
+  // pass: same time, but 1.8x instead of 1.5x the algorithmic HBM bytes at 96x96 -- profiles/r04_queue_ablation.txt.)
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = fdiv(logical, bc.m_kv_wgbh), rem_ = logical - b * (bc.kv_wg_per_bh * p.H);
+  const int wgi = fdiv(rem_, c.m_H), h = rem_ - wgi * p.H;
+  const int bh = b * p.H + h;
   const unsigned tab_lds = lds_addr(smem);
 
   float* tab = (float*)smem;
@@ -666,30 +669,17 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       row_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ (SWZ * (((row2 >> 2) & 1) << 5)));
   }
 
-  const bool lpt = g.nact == 9 && g.exact != -1;
-  UnitList list;
-  list.init(bc.uq_kv, p.B, p.H, wave, bc.kv_wpw);
-  for (int k = 0;; ++k) {
-    const int cur = list.entry(k);
-    if (cur < 0) break;
-    const int b = fdiv(cur, bc.uq_kv.m_units_bh), urank = cur - b * bc.uq_kv.units_bh;
-    const int bh = b * p.H + h;
-    const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const T*)p.q + b * p.q_sb + h * p.q_sh);
-    const __amdgpu_buffer_rsrc_t drs = make_rsrc((const T*)p.dout + b * p.do_sb + h * p.do_sh);
-    const T* kb = (const T*)p.k + b * p.k_sb + h * p.k_sh;
-    const T* vb = (const T*)p.v + b * p.v_sb + h * p.v_sh;
-    T* dkb = (T*)p.dk + b * p.dk_sb + h * p.dk_sh;
-    T* dvb = (T*)p.dv + b * p.dv_sb + h * p.dv_sh;
-    const float* lse_bh = p.lse + (int64_t)bh * Nloc;
-    const float* dlt_bh = p.delta + (int64_t)bh * Nloc;
-    // ranks [0, nsplit): the global-key owner units; then the key chunks in order of decreasing work
-    int unit;
-    if (urank < bc.nsplit) unit = nown + urank;
-    else {
-      const int r2 = urank - bc.nsplit;
-      const int rk = fdiv(r2, bc.m_kv_NWP), wp_ = r2 - rk * bc.kv_NWP;
-      unit = (lpt ? chunk_of_rank(rk, g.mx, g.my) : rk) * bc.kv_NWP + wp_;
-    }
+  const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const T*)p.q + b * p.q_sb + h * p.q_sh);
+  const __amdgpu_buffer_rsrc_t drs = make_rsrc((const T*)p.dout + b * p.do_sb + h * p.do_sh);
+  const T* kb = (const T*)p.k + b * p.k_sb + h * p.k_sh;
+  const T* vb = (const T*)p.v + b * p.v_sb + h * p.v_sh;
+  T* dkb = (T*)p.dk + b * p.dk_sb + h * p.dk_sh;
+  T* dvb = (T*)p.dv + b * p.dv_sb + h * p.dv_sh;
+  const float* lse_bh = p.lse + (int64_t)bh * Nloc;
+  const float* dlt_bh = p.delta + (int64_t)bh * Nloc;
+  for (int gi = 0; gi < bc.kv_gpw; ++gi) {
+    const int unit = (wgi * bc.kv_gpw + gi) * bc.kv_wpw + wave;
+    if (unit >= bc.units_kv_bh) break;
     const bool glo = unit >= nown;                 // global-key owner unit
     const int split = unit - nown;
     const int ch = glo ? 0 : fdiv(unit, bc.m_kv_NWP), wp = glo ? 0 : unit - ch * bc.kv_NWP;
@@ -1170,10 +1160,14 @@ __global__ void k_mfma_delta(VilParams p, unsigned* norm2) {
   constexpr int LPR = MD == 4 ? 8 : (MD == 2 ? 4 : 2);
   constexpr int NL = M / (8 * LPR);
   const int Nloc = p.g.nx * p.g.ny;
-  // grid (ceil(Nloc*LPR/256), B*H): no per-thread division by a run-time value
+  // grid (ceil(Nloc*H*LPR/256), B): consecutive lanes walk (token, head, piece) with the piece fastest and the head next,
+  // i.e. the H*M contiguous values of a token row: a wave reads whole rows.  (Round 3 gave every head its own blocks:
+  // each 128-byte line of out / dout / v -- two heads at head_dim 32 -- was fetched once per head, by blocks that ran at
+  // different times: 2.94x the algorithmic bytes at ViL-Small stage 1, profiles/r03_pmc_traffic.json.)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int tok = t / LPR, sub = t % LPR;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int sub = t % LPR, th = t / LPR;
+  const int tok = th / p.H, h = th - tok * p.H;
+  const int b = blockIdx.y, bh = b * p.H + h;
   const bool live = tok < Nloc;
   const int64_t i = (int64_t)bh * Nloc + tok;
   float n_do = 0.f, n_v = 0.f, s = 0.f, n_vg = 0.f;
@@ -1325,8 +1319,8 @@ int vil_mfma_bwd_supported(const VilAttnDesc* d) {
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   BwdCfg bc; bwd_cfg(d, c, bc);
   if (dq_lds(c, bc) > 160 * 1024 || kv_lds(c, bc) > 160 * 1024) return VIL_E_BACKEND;
-  for (uint64_t u : {(uint64_t)bc.dq_units_bh, (uint64_t)bc.units_kv_bh})        // fdiv exactness, see vil_mfma_supported
-    if ((uint64_t)d->B * u * u >= (1ull << 32)) return VIL_E_BACKEND;
+  if ((uint64_t)d->B * bc.dq_units_bh * (uint64_t)bc.dq_units_bh >= (1ull << 32)) return VIL_E_BACKEND;   // fdiv exactness
+  if ((uint64_t)d->B * d->H * bc.kv_wg_per_bh * ((uint64_t)bc.kv_wg_per_bh * d->H) >= (1ull << 32)) return VIL_E_BACKEND;
   return VIL_OK;
 }
 
@@ -1405,7 +1399,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     if ((e = (int)hipGetLastError())) return e;
   }
   vil_prof_begin(VIL_K_DELTA, s, w.delta_bytes(), 0);
-  BWD_SWITCH((k_mfma_delta<TT_, MD_><<<dim3((unsigned)((p.g.nx * p.g.ny * (MD_ == 4 ? 8 : (MD_ == 2 ? 4 : 2)) + 255) / 256), p.B * p.H), dim3(256), 0, s>>>(
+  BWD_SWITCH((k_mfma_delta<TT_, MD_><<<dim3((unsigned)(((int64_t)p.g.nx * p.g.ny * p.H * (MD_ == 4 ? 8 : (MD_ == 2 ? 4 : 2)) + 255) / 256), p.B), dim3(256), 0, s>>>(
       p, bc.do_hist ? bc.norm2 : nullptr)));
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
@@ -1425,14 +1419,11 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   }
   {
     const size_t lds = kv_lds(c, bc);
-    const int64_t units_total = (int64_t)p.B * p.H * bc.units_kv_bh;
+    const unsigned grid = (unsigned)(p.B * p.H * bc.kv_wg_per_bh);
     vil_prof_begin(VIL_K_MFMA_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
     BWD_SWITCH({
-      const void* kf_ = (const void*)k_mfma_bwd_dkdv<TT_, MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))>;
-      if (int he = vil_ensure_dyn_lds(kf_, lds)) return he;
-      const int grid = vil_persistent_grid(kv_waves(MD_), bc.kv_wpw, lds, p.H, units_total);
-      if (grid < bc.kv_nwg) bc.kv_nwg = grid;
-      k_mfma_bwd_dkdv<TT_, MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))><<<dim3((unsigned)bc.kv_nwg), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
+      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dkdv<TT_, MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))>, lds)) return he;
+      k_mfma_bwd_dkdv<TT_, MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
     });
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;

@@ -3,7 +3,9 @@
 // xf32 / tf32 rounding), for the reference's fp32 protocol (src/tests/benchmark_vil.py:171-251 and its CPU path).
 // Same C ABI entry points, same bias-table image, masks and key-slot tables as the 16-bit family
 // (vil_mfma_common.h); the one-query-per-lane VALU family (vil_attn_scalar.hip) stays the fallback for what this
-// family declines (bias-table gradients, head_dim 8, W > 32, G > 16).
+// family declines (head_dim 8, W > 32, G > 16).  Round 4: d(bias table) / d(g2l) come from the dQ pass's fixed-point LDS
+// histogram like in the 16-bit families (per-workgroup power-of-two scale, one record per workgroup, summed in a fixed
+// order in double: bit-reproducible) -- they used to send the whole backward to the VALU family.
 //
 // Tile algebra (D = A B + C with A 16x4, B 4x16, lane l: A[l%16][l/16], B[l/16][l%16], D[4(l/16)+r][l%16]):
 //   S^T (16 keys x 16 queries)  = sum over M/4 MFMAs of K-rows x Q-rows: lane (j, g) feeds key j / query j with head
@@ -37,6 +39,8 @@ struct F32Cfg {
   unsigned m_NWP, m_HQ, m_kNWP, m_kHQ, m_wgbh, m_kwgbh;
   int2* kv_slots; int* kv_nchunks;
   float* glo_parts;                                       // (B*H, gsplit, G, 2, M) partial dK / dV of the global keys
+  unsigned* vnorm;                                        // [0] max_k |v_k|^2 over the whole call (float bits; k_f32_vmax)
+  int* hist_parts;                                        // (dQ workgroups, 2 tabsize + 4): hi bins, lo bins, [2 tabsize] = lfx
 };
 
 // ------------------------------------------------------------------ forward
@@ -157,10 +161,19 @@ __global__ __launch_bounds__(256, 2) void k_f32_fwd(VilParams p, MfmaCfg c, F32C
 }
 
 // ------------------------------------------------------------------ backward, dQ pass (+ delta = rowsum(dO o O))
-template <int MD, int QT>
+// HIST: dS is also accumulated into a per-workgroup LDS histogram laid out like the bias-table image (the bin of a score
+// is the table entry its bias was gathered from), fixed point with the workgroup's own power-of-two scale:
+// |dS| <= 2 |dO_q| |v_k| (Cauchy-Schwarz) with the maximum of |dO_q|^2 over the workgroup's queries and of |v_k|^2 over
+// the call (k_f32_vmax); a bin receives at most one contribution per query.  2^lfx rides on P through lse (exact in
+// fp32: a power of two) and leaves dQ in the epilogue.  fp32 tolerances need more than the 22 bits an int32 bin leaves per
+// contribution (measured: 1e-3 absolute error on d(table)): a bin is TWO int32 words, x = 65536 hi + lo with
+// hi = rint(x / 65536) and lo = x - 65536 hi (exact in fp32), each summed by its own ds_add_u32 -- 44-bit fixed point
+// under an fp32 value's 24 significant bits.  One record per workgroup, summed by k_f32_hist_reduce.
+template <int MD, int QT, bool HIST>
 __global__ __launch_bounds__(256, 2) void k_f32_bwd_dq(VilParams p, MfmaCfg c, F32Cfg fc) {
   constexpr int M = 16 * MD, MQ = M / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned s_domax;
   const VilGeom& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,16 +182,25 @@ __global__ __launch_bounds__(256, 2) void k_f32_bwd_dq(VilParams p, MfmaCfg c, F
   const int b = fdiv(logical, fc.m_wgbh), rem_ = logical - b * (fc.wg_per_bh * p.H);
   const int wgi = fdiv(rem_, c.m_H), h = rem_ - wgi * p.H;
   const int bh = b * p.H + h;
+  int* hist = (int*)smem + c.tabsize;                         // HIST: [table | hi bins | lo bins | per-wave slot tables]
+  const unsigned hist_off = (unsigned)c.tabsize * 4u;
   {
     const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
     for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)smem)[i] = src[i];
+    if (HIST) {
+      for (int i = tid; i < 2 * c.tabsize; i += blockDim.x) hist[i] = 0;
+      if (tid == 0) s_domax = 0u;
+    }
   }
   __syncthreads();
   const unsigned tab_lds = lds_addr(smem);
-  int* s_koff = (int*)(smem + (size_t)c.tabsize * 4 + (size_t)wave * fc.wave_lds);
+  int* s_koff = (int*)(smem + (size_t)c.tabsize * (HIST ? 12 : 4) + (size_t)wave * fc.wave_lds);
   int* s_akey = s_koff + c.NSP;
   const int unit = wgi * 4 + wave;
-  if (unit >= fc.units_bh) return;
+  const bool active = unit < fc.units_bh;
+  if (!HIST && !active) return;
+  int lfx = 0;
+  if (active) {                                                // (HIST: idle waves of the last workgroup still meet the barriers)
   const int Nloc = g.nx * g.ny, W = g.W;
   const int kstride_b = (int)p.k_st * 4;
   const unsigned kv_bytes = (unsigned)(p.G + Nloc - 1) * (unsigned)kstride_b + M * 4;
@@ -199,26 +221,44 @@ __global__ __launch_bounds__(256, 2) void k_f32_bwd_dq(VilParams p, MfmaCfg c, F
   int qtok[QT];
   bool qreal[QT];
   float qf[QT][MQ], dof[QT][MQ], lse2[QT], ndlt[QT];
+  float domax = 0.f;
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const int qy = QT * qhq + qt;
     const int qr = cm * W + qx, qc = cn * W + qy;
     qreal[qt] = qx < W && qy < W && qr < g.nx && qc < g.ny;
     qtok[qt] = qreal[qt] ? qr * g.ny + qc : (cm * W) * g.ny + cn * W;
-    float dl = 0.f;
+    float dl = 0.f, n2 = 0.f;
 #pragma unroll
     for (int t = 0; t < MQ; t += 4) {
       const f32x4 a4 = *(const f32x4*)(qb + (int64_t)qtok[qt] * p.q_st + lg * MQ + t);
       const f32x4 d4 = *(const f32x4*)(dob + (int64_t)qtok[qt] * p.do_st + lg * MQ + t);
       const f32x4 o4 = *(const f32x4*)(outb + (int64_t)qtok[qt] * p.o_st + lg * MQ + t);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { qf[qt][t + e] = a4[e]; dof[qt][t + e] = d4[e]; dl = __builtin_fmaf(d4[e], o4[e], dl); }
+      for (int e = 0; e < 4; ++e) {
+        qf[qt][t + e] = a4[e]; dof[qt][t + e] = d4[e]; dl = __builtin_fmaf(d4[e], o4[e], dl);
+        if (HIST) n2 = __builtin_fmaf(d4[e], d4[e], n2);
+      }
     }
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
+    if (HIST) { n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64); domax = fmaxf(domax, qreal[qt] ? n2 : 0.f); }
     if (qreal[qt] && lg == 0) p.delta[(int64_t)bh * Nloc + qtok[qt]] = dl;        // the dK/dV pass reads it
     ndlt[qt] = qreal[qt] ? -dl : 0.f;
     lse2[qt] = qreal[qt] ? p.lse[(int64_t)bh * Nloc + qtok[qt]] * LOG2E : F32_LSE_PAD;   // padding slot: p = 0
+  }
+  if (HIST) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) domax = fmaxf(domax, __shfl_xor(domax, o, 64));
+    if (lane == 0) __hip_atomic_fetch_max(&s_domax, __float_as_uint(domax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();                                           // (the idle waves' matching barrier: below)
+    const float bound = 2.0f * __builtin_sqrtf(__uint_as_float(s_domax) * __uint_as_float(fc.vnorm[0]));
+    if (bound > 0.f && bound < 1e30f) {
+      lfx = 44 - (int)ceilf(__log2f(bound * (float)(4 * 16 * QT)));      // <= 16 QT queries per wave, 4 waves per workgroup
+      lfx = max(-60, min(60, lfx));
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) if (qreal[qt]) lse2[qt] -= (float)lfx;
   }
   f32x4 dq[MD][QT];
 #pragma unroll
@@ -252,19 +292,116 @@ __global__ __launch_bounds__(256, 2) void k_f32_bwd_dq(VilParams p, MfmaCfg c, F
       for (int t = 0; t < MQ; ++t) { acc = mfma4(kfr[t], qf[qt][t], acc); dp = mfma4(vfr[t], dof[qt][t], dp); }
       f32x4 ds;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], c1, -lse2[qt])) * dp[r];
+      for (int r = 0; r < 4; ++r) {
+        ds[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], c1, -lse2[qt])) * dp[r];
+        if (HIST) {
+          const float hi = __builtin_rintf(ds[r] * (1.0f / 65536.0f));
+          const float lo = __builtin_fmaf(hi, -65536.0f, ds[r]);                 // exact: |lo| <= 32768
+          auto* bin = lds_i32(aq0b - (unsigned)ak[r] + hist_off) + qt;
+          __hip_atomic_fetch_add(bin, (int)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(bin + c.tabsize, (int)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
 #pragma unroll
       for (int dt = 0; dt < MD; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dq[dt][qt] = mfma4(kk[dt][r], ds[r], dq[dt][qt]);
     }
   }
+  const float unscale = HIST ? p.scale * __builtin_amdgcn_exp2f((float)-lfx) : p.scale;
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt)
     if (qreal[qt]) {
 #pragma unroll
-      for (int dt = 0; dt < MD; ++dt) *(f32x4*)(dqb + (int64_t)qtok[qt] * p.dq_st + dt * 16 + lg * 4) = dq[dt][qt] * p.scale;
+      for (int dt = 0; dt < MD; ++dt) *(f32x4*)(dqb + (int64_t)qtok[qt] * p.dq_st + dt * 16 + lg * 4) = dq[dt][qt] * unscale;
     }
+  } else if (HIST) {
+    __syncthreads();                                           // an idle wave: the barrier after the |dO|^2 maximum
+  }
+  if (HIST) {
+    // every wave of a workgroup derives the same lfx (same s_domax); an idle wave has none: wave 0 is always active
+    __shared__ int s_lfx;
+    if (tid == 0) s_lfx = lfx;
+    __syncthreads();
+    int* rec = fc.hist_parts + (int64_t)logical * (2 * c.tabsize + 4);
+    for (int i = tid; i < 2 * c.tabsize; i += blockDim.x) rec[i] = hist[i];
+    if (tid == 0) rec[2 * c.tabsize] = s_lfx;
+  }
+}
+
+// max_k |v_k|^2 over every (image, head, token) row of v -- the second factor of the histogram's bound: 4 lanes per row,
+// one atomic maximum (float bits: the values are non-negative) per workgroup
+template <int MD>
+__global__ __launch_bounds__(256) void k_f32_vmax(VilParams p, unsigned* vnorm) {
+  constexpr int M = 16 * MD, MQ = M / 4;
+  __shared__ float s_m[4];
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int sub = (int)(t & 3);
+  const int64_t row = t >> 2, ntok = (int64_t)p.G + (int64_t)p.g.nx * p.g.ny;
+  float n2 = 0.f;
+  if (row < (int64_t)p.B * ntok * p.H) {
+    const int h = (int)(row % p.H);
+    const int64_t bt = row / p.H, tok = bt % ntok, b = bt / ntok;
+    const float* vp = (const float*)p.v + b * p.v_sb + tok * p.v_st + h * p.v_sh + sub * MQ;
+#pragma unroll
+    for (int e = 0; e < MQ; e += 4) {
+      const f32x4 v4 = *(const f32x4*)(vp + e);
+      n2 = __builtin_fmaf(v4[0], v4[0], __builtin_fmaf(v4[1], v4[1], __builtin_fmaf(v4[2], v4[2], __builtin_fmaf(v4[3], v4[3], n2))));
+    }
+  }
+  n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64);
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) n2 = fmaxf(n2, __shfl_xor(n2, o, 64));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = n2;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(vnorm, __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]))));
+}
+
+// d(table)[idx*H + h] and d(g2l)[h*G + g] from the dQ workgroups' records.  grid (ceil(tabsize / 64), H), 1024 threads =
+// 64 bins x 16 record groups; the records of head h are logical workgroups j*H + h.  Every bin is summed in a fixed order
+// in double with its record's scale: bit-reproducible (d(g2l) sums a region of bins: one float atomic per block).
+__global__ __launch_bounds__(1024) void k_f32_hist_reduce(VilParams p, MfmaCfg c, F32Cfg fc) {
+  __shared__ double red[16][64];
+  const int h = blockIdx.y, bin = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  const int nrec = p.B * fc.wg_per_bh, stride = 2 * c.tabsize + 4;
+  double s = 0.0;
+  if (bin < c.tabsize)
+    for (int j0 = grp; j0 < nrec; j0 += 64) {
+      int vh[4], vl[4], lf[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = min(j0 + 16 * u, nrec - 1);
+        const int* r = fc.hist_parts + ((int64_t)j * p.H + h) * stride;
+        const bool ok = j0 + 16 * u < nrec;
+        vh[u] = ok ? r[bin] : 0; vl[u] = ok ? r[c.tabsize + bin] : 0;
+        lf[u] = r[2 * c.tabsize];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += ldexp((double)vh[u] * 65536.0 + (double)vl[u], -lf[u]);
+    }
+  red[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp != 0) return;
+  double t = 0.0;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) t += red[u][threadIdx.x];
+  const float sf = (float)t;
+  int gg = -1;
+  if (bin < c.trows * c.P) {
+    const int row = bin / c.P, col = bin % c.P - VIL_CPAD;
+    const int dx = row - c.tcen, dy = col - c.tcen, o = p.bias_off;
+    if (col >= 0 && col < c.trows && p.dtable && dx >= -o && dx <= o && dy >= -o && dy <= o)
+      p.dtable[(int64_t)((dx + o) * p.bias_S + (dy + o)) * p.H + h] = sf;
+  } else if (bin >= c.glo0 && bin < c.tabsize && p.dg2l) {
+    gg = (bin - c.glo0) / c.gsz;
+  }
+  for (int g_ = 0; g_ < p.G; ++g_) {
+    if (!__any(gg == g_)) continue;
+    float v = gg == g_ ? sf : 0.f;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2, 64);
+    if (threadIdx.x == 0 && v != 0.f) atomicAdd(&p.dg2l[h * p.G + g_], v);
+  }
 }
 
 // ------------------------------------------------------------------ backward, dK/dV pass (one wave per 16*KT keys of a key chunk;
@@ -491,8 +628,8 @@ static void f32_cfg(const VilAttnDesc* d, const MfmaCfg& c, F32Cfg& fc) {
   fc.m_kNWP = vil_magic((unsigned)fc.kNWP); fc.m_kHQ = vil_magic((unsigned)fc.kHQ);
   fc.m_wgbh = vil_magic((unsigned)(fc.wg_per_bh * d->H)); fc.m_kwgbh = vil_magic((unsigned)(fc.kwg_per_bh * d->H));
 }
-static size_t f32_lds(const MfmaCfg& c, const F32Cfg& fc, bool kv) {
-  return (size_t)c.tabsize * 4 + (size_t)4 * (kv ? fc.kwave_lds : fc.wave_lds);
+static size_t f32_lds(const MfmaCfg& c, const F32Cfg& fc, bool kv, bool hist = false) {
+  return (size_t)c.tabsize * (hist ? 12 : 4) + (size_t)4 * (kv ? fc.kwave_lds : fc.wave_lds);
 }
 
 int vil_f32_supported(const VilAttnDesc* d, int pass) {
@@ -510,28 +647,30 @@ int vil_f32_supported(const VilAttnDesc* d, int pass) {
   }
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   F32Cfg fc; f32_cfg(d, c, fc);
-  if (f32_lds(c, fc, pass != 0) > 160 * 1024 || f32_lds(c, fc, false) > 160 * 1024) return VIL_E_BACKEND;
+  if (f32_lds(c, fc, pass != 0) > 160 * 1024 || f32_lds(c, fc, false, pass != 0) > 160 * 1024) return VIL_E_BACKEND;
   for (uint64_t w : {(uint64_t)fc.wg_per_bh, (uint64_t)fc.kwg_per_bh})
     if ((uint64_t)d->B * d->H * w * (w * d->H) >= (1ull << 32)) return VIL_E_BACKEND;
   return VIL_OK;
 }
 
-// floats: [delta | table images | key-slot tables | dK/dV slot tables + counts | global-key partials]
-static void f32_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const F32Cfg& fc, size_t off[6]) {
+// floats: [delta | table images | key-slot tables | dK/dV slot tables + counts | global-key partials | v-norm word |
+//          histogram records of the dQ workgroups]
+static void f32_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const F32Cfg& fc, size_t off[8]) {
   const size_t rows = (size_t)d->B * d->H * d->nx * d->ny;
   off[0] = 0;
   off[1] = (rows + 3) & ~(size_t)3;
   off[2] = off[1] + (size_t)d->H * c.tabsize;
   off[3] = off[2] + vil_key_slots_floats(c, fc.nch);
   off[4] = off[3] + (size_t)fc.nch * fc.nqs * 2 + (((size_t)fc.nch + 3) & ~(size_t)3);
-  off[5] = off[4] + (size_t)d->B * d->H * fc.gsplit * d->G * 2 * d->M;
+  off[5] = (off[4] + (size_t)d->B * d->H * fc.gsplit * d->G * 2 * d->M + 3) & ~(size_t)3;
+  off[6] = off[5] + 32;
+  off[7] = off[6] + (size_t)d->B * d->H * fc.wg_per_bh * (2 * c.tabsize + 4);
 }
 size_t vil_f32_workspace(const VilAttnDesc* d, int pass) {
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   F32Cfg fc; f32_cfg(d, c, fc);
-  size_t off[6]; f32_ws_layout(d, c, fc, off);
-  (void)pass;
-  return off[5] * sizeof(float) + 64;
+  size_t off[8]; f32_ws_layout(d, c, fc, off);
+  return off[pass != 0 ? 7 : 5] * sizeof(float) + 64;
 }
 
 #define F32_SWITCH(...)                                      \
@@ -546,7 +685,7 @@ size_t vil_f32_workspace(const VilAttnDesc* d, int pass) {
 int vil_f32_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   F32Cfg fc; f32_cfg(d, c, fc);
-  size_t off[6]; f32_ws_layout(d, c, fc, off);
+  size_t off[8]; f32_ws_layout(d, c, fc, off);
   float* ws = (float*)p.delta;
   if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.o | (uintptr_t)ws) & 15) return VIL_E_ALIGN;
   c.tabws = ws + off[1];
@@ -568,10 +707,11 @@ int vil_f32_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
 }
 
 int vil_f32_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
-  if (p.dtable || p.dg2l || p.glo_rows) return VIL_E_BACKEND;     // bias-table gradients: the VALU family (vil_attn_api.hip routes them there)
+  if (p.glo_rows) return VIL_E_BACKEND;     // the fused global-query rows (vil_attn_bwd_full) are 16-bit
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   F32Cfg fc; f32_cfg(d, c, fc);
-  size_t off[6]; f32_ws_layout(d, c, fc, off);
+  size_t off[8]; f32_ws_layout(d, c, fc, off);
+  const bool hist = p.dtable != nullptr || (p.dg2l != nullptr && p.G > 0);
   float* ws = (float*)p.delta;
   if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.dout | (uintptr_t)p.out | (uintptr_t)p.dq | (uintptr_t)p.dk |
        (uintptr_t)p.dv | (uintptr_t)ws) & 15) return VIL_E_ALIGN;
@@ -582,20 +722,42 @@ int vil_f32_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   fc.kv_slots = (int2*)(ws + off[3]);
   fc.kv_nchunks = (int*)(fc.kv_slots + (size_t)fc.nch * fc.nqs);
   fc.glo_parts = ws + off[4];
+  fc.vnorm = (unsigned*)(ws + off[5]);
+  fc.hist_parts = (int*)(ws + off[6]);
   BwdCfg bc; memset(&bc, 0, sizeof(bc));
   bc.nch = fc.nch; bc.nsplit = 0; bc.nqs = fc.nqs; bc.kv_slots = fc.kv_slots; bc.kv_nchunks = fc.kv_nchunks;
   PrepZero zr; memset(&zr, 0, sizeof(zr));
+  if (hist) {
+    zr.ptr[0] = fc.vnorm; zr.n[0] = 32;
+    zr.ptr[1] = (unsigned*)p.dg2l; zr.n[1] = (p.dg2l && p.G > 0) ? p.H * p.G : 0;
+    // the LDS image covers only part of the caller's table: the rest of d(table) is 0
+    zr.ptr[2] = (unsigned*)p.dtable; zr.n[2] = (p.dtable && c.trows < p.bias_S) ? p.bias_S * p.bias_S * p.H : 0;
+    zr.total = zr.n[0] + zr.n[1] + zr.n[2];
+  }
   const VilWork w(d);
   vil_prof_begin(VIL_K_TABLE, s, 0, 0);
   int e = vil_mfma_launch_prep_bwd(p, c, bc, (int)p.k_st * 4, zr, s);
   vil_prof_end(s);
   if (e) return e;
+  if (hist) {
+    const int64_t rows4 = (int64_t)p.B * ((int64_t)p.G + (int64_t)p.g.nx * p.g.ny) * p.H * 4;
+    vil_prof_begin(VIL_K_DELTA, s, 0, 0);
+    F32_SWITCH((k_f32_vmax<MD_><<<dim3((unsigned)((rows4 + 255) / 256)), dim3(256), 0, s>>>(p, fc.vnorm)));
+    vil_prof_end(s);
+    if ((e = (int)hipGetLastError())) return e;
+  }
   vil_prof_begin(VIL_K_MFMA_DQ, s, w.dq_bytes() + w.delta_bytes(), w.dq_flops());
   {
-    const size_t lds = f32_lds(c, fc, false);
+    const size_t lds = f32_lds(c, fc, false, hist);
+    const dim3 grid((unsigned)(p.B * p.H * fc.wg_per_bh));
     F32_SWITCH({
-      if (int he = vil_ensure_dyn_lds((const void*)k_f32_bwd_dq<MD_, 2>, lds)) return he;
-      k_f32_bwd_dq<MD_, 2><<<dim3((unsigned)(p.B * p.H * fc.wg_per_bh)), dim3(256), lds, s>>>(p, c, fc);
+      if (hist) {
+        if (int he = vil_ensure_dyn_lds((const void*)k_f32_bwd_dq<MD_, 2, true>, lds)) return he;
+        k_f32_bwd_dq<MD_, 2, true><<<grid, dim3(256), lds, s>>>(p, c, fc);
+      } else {
+        if (int he = vil_ensure_dyn_lds((const void*)k_f32_bwd_dq<MD_, 2, false>, lds)) return he;
+        k_f32_bwd_dq<MD_, 2, false><<<grid, dim3(256), lds, s>>>(p, c, fc);
+      }
     });
   }
   vil_prof_end(s);
@@ -613,6 +775,12 @@ int vil_f32_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   if (p.G > 0) {
     vil_prof_begin(VIL_K_REDUCE_GLO, s, 0, 0);
     k_f32_glo_reduce<<<dim3((unsigned)(p.B * p.H * p.G)), dim3(128), 0, s>>>(p, fc);
+    vil_prof_end(s);
+    if ((e = (int)hipGetLastError())) return e;
+  }
+  if (hist) {
+    vil_prof_begin(VIL_K_REDUCE_BIAS, s, 0, 0);
+    k_f32_hist_reduce<<<dim3((unsigned)((c.tabsize + 63) / 64), (unsigned)p.H), dim3(1024), 0, s>>>(p, c, fc);
     vil_prof_end(s);
     e = (int)hipGetLastError();
   }

@@ -11,7 +11,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define VIL_HD __host__ __device__ __forceinline__
 #else
 #define VIL_HD inline

@@ -41,27 +41,26 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 //   Aq - Ak + aconst,  Aq = xq*P + yq,  Ak = X*P + Y,  aconst = tcen*(P+1) + CPAD,
 // so a lane gathers it with one v_sub (per key) and an immediate offset (per query of its quad).
 // P == 11 (mod 32) spreads the 16 query columns of a wave (x*P + 4*hq) over distinct banks.
-// ---- persistent workgroups (round 4).  The sliding-chunk passes used to launch one short-lived workgroup per group of
-// four chunks: waves of a workgroup walk 7 .. 14 key steps depending on where their chunk sits, the workgroup's slots
-// stay occupied until its slowest wave ends, each workgroup pays the table load + barrier, and B*H*chunks/4 workgroups on
-// 512 .. 768 resident slots quantise into rounds -- rocprofv3 counters (profiles/r04_pipe_utilisation.txt) showed 1.06
-// (48x48, M 64) to 2.4 (56x56, M 32) resident waves per SIMD of the 2 / 3 the registers allow.  Now a pass launches
-// exactly as many workgroups as are resident at once and every WAVE walks its own list of (image, chunk) units:
-//   * a workgroup is bound to one head (the bias-table image it holds in LDS: head = (blockIdx / 8) % H) and to the
-//     XCD the hardware places it on (blockIdx % 8), whose queue covers the images [B x / 8, B (x + 1) / 8) -- the H
-//     workgroups that walk the same images run on the same L2, as the (image, chunk group, head) launch order of round 2
-//     arranged;
+// ---- persistent workgroups of the dQ pass (round 4).  The sliding-chunk passes launch short-lived workgroups of four
+// adjacent chunks in (image, chunk group, head) order; the dQ pass could not (every workgroup leaves a histogram
+// partial), ran 4096 long-lived workgroups in (image, head) order and moved 1.83x its algorithmic bytes.  It now launches
+// as many workgroups as are resident at once, and every WAVE walks its own list of (image, chunk) units:
+//   * a workgroup is bound to one head (the bias-table image and histogram it holds in LDS: head = (blockIdx / 8) % H)
+//     and to the XCD the hardware places it on (blockIdx % 8), whose queue covers the images [B x / 8, B (x + 1) / 8) --
+//     the H workgroups that walk the same images run on the same L2;
 //   * entry k of wave w's list (w = the wave's index among the nw waves that serve the queue) is unit
-//     k * nw + (w + 37 k) mod nw: at any time the waves of an XCD work inside a window of ~nw units (two images: the L2
-//     footprint of round 2), the four waves of a workgroup are on ADJACENT chunks (their 3x3 neighbourhoods overlap:
-//     the CU's L1 serves part of their K / V reads -- dealing a workgroup's waves unrelated chunks cost 13 % at 48x48), and
-//     the rotation gives every wave a mix of interior, edge and corner chunks over its entries;
+//     k * nw + (w + 37 k) mod nw: at any time the waves of an XCD work inside a window of a few rows of nw units, the four
+//     waves of a workgroup sit on ADJACENT chunks (their 3x3 neighbourhoods overlap: the CU's L1 serves part of their
+//     K / V reads), and the rotation deals every wave a mix of interior, edge and corner chunks;
 //   * inside an image the chunks come in order of decreasing work (chunk_of_rank), so the last entries are short units.
-// Measured first, not kept (profiles/r04_queue_ablation.txt): (1) ONE atomic ticket counter per (XCD, head) in global
-// memory -- a returning global atomic in flight next to a wave's K / V load stream made the forward 2.6 - 3.6x slower
-// even with its result unused (loads return in order behind it, ~128 waves per counter queue up at the L2); (2) a
-// workgroup-level list drawn through an LDS counter: balances the four waves, but they no longer sit on adjacent chunks
-// (forward at 48x48: 74 us against 64.5 us for the per-wave lists, 72 - 74 us for round 3's short-lived workgroups).
+// dQ in the ViL-Small step: HBM traffic 1.83x -> 0.83x of the algorithmic bytes (profiles/r04_pmc_traffic.json), one
+// 64-bit histogram record per workgroup (768 instead of 4096: the reduce pass 32 -> 9 us).
+// The forward and dK/dV passes keep their short-lived workgroups: with per-wave lists they run at the same speed but the
+// waves drift apart over their entries and the L2 window with them (forward 1.05x -> 1.86x of the algorithmic bytes at
+// 56x56); handing units out through global atomic tickets -- per unit, per block of four, prefetched or not -- made
+// every pass 2 - 3.6x slower (a returning global atomic under these kernels' load stream takes tens of microseconds,
+// and loads return in order behind it); a workgroup-level list drawn through an LDS counter loses the adjacency
+// (forward at 48x48: 74 us against 64.5 us): profiles/r04_queue_ablation.txt.
 struct UnitQueue {
   int units_bh;          // units per (image, head)
   unsigned m_units_bh;   // vil_magic(units_bh)

@@ -199,7 +199,9 @@ class Attention(nn.Module):
         M = C // H
         nglo = self.nglo if self.rpe else (N - nx * ny if nx is not None else -1)
         gx, gy = (self.wx, self.wy) if self.rpe else (nx, ny)
-        ok = (qkv.is_cuda and qkv.dtype in (torch.bfloat16, torch.float16) and gx is not None and 0 <= nglo
+        # fp32 (the reference's CPU / test precision) takes the one-chunk case of the fp32 matrix-core kernels (round 4; it
+        # used to fall to scaled_dot_product_attention with a materialised (H, N, N) bias)
+        ok = (qkv.is_cuda and qkv.dtype in (torch.bfloat16, torch.float16, torch.float32) and gx is not None and 0 <= nglo
               and nglo + gx * gy == N and (self.attn_drop.p == 0.0 or not self.training))
         if ok and (dense_family_supported(qkv, gx, gy, nglo, H)
                    or (gx == gy and gx <= 32 and nglo <= FULL_MAX_G and M in (16, 32, 48, 64))):
