@@ -59,7 +59,7 @@ for STEP in "$@"; do
     profile)      # rocprofv3 kernel trace + stats of the bench command (graph mode) and its steady-state summary
       cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
       for CFG in vil_small_224 vil_medium_deep_384; do
-        timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$CFG" -o t -- python bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > "$OUT/trace_$CFG.json" 2> "$OUT/trace_$CFG.err"
+        timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$CFG" -o t -- python bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-eval --no-tertiary > "$OUT/trace_$CFG.json" 2> "$OUT/trace_$CFG.err"
         KT=$(find "$OUT/trace_$CFG" -name "*kernel_trace.csv" | head -1)
         ST=$(find "$OUT/trace_$CFG" -name "*kernel_stats.csv" | head -1)
         MARK="void k_mfma_fwd<bf16,2>"

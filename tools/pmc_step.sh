@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 rm -f "$OUT/tags.json"
 for CFG in vil_small_224 vil_medium_deep_384; do
-  ARGS="bench.py --graph off --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --config $CFG"
+  ARGS="bench.py --graph off --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-eval --no-tertiary --config $CFG"
   VIL_BENCH_DUMP_TAGS=$PWD/$OUT/tags.json timeout 600 python $ARGS > "$OUT/plain_$CFG.json" 2> "$OUT/plain_$CFG.err"
   timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_$CFG" -o pmc -- python $ARGS > "$OUT/fetch_$CFG.log" 2>&1
   timeout 900 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/write_$CFG" -o pmc -- python $ARGS > "$OUT/write_$CFG.log" 2>&1

@@ -48,6 +48,10 @@ __device__ __forceinline__ void glo_ld(const T* p, float (&v)[DPL]) {
 
 #define GLO_MAXG 4          // global tokens handled per pass (loops over G in chunks)
 #define GLO_THREADS 256
+// forward: 16 waves per (image, head) and two to four key rows per lane in flight.  Round 3 ran 4 waves per (image, head) with one
+// row per lane and no load ahead of its use: 49 (56x56) .. 144 (96x96) serial memory round trips per workgroup, 52 / 89 us
+// for 19 / 14 us of HBM time, on 96 .. 384 workgroups.
+#define GLO_FWD_THREADS 1024        // sequences of >= 2048 keys; shorter ones (28x28: 785 keys) keep 4 waves: fewer partials to merge
 #define GLO_NEG (-1.0e30f)
 
 struct GloParams {
@@ -62,21 +66,30 @@ struct GloParams {
   float* dg2g; float* dg2l0;               // accumulated with atomics, or null
 };
 
-// lane layout: 4 lanes per key row (each DPL = M/4 consecutive dims), 64 key rows per pass of 256 threads
-template <typename T, int M>
-__global__ __launch_bounds__(GLO_THREADS) void k_glo_fwd(GloParams p, int g0) {
-  constexpr int DPL = M / 4;
-  __shared__ float s_m[GLO_MAXG][4], s_l[GLO_MAXG][4];
-  __shared__ float s_o[GLO_MAXG][4][M];
-  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+// lane layout: 4 lanes per key row (each DPL = M/4 consecutive dims), 256 key rows per pass of 1024 threads, the rows of
+// GLO_FWD_ROWS passes loaded before any of them is used
+// NGT: global queries the instantiation keeps per lane (1: every published model, half the registers; GLO_MAXG otherwise)
+template <typename T, int M, int NGT, int NW>
+__device__ __forceinline__ void glo_fwd_body(const GloParams& p, int g0) {
+  constexpr int DPL = M / 4, RPP = NW * 16;
+  constexpr int GLO_FWD_ROWS = (M <= 32 && NGT == 1) ? 4 : 2;      // rows in flight per lane (128 registers per lane at 16 waves)
+  __shared__ float s_m[NGT][NW], s_l[NGT][NW];
+  __shared__ float s_o[NGT][NW][M];
+  // the H heads of an image share K / V cache lines (two heads per 128-byte line at head_dim 32): they run on the SAME
+  // XCD (the hardware places block i on XCD i % 8) in consecutive slots, so a line is fetched from HBM once
+  // (bh-ordered blocks put the heads of an image on different XCDs: 2.0x the algorithmic bytes, round 3)
+  const int slot = blockIdx.x >> 3;
+  const int b = (slot / p.H) * 8 + (int)(blockIdx.x & 7), h = slot % p.H;
+  if (b >= p.B) return;
+  const int bh = b * p.H + h;
   const int tid = threadIdx.x, sub = tid & 3, rowl = tid >> 2;
-  const int ng = min(GLO_MAXG, p.G - g0);
+  const int ng = min(NGT, p.G - g0);
   const int N = p.G + p.Nloc;
   const T* kb = (const T*)p.k + b * p.k_sb + h * p.k_sh;
   const T* vb = (const T*)p.v + b * p.v_sb + h * p.v_sh;
-  float q[GLO_MAXG][DPL], o[GLO_MAXG][DPL], m[GLO_MAXG], l[GLO_MAXG];
+  float q[NGT][DPL], o[NGT][DPL], m[NGT], l[NGT];
 #pragma unroll
-  for (int g = 0; g < GLO_MAXG; ++g) {
+  for (int g = 0; g < NGT; ++g) {
     m[g] = GLO_NEG; l[g] = 0.f;
 #pragma unroll
     for (int d = 0; d < DPL; ++d) {
@@ -84,38 +97,47 @@ __global__ __launch_bounds__(GLO_THREADS) void k_glo_fwd(GloParams p, int g0) {
       q[g][d] = g < ng ? GIO<T>::ld((const T*)p.q + b * p.q_sb + (int64_t)(g0 + g) * p.q_st + h * p.q_sh + sub * DPL + d) * p.scale : 0.f;
     }
   }
-  for (int j = rowl; j < N; j += GLO_THREADS / 4) {
-    float kk[DPL], vv[DPL];
-    glo_ld<T, DPL>(kb + (int64_t)j * p.k_st + sub * DPL, kk);
-    glo_ld<T, DPL>(vb + (int64_t)j * p.v_st + sub * DPL, vv);
+  for (int j0 = rowl; j0 < N; j0 += RPP * GLO_FWD_ROWS) {
+    float kk[GLO_FWD_ROWS][DPL], vv[GLO_FWD_ROWS][DPL];
 #pragma unroll
-    for (int g = 0; g < GLO_MAXG; ++g) {
-      if (g < ng) {
-        float s = 0.f;
+    for (int u = 0; u < GLO_FWD_ROWS; ++u) {
+      const int j = min(j0 + u * RPP, N - 1);                  // (rows past the end: loaded, not used)
+      glo_ld<T, DPL>(kb + (int64_t)j * p.k_st + sub * DPL, kk[u]);
+      glo_ld<T, DPL>(vb + (int64_t)j * p.v_st + sub * DPL, vv[u]);
+    }
 #pragma unroll
-        for (int d = 0; d < DPL; ++d) s = fmaf(q[g][d], kk[d], s);
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        if (j < p.G) { if (p.g2g) s += p.g2g[((int64_t)h * p.G + g0 + g) * p.G + j]; }
-        else if (p.g2l0) s += p.g2l0[h * p.G + g0 + g];
-        if (s > m[g]) {
-          const float a = __expf(m[g] - s);
-          l[g] *= a;
+    for (int u = 0; u < GLO_FWD_ROWS; ++u) {
+      const int j = j0 + u * RPP;
+      if (j >= N) break;
 #pragma unroll
-          for (int d = 0; d < DPL; ++d) o[g][d] *= a;
-          m[g] = s;
+      for (int g = 0; g < NGT; ++g) {
+        if (g < ng) {
+          float s = 0.f;
+#pragma unroll
+          for (int d = 0; d < DPL; ++d) s = fmaf(q[g][d], kk[u][d], s);
+          s += __shfl_xor(s, 1, 64);
+          s += __shfl_xor(s, 2, 64);
+          if (j < p.G) { if (p.g2g) s += p.g2g[((int64_t)h * p.G + g0 + g) * p.G + j]; }
+          else if (p.g2l0) s += p.g2l0[h * p.G + g0 + g];
+          if (s > m[g]) {
+            const float a = __expf(m[g] - s);
+            l[g] *= a;
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) o[g][d] *= a;
+            m[g] = s;
+          }
+          const float pr = __expf(s - m[g]);
+          l[g] += pr;
+#pragma unroll
+          for (int d = 0; d < DPL; ++d) o[g][d] = fmaf(pr, vv[u][d], o[g][d]);
         }
-        const float pr = __expf(s - m[g]);
-        l[g] += pr;
-#pragma unroll
-        for (int d = 0; d < DPL; ++d) o[g][d] = fmaf(pr, vv[d], o[g][d]);
       }
     }
   }
-  // merge: butterfly over the 16 row-groups of each wave, then the 4 waves through LDS
+  // merge: butterfly over the 16 row-groups of each wave, then the waves through LDS
   const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-  for (int g = 0; g < GLO_MAXG; ++g) {
+  for (int g = 0; g < NGT; ++g) {
     if (g >= ng) break;                            // (wave-uniform) G is 1 in every published model
 #pragma unroll
     for (int off = 4; off < 64; off <<= 1) {
@@ -134,12 +156,12 @@ __global__ __launch_bounds__(GLO_THREADS) void k_glo_fwd(GloParams p, int g0) {
     }
   }
   __syncthreads();
-  for (int e = tid; e < ng * M; e += GLO_THREADS) {
+  for (int e = tid; e < ng * M; e += NW * 64) {
     const int g = e / M, d = e % M;
     float mm = GLO_NEG;
-    for (int r = 0; r < 4; ++r) mm = fmaxf(mm, s_m[g][r]);
+    for (int r = 0; r < NW; ++r) mm = fmaxf(mm, s_m[g][r]);
     float ll = 0.f, oo = 0.f;
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NW; ++r) {
       const float a = __expf(s_m[g][r] - mm);
       ll = fmaf(s_l[g][r], a, ll);
       oo = fmaf(s_o[g][r][d], a, oo);
@@ -148,6 +170,13 @@ __global__ __launch_bounds__(GLO_THREADS) void k_glo_fwd(GloParams p, int g0) {
     if (d == 0) p.lse[(int64_t)bh * p.G + g0 + g] = mm + __logf(ll);
   }
 }
+
+template <typename T, int M>
+__global__ __launch_bounds__(GLO_FWD_THREADS) void k_glo_fwd(GloParams p, int g0) { glo_fwd_body<T, M, 1, GLO_FWD_THREADS / 64>(p, g0); }
+template <typename T, int M>
+__global__ __launch_bounds__(GLO_THREADS) void k_glo_fwd_short(GloParams p, int g0) { glo_fwd_body<T, M, 1, GLO_THREADS / 64>(p, g0); }
+template <typename T, int M>
+__global__ __launch_bounds__(GLO_THREADS) void k_glo_fwd_multi(GloParams p, int g0) { glo_fwd_body<T, M, GLO_MAXG, GLO_THREADS / 64>(p, g0); }
 
 template <typename T, int M>
 __global__ __launch_bounds__(GLO_THREADS) void k_glo_bwd(GloParams p, int g0) {
@@ -320,7 +349,10 @@ extern "C" int vil_glo_attn_fwd(const VilAttnDesc* d, const void* q_g, const voi
   vil_prof_tag_desc(d);
   const double e_ = d->dtype == VIL_DTYPE_F32 ? 4 : 2, n_ = (double)d->G + (double)d->nx * d->ny;
   vil_prof_begin(VIL_K_GLO_FWD, s, d->B * (2 * n_ + 2 * d->G) * d->H * d->M * e_, d->B * 4.0 * d->G * n_ * d->H * d->M);
-  GLO_DISPATCH(k_glo_fwd, dim3(d->B * d->H), dim3(GLO_THREADS), 0, s);
+  const dim3 grid((unsigned)(((d->B + 7) / 8) * 8 * d->H));        // (image, head) -> block: see glo_fwd_body
+  if (d->G > 1) { GLO_DISPATCH(k_glo_fwd_multi, grid, dim3(GLO_THREADS), 0, s); }
+  else if ((int64_t)d->nx * d->ny >= 2048) { GLO_DISPATCH(k_glo_fwd, grid, dim3(GLO_FWD_THREADS), 0, s); }
+  else { GLO_DISPATCH(k_glo_fwd_short, grid, dim3(GLO_THREADS), 0, s); }
   vil_prof_end(s);
   return (int)hipGetLastError();
 }

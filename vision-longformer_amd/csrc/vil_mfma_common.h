@@ -46,7 +46,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // partial), ran 4096 long-lived workgroups in (image, head) order and moved 1.83x its algorithmic bytes.  It now launches
 // as many workgroups as are resident at once, and every WAVE walks its own list of (image, chunk) units:
 //   * a workgroup is bound to one head (the bias-table image and histogram it holds in LDS: head = (blockIdx / 8) % H)
-//     and to the XCD the hardware places it on (blockIdx % 8), whose queue covers the images [B x / 8, B (x + 1) / 8) --
+//     and to the XCD the hardware places it on (blockIdx % 8), whose queue covers an eighth of the images --
 //     the H workgroups that walk the same images run on the same L2;
 //   * entry k of wave w's list (w = the wave's index among the nw waves that serve the queue) is unit
 //     k * nw + (w + 37 k) mod nw: at any time the waves of an XCD work inside a window of a few rows of nw units, the four
@@ -124,15 +124,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
 }
 
-__device__ __forceinline__ int uq_img0(int B, int x) { return (B * x) >> 3; }
 // The unit list of one wave.  entry(k) returns the k-th unit as an index into head h's image-major unit list, or -1 when
 // the list is exhausted (entries grow: once one is beyond the queue, all later ones are).
 struct UnitList {
   int q0, nq, w, nw;     // the (XCD, head) queue: first unit, units; this wave's index among the queue's nw waves
   __device__ __forceinline__ void init(const UnitQueue& q, int B, int H, int wave, int waves_per_wg) {
+    // the XCD's share of head h's image-major unit list: an eighth of the UNITS (whole images when B is a multiple of 8;
+    // with B < 8 -- the reference's operator benchmark runs B = 2 -- image boundaries fall inside a queue)
     const int xcd = blockIdx.x & 7;
-    const int i0 = uq_img0(B, xcd);
-    q0 = i0 * q.units_bh; nq = (uq_img0(B, xcd + 1) - i0) * q.units_bh;
+    const long long U = (long long)B * q.units_bh;
+    q0 = (int)((U * xcd) >> 3); nq = (int)((U * (xcd + 1)) >> 3) - q0;
     w = ((int)(blockIdx.x >> 3) / H) * waves_per_wg + wave; nw = ((int)gridDim.x / (8 * H)) * waves_per_wg;
   }
   __device__ __forceinline__ int entry(int k) const {

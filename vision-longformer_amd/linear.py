@@ -370,7 +370,7 @@ class _GeluLinearFn(torch.autograd.Function):
 def vil_gelu_linear(h, weight, bias, a=None):
     """F.linear(F.gelu(h), weight, bias) (exact GELU) whose backward fuses the GELU derivative into the input-gradient
     GEMM; same autocast semantics as vil_linear.  a: gelu(h) when the caller already has it (vil_linear_gelu)."""
-    if h.is_cuda and torch.is_grad_enabled():
+    if h.is_cuda:                   # (also under no_grad: the evaluation forward runs the same kernels)
         if torch.is_autocast_enabled("cuda"):
             dt = torch.get_autocast_dtype("cuda")
             h, w = h.to(dt), weight.to(dt)
@@ -384,7 +384,7 @@ def vil_gelu_linear(h, weight, bias, a=None):
 def vil_linear_gelu(x, weight, bias):
     """(h, gelu(h)) with h = F.linear(x, weight, bias): the head of the MLP block (reference msvit.py:29-31) as one
     autograd node -- one launch where the weights-in-registers GEMM serves the shape.  Feed both to vil_gelu_linear."""
-    if x.is_cuda and torch.is_grad_enabled():
+    if x.is_cuda:
         if torch.is_autocast_enabled("cuda"):
             dt = torch.get_autocast_dtype("cuda")
             x, w = x.to(dt), weight.to(dt)
@@ -399,7 +399,7 @@ def vil_linear_gelu(x, weight, bias):
 def vil_linear(x, weight, bias):
     """F.linear with the library's weight / bias gradient on device tensors (any number of tokens: every bias
     gradient must stay off PyTorch's multi-block reductions, see _colsum)."""
-    if x.is_cuda and torch.is_grad_enabled():
+    if x.is_cuda:
         if torch.is_autocast_enabled("cuda"):
             dt = torch.get_autocast_dtype("cuda")
             # autocast semantics of nn.Linear: inputs and parameters in the autocast dtype
@@ -477,7 +477,7 @@ def vil_linear_pair(x, lin1, lin2):
     """lin1(x) and lin2(x) as ONE projection (columns [lin1 | lin2]); None when the pair cannot run packed (the
     caller then applies the two Linears separately)."""
     w1, w2, b1, b2 = lin1.weight, lin2.weight, lin1.bias, lin2.bias
-    if not (x.is_cuda and torch.is_grad_enabled() and w1.dtype == w2.dtype and w1.dtype == x.dtype == torch.bfloat16
+    if not (x.is_cuda and w1.dtype == w2.dtype and w1.dtype == x.dtype == torch.bfloat16
             and (b1 is None) == (b2 is None) and w1.shape[1] == w2.shape[1]):
         return None
     if not (_adjacent(w1, w2) and (b1 is None or _adjacent(b1, b2))):

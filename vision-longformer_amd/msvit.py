@@ -508,7 +508,7 @@ class MsViT(nn.Module):
                 continue
             if pend is not None and res_layernorm_ok(x, pend[0], blk.norm):
                 x, y = res_layernorm(x, pend[0], pend[1], blk.norm)
-            elif pend is None and torch.is_grad_enabled() and x.requires_grad and pass_layernorm_ok(x, blk.norm):
+            elif pend is None and (x.requires_grad or not torch.is_grad_enabled()) and pass_layernorm_ok(x, blk.norm):
                 x, y = pass_layernorm(x, blk.norm)      # first block of a stage: x feeds the norm AND the residual stream
             else:
                 x = self._settle(x, pend)
