@@ -11,15 +11,24 @@
 //     {8g+4..8g+7} in the odd one) -> one 16-byte store per lane and tile pair, bias added from registers;
 //   * the in-tile of a step is read from LDS by every wave (B fragments, ds_read_b128 from the XOR-swizzled 128-byte-row
 //     image of vil_attn_dense.hip, one image per 64 k);
-//   * no workgroup barrier except the one that publishes a landed tile (each wave waits for its own LDS-DMA requests
-//     before the tile's first store: lds_dma_wait, vil_mfma_common.h).
+//   * one extra wave per workgroup is a LOADER (round 4): it issues every LDS-DMA request of the ring and owns their
+//     completion (a counted s_waitcnt vmcnt in front of the barrier that publishes a tile; its vmcnt sees loads only).
+//     Until round 4 every wave requested its share of the next tiles and waited for it with s_waitcnt vmcnt(0) before
+//     the tile's first store -- which also waits for the PREVIOUS tile's stores (gfx9: one counter for loads and
+//     stores), and the __syncthreads() that published a tile carried a release fence, i.e. another vmcnt(0).  With a K
+//     loop of ~0.5 us per tile and ~2 us for a store to drain, the waves spent 73 % of their time in those waits
+//     (profiles/r04_pipe_utilisation.txt: stage 1's qkv projection ran at 1.96 TB/s).  The compute waves now never
+//     execute s_waitcnt vmcnt inside the tile loop and the tile barrier is a bare s_barrier.
 #include "vil_mfma_common.h"
+
+__device__ __forceinline__ void sk_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 struct SkParams {
   const void* in; const void* w; const void* bias; void* out;
   void* out2;                 // GELU instantiations: gelu(out), same layout
   int T, K, N;
   int in_rs, out_rs;          // row strides (elements)
+  int n0, n1;                 // the output features [n0, n1) this launch computes (the whole row unless N needs > 7 waves)
   int wn, wt;                 // waves along n (32 * NP features each) x waves along t
   int ntiles;                 // ceil(T / RT)
 };
@@ -51,10 +60,10 @@ __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
   constexpr int SLOT = KB * IMG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6;   // nwaves - 1 compute waves + the loader
   const int lj = lane & 15, lg = lane >> 4;
   const int wni = wave % p.wn, wti = wave / p.wn;
-  const int n_base = wni * (32 * NP);
+  const int n_base = p.n0 + wni * (32 * NP);
   const int rows_w = RT / p.wt;                    // token rows of a tile this wave computes
   const int r_base = wti * rows_w;
 
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           X8 z = {};
-          afr[pr][hf][ks] = n < p.N ? *(const X8*)(wb + (int64_t)n * p.K + ks * 32 + lg * 8) : z;
+          afr[pr][hf][ks] = n < p.n1 ? *(const X8*)(wb + (int64_t)n * p.K + ks * 32 + lg * 8) : z;
         }
       }
   } else {
@@ -117,50 +126,56 @@ __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
   for (int pr = 0; pr < NP; ++pr) {
     X8 z = {};
     const int n8 = n_base + 32 * pr + 8 * lg;
-    bias8[pr] = (p.bias && n8 < p.N) ? *(const X8*)((const T_*)p.bias + n8) : z;
+    bias8[pr] = (p.bias && n8 < p.n1) ? *(const X8*)((const T_*)p.bias + n8) : z;
   }
 
   // ---- in-tile ring (LDS-DMA): piece = 8 rows x 128 bytes of one 64-k image
-  const __amdgpu_buffer_rsrc_t irs = make_rsrc_n(p.in, (unsigned)(((int64_t)(p.T - 1) * p.in_rs + p.K) * 2));
-  const int drow = lane >> 3, dslot = lane & 7, dchunk = dslot ^ (((drow >> 1) & 3) << 1);
-  const int in_v0 = drow * (p.in_rs * 2) + dchunk * 16;
-  auto issue = [&](int tile, int slot) {
-    char* base = smem + slot * SLOT;
-    const int t0 = tile * RT;
-    for (int pc = wave; pc < KB * (RT / 8); pc += nwaves) {
-      const int kb = pc / (RT / 8), pp = pc - kb * (RT / 8);
-      // (the last image of an odd KS holds 32 k: its upper four chunks per row are not requested)
-      if (kb * 2 + 1 < KS || dchunk < 4)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)(base + kb * IMG + pp * 1024),
-                                                 16, in_v0 + (t0 + pp * 8) * (p.in_rs * 2) + kb * 128, 0, 0, 0);
+  const int first = blockIdx.x;
+  if (wave == nwaves - 1) {                                // ---- the loader wave
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int PIECES = KB * (RT / 8);                  // requests per tile
+    static_assert(PIECES <= 63, "counted wait");
+    const __amdgpu_buffer_rsrc_t irs = make_rsrc_n(p.in, (unsigned)(((int64_t)(p.T - 1) * p.in_rs + p.K) * 2));
+    const int drow = lane >> 3, dslot = lane & 7, dchunk = dslot ^ (((drow >> 1) & 3) << 1);
+    const int in_v0 = drow * (p.in_rs * 2) + dchunk * 16;
+    auto issue = [&](int tile, int slot) {
+      char* base = smem + slot * SLOT;
+      const int t0 = tile * RT;
+#pragma unroll 4
+      for (int pc = 0; pc < PIECES; ++pc) {
+        const int kb = pc / (RT / 8), pp = pc - kb * (RT / 8);
+        // (the last image of an odd KS holds 32 k: its upper four chunks per row are not requested)
+        if (kb * 2 + 1 < KS || dchunk < 4)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)(base + kb * IMG + pp * 1024),
+                                                   16, in_v0 + (t0 + pp * 8) * (p.in_rs * 2) + kb * 128, 0, 0, 0);
+      }
+    };
+    lds_dma_wait();                                        // (this wave's share of the weight loads above)
+    for (int a = 0; a < NSLOT - 1; ++a)
+      if (first + a * (int)gridDim.x < p.ntiles) issue(first + a * gridDim.x, a);
+    int it = 0;
+    for (int tile = first; tile < p.ntiles; tile += gridDim.x, ++it) {
+      // tile it has landed: of this wave's requests only those of tile it + 1 (NSLOT - 2 tiles ahead) may be in flight
+      if (NSLOT > 2 && tile + (int)gridDim.x < p.ntiles) lds_dma_wait<PIECES*(NSLOT > 2 ? 1 : 0)>();
+      else lds_dma_wait();
+      sk_barrier();                                        // ... and every compute wave is done with tile it - 1
+      const int nxt = tile + (NSLOT - 1) * gridDim.x;
+      if (nxt < p.ntiles) issue(nxt, (it + NSLOT - 1) % NSLOT);
     }
-  };
+    return;
+  }
   int bnat[2];
 #pragma unroll
   for (int k2 = 0; k2 < 2; ++k2) bnat[k2] = sk_off(lj, k2 * 64 + lg * 16);
 
   T_* ob = (T_*)p.out;
   int it = 0;
-  const int first = blockIdx.x;
-  if (first < p.ntiles) issue(first, 0);
-  lds_dma_wait();                                         // the first tile (and the weight / bias loads)
   for (int tile = first; tile < p.ntiles; tile += gridDim.x, ++it) {
     const int slot = it % NSLOT;
-    // every wave has waited for its own requests of the tiles up to it + NSLOT - 2 (before the loop, or below before the
-    // first store of the previous tile): this tile has landed; the slot of it + NSLOT - 1 is free
-    __syncthreads();
-    const int nxt = tile + (NSLOT - 1) * gridDim.x;
-    if (NSLOT > 1) {
-      // keep NSLOT-1 tiles in flight: request tile it+NSLOT-1 into the slot that tile it-1 has just released
-      if (it == 0) {
-        for (int a = 1; a < NSLOT - 1; ++a)
-          if (tile + a * (int)gridDim.x < p.ntiles) issue(tile + a * gridDim.x, a);
-      }
-      if (nxt < p.ntiles) issue(nxt, (it + NSLOT - 1) % NSLOT);
-    }
+    sk_barrier();                                          // tile it is in its slot (the loader waited for it)
     const char* tb = smem + slot * SLOT;
     const int t0 = tile * RT;
-    if (n_base < p.N) {
+    if (n_base < p.n1) {
       for (int r0 = r_base; r0 < r_base + rows_w; r0 += 16 * TT) {     // 16*TT token rows at a time
         const int ntt = min(TT, (r_base + rows_w - r0) >> 4);
         f32x4 acc[NP][2][TT];
@@ -183,9 +198,6 @@ __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
 #pragma unroll
               for (int tt = 0; tt < TT; ++tt) acc[pr][hf][tt] = mfma16(afr[pr][hf][ks], bq[tt], acc[pr][hf][tt]);
         }
-        // the requests for the tiles ahead have had the MFMA phase to land: wait for them HERE, before the tile's first
-        // store (stores share vmcnt and must not be waited for at the next barrier)
-        if (r0 == r_base) lds_dma_wait();
         // epilogue: lane (j, g) of pair pr, column tile tt: token t0 + r0 + 16 tt + j, features n_base + 32 pr + 8 g .. +7
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
 #pragma unroll
             for (int pr = 0; pr < NP; ++pr) {
               const int n8 = n_base + 32 * pr + 8 * lg;
-              if (n8 < p.N) {
+              if (n8 < p.n1) {
                 X8 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -214,27 +226,38 @@ __global__ __launch_bounds__(512, 2) void k_skinny(SkParams p) {
           }
         }
       }
-    } else lds_dma_wait();                                // (a wave without output features still owns requests)
+    }
   }
 }
 
 template <int KS, int NP, int TT, int RT, int NSLOT, bool NN, bool GELU = false>
 static int sk_launch(SkParams& p, int ncu, hipStream_t s) {
-  p.wn = (p.N + 32 * NP - 1) / (32 * NP);
-  if (p.wn > 8) return VIL_E_BACKEND;
-  // waves along t: as many as the tile's 16*TT-row chunks and the 8-wave workgroup allow (K <= 192: the shape the
-  // first version was tuned with -- 4 / 2 / 1 for 1 / 2 / >= 3 waves along n)
-  const int by_rows = RT / (16 * TT), by_waves = 8 / p.wn;
-  p.wt = KS <= 6 ? (p.wn == 1 ? 4 : (p.wn == 2 ? 2 : 1)) : (by_rows < by_waves ? by_rows : by_waves);
-  if (p.wt < 1) p.wt = 1;
-  p.ntiles = (p.T + RT - 1) / RT;
-  const size_t lds = (size_t)NSLOT * ((KS + 1) / 2) * RT * 128;
-  const int wg_per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
-  int grid = ncu * wg_per_cu;
-  if (grid > p.ntiles) grid = p.ntiles;
-  if (int he = vil_ensure_dyn_lds((const void*)k_skinny<KS, NP, TT, RT, NSLOT, NN, GELU>, lds)) return he;
-  k_skinny<KS, NP, TT, RT, NSLOT, NN, GELU><<<dim3(grid), dim3(64 * p.wn * p.wt), lds, s>>>(p);
-  return (int)hipGetLastError();
+  // 7 compute waves + the loader = 8 waves of 256 registers: a row of more than 7 x 32 NP features (N = 768 at 96 per
+  // wave) is computed in two launches over the two halves of the features
+  const int wn_all = (p.N + 32 * NP - 1) / (32 * NP);
+  const int nwin = wn_all > 7 ? 2 : 1;
+  if (wn_all > 14) return VIL_E_BACKEND;
+  const int wn_first = (wn_all + nwin - 1) / nwin;
+  for (int win = 0; win < nwin; ++win) {
+    p.n0 = win * wn_first * (32 * NP);
+    p.n1 = win + 1 < nwin ? (win + 1) * wn_first * (32 * NP) : p.N;
+    p.wn = (p.n1 - p.n0 + 32 * NP - 1) / (32 * NP);
+    // waves along t: as many as the tile's 16*TT-row chunks and the 7 compute waves allow (K <= 192: 4 / 2 / 2 / 1 for
+    // 1 / 2 / 3 / >= 4 waves along n)
+    const int by_rows = RT / (16 * TT), by_waves = 7 / p.wn;
+    p.wt = KS <= 6 ? (p.wn == 1 ? 4 : (p.wn <= 3 ? 2 : 1)) : (by_rows < by_waves ? by_rows : by_waves);
+    if (p.wt < 1) p.wt = 1;
+    p.ntiles = (p.T + RT - 1) / RT;
+    const size_t lds = (size_t)NSLOT * ((KS + 1) / 2) * RT * 128;
+    // resident workgroups per CU: by LDS, and by waves (the kernel is compiled for 2 waves per SIMD)
+    const int wg_per_cu = (lds * 2 <= 160 * 1024 && 2 * (p.wn * p.wt + 1) <= 8) ? 2 : 1;
+    int grid = ncu * wg_per_cu;
+    if (grid > p.ntiles) grid = p.ntiles;
+    if (int he = vil_ensure_dyn_lds((const void*)k_skinny<KS, NP, TT, RT, NSLOT, NN, GELU>, lds)) return he;
+    k_skinny<KS, NP, TT, RT, NSLOT, NN, GELU><<<dim3(grid), dim3(64 * (p.wn * p.wt + 1)), lds, s>>>(p);
+    if (int he = (int)hipGetLastError()) return he;
+  }
+  return 0;
 }
 
 // CU count of the current device, queried once per device (a device-attribute query is not a legal call while another
@@ -254,7 +277,7 @@ static int sk_cu_count() {
 // op 1: out[T][N] = in[T][K] . w[K][N]                  (its input gradient: w = the weight as stored, K = out_features)
 // bf16, fp32 accumulate.  VIL_E_BACKEND outside the table below (the caller then uses the library GEMM).
 //   K     features / wave   rows / tile   ring        stages it serves (ViL: C = 96, 192)
-//   96      96                 128        2 x 32 KB   qkv / proj / fc1 forward and proj input gradient at C = 96
+//   96      96                 128        3 x 32 KB   qkv / proj / fc1 forward and proj input gradient at C = 96
 //   192     96                 128        3 x 48 KB   the same at C = 192
 //   288     32                  64        3 x 40 KB   qkv input gradient at C = 96
 //   384     32                  64        3 x 48 KB   fc2 forward, fc1 input gradient at C = 96
@@ -276,7 +299,7 @@ extern "C" int vil_gemm_skinny_bf16(int op, const void* in, const void* w, const
   hipStream_t s = (hipStream_t)stream;
 #define SK_CASE(KK, KS, NP, TT, RT, NSLOT)                                                   \
   if (K == KK) return op ? sk_launch<KS, NP, TT, RT, NSLOT, true>(p, ncu, s) : sk_launch<KS, NP, TT, RT, NSLOT, false>(p, ncu, s);
-  SK_CASE(96, 3, 3, 4, 128, 2)
+  SK_CASE(96, 3, 3, 4, 128, 3)
   SK_CASE(192, 6, 3, 2, 128, 3)
   if (N > 256) return VIL_E_BACKEND;              // (32 features per wave from here on)
   SK_CASE(288, 9, 1, 2, 64, 3)
@@ -304,5 +327,5 @@ extern "C" int vil_gemm_skinny_gelu_bf16(const void* in, const void* w, const vo
   p.in_rs = (int)in_row_stride; p.out_rs = (int)out_row_stride;
   const int ncu = sk_cu_count();
   hipStream_t s = (hipStream_t)stream;
-  return K == 96 ? sk_launch<3, 3, 4, 128, 2, false, true>(p, ncu, s) : sk_launch<6, 3, 2, 128, 3, false, true>(p, ncu, s);
+  return K == 96 ? sk_launch<3, 3, 4, 128, 3, false, true>(p, ncu, s) : sk_launch<6, 3, 2, 128, 3, false, true>(p, ncu, s);
 }

@@ -194,6 +194,9 @@ template <int OFF> __device__ __forceinline__ s16x4 lds_tr_issue(unsigned addr) 
 __device__ __forceinline__ void lds_tr_settle(s16x4& a, s16x4& b, s16x4& c, s16x4& d, s16x4& e, s16x4& f, s16x4& g, s16x4& h) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
 }
+__device__ __forceinline__ void lds_tr_settle(s16x4& a, s16x4& b, s16x4& c, s16x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 template <typename T> __device__ __forceinline__ typename V16<T>::x8 lds_tr_join(s16x4 lo, s16x4 hi) {
   typedef typename V16<T>::x4 X4;
   const X4 l = __builtin_bit_cast(X4, lo), h = __builtin_bit_cast(X4, hi);
