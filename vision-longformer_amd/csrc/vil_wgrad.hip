@@ -221,8 +221,19 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgradParams p) {
 //   * partial records are written in accumulator order (1 KB contiguous per store instruction); the reduce pass
 //     un-permutes; db: column sums on the VALU, the 16-row blocks dealt over the waves that hold the same dY rows.
 #include "vil_mfma_common.h"
+#include <type_traits>
 
+#ifndef WG2_SWZ_OLD
+// (round 4: + bit 2 of the row.  Rows r and r + 4 of a stage start on the same bank -- 4 x 192 and 4 x 384 bytes are
+// multiples of 256 -- and the two 16-lane groups of a half wave read exactly such a pair: SQ_LDS_BANK_CONFLICT was 50 % of
+// SQ_LDS_IDX_ACTIVE for both operand widths.  With the extra term the 8 rows x 32 bytes of a half wave cover 8 different
+// 32-byte bank groups, and the 4 rows of a 16-lane group still cover 4.)
+template <int W> __device__ __forceinline__ int wg2_swz(int row) {
+  return W == 192 ? ((row & 3) ^ ((row >> 2) & 1)) : (((row >> 1) & 1) ^ ((row >> 2) & 1));
+}
+#else
 template <int W> __device__ __forceinline__ int wg2_swz(int row) { return W == 192 ? (row & 3) : ((row >> 1) & 1); }
+#endif
 
 __device__ __forceinline__ unsigned wg2_lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
@@ -317,9 +328,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(WgradParams p) {
   {
     const int r = lg * 4 + (lj >> 2);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) aoff[i] = r * PA + (((ch * MI + i) ^ wg2_swz<TM>(lj >> 2)) << 5) + (lj & 3) * 8;
+    for (int i = 0; i < MI; ++i) aoff[i] = r * PA + (((ch * MI + i) ^ wg2_swz<TM>(r)) << 5) + (lj & 3) * 8;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) boff[j] = ABYTES + r * PB + (((cw * NJ + j) ^ wg2_swz<TN>(lj >> 2)) << 5) + (lj & 3) * 8;
+    for (int j = 0; j < NJ; ++j) boff[j] = ABYTES + r * PB + (((cw * NJ + j) ^ wg2_swz<TN>(r)) << 5) + (lj & 3) * 8;
   }
 
   wg_f32x4 acc[MI][NJ];
@@ -335,19 +346,30 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(WgradParams p) {
 
 #pragma unroll
   for (int a = 0; a < NST - 1; ++a) issue(a, a);
-  for (int st = 0; st < nsteps; ++st) {
+  // The step loop is unrolled NST times so that a step's ring slot is a compile-time constant: the slot offset rides in the
+  // offset field of every transposed read and in the scalar arithmetic of the DMA requests (round 4: the runtime
+  // `st % NST` cost 18 vector adds, two scalar multiply-high modulo sequences and five M0 selects per step -- 135 issued
+  // instructions per 18 MFMAs, profiles/r04_pmc_k_wgrad2_6_3_3_wgrad_s3_fc1.json).
+  const unsigned S0 = wg2_lds_addr(wsm);
+  unsigned aad[MI], bad[NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) aad[i] = S0 + aoff[i];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) bad[j] = S0 + boff[j];
+  auto step = [&](int st, auto slot_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
     wg2_wait_barrier<DPW * (NST - 2)>();                 // stage st has landed everywhere; the slot of st - 1 is free
-    issue(st + NST - 1, (st + NST - 1) % NST);
+    issue(st + NST - 1, (SLOT + NST - 1) % NST);
     // The transposed reads are issued as inline assembly: through the builtin the compiler treats them as LDS WRITES
     // that may alias the DMA requests in flight and puts s_waitcnt vmcnt(0) in front of the first one, which
     // serialises every step behind the stage it has just requested.  Order and completion are handled here: the
     // reads return in order, the first wait releases the a fragments and half of b, the second the rest.
-    const unsigned S = wg2_lds_addr(wsm) + (st % NST) * STAGE;
+    constexpr int SO = SLOT * STAGE;
     wg_s16x4 al[MI], ah[MI], bl[NJ], bh[NJ];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) { al[i] = wg2_tr<0>(S + aoff[i]); ah[i] = wg2_tr<16 * PA>(S + aoff[i]); }
+    for (int i = 0; i < MI; ++i) { al[i] = wg2_tr<SO>(aad[i]); ah[i] = wg2_tr<SO + 16 * PA>(aad[i]); }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { bl[j] = wg2_tr<0>(S + boff[j]); bh[j] = wg2_tr<16 * PB>(S + boff[j]); }
+    for (int j = 0; j < NJ; ++j) { bl[j] = wg2_tr<SO>(bad[j]); bh[j] = wg2_tr<SO + 16 * PB>(bad[j]); }
     constexpr int NJ0 = NJ / 2 + (NJ & 1), LATE = 2 * (NJ - NJ0);
     if constexpr (MI == 6) wg2_settle<LATE>(al[0], ah[0], al[1], ah[1], al[2], ah[2], al[MI - 3], ah[MI - 3], al[MI - 2], ah[MI - 2], al[MI - 1], ah[MI - 1]);
     else wg2_settle<LATE>(al[0], ah[0], al[1], ah[1], al[2], ah[2]);
@@ -379,6 +401,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad2(WgradParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) dbs[i] += (float)a[i][e];
       }
+  };
+  static_assert(NST == 3, "the step loop is unrolled by hand");
+  for (int st = 0; st < nsteps; st += NST) {
+    step(st, std::integral_constant<int, 0>{});
+    if (st + 1 < nsteps) step(st + 1, std::integral_constant<int, 1>{});
+    if (st + 2 < nsteps) step(st + 2, std::integral_constant<int, 2>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zero-filling requests past the last step
 
