@@ -66,7 +66,6 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;            // 32-wide K steps over the head dim
   constexpr int VCH = 2 * MD;                 // 16-byte chunks per V row
-  constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;  // V tile XOR swizzle needs rows that are multiples of 64 B
   constexpr bool PIPE = VIL_FWD_PIPE && MD <= 2;   // software pipeline over steps (two score tiles + two LDS V tiles live)
   constexpr int PF = MD <= 2 ? (PIPE ? 2 : VIL_FWD_PF) : 1;   // depth of the K / V prefetch ring (M = 64 runs at 244 registers)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   for (int it = 0; it < MD; ++it) {
     const int cid = it * 64 + lane;
     const int row = cid / VCH, chn = cid % VCH;
-    vst_off[it] = row * (M * 2) + ((chn * 16) ^ (SWZ * (((row >> 2) & 1) << 5)));
+    vst_off[it] = row * (M * 2) + ((chn * 16) ^ tile_swz<MD>(row));
     vld_off[it] = chn * 16;
   }
 #pragma unroll
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
     const int row = hf * 16 + lg * 4 + (lj >> 2);
 #pragma unroll
     for (int dt = 0; dt < MD; ++dt)
-      vtr_off[hf][dt] = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
+      vtr_off[hf][dt] = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ tile_swz<MD>(row));
   }
   const int lgo = lg * 16;
 

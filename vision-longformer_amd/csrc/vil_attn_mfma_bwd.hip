@@ -45,7 +45,6 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;
   constexpr int VCH = 2 * MD;
-  constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;
   constexpr bool PIPE = VIL_DQ_PIPE && MD == 2;   // software pipeline over steps (two score tiles + two LDS K tiles live; M = 16 runs QT = 4 and would spill)
   constexpr int PF = PIPE ? 2 : (MD <= 2 ? VIL_DQ_PF : 1);   // depth of the K / V prefetch ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
   for (int it = 0; it < MD; ++it) {
     const int cid = it * 64 + lane;
     const int row = cid / VCH, chn = cid % VCH;
-    kst_off[it] = row * (M * 2) + ((chn * 16) ^ (SWZ * (((row >> 2) & 1) << 5)));
+    kst_off[it] = row * (M * 2) + ((chn * 16) ^ tile_swz<MD>(row));
     kld_off[it] = chn * 16;
   }
 #pragma unroll
@@ -121,11 +120,11 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
     const int row = hf * 16 + lg * 4 + (lj >> 2);
 #pragma unroll
     for (int dt = 0; dt < MD; ++dt)
-      ktr_off[hf][dt] = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
+      ktr_off[hf][dt] = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ tile_swz<MD>(row));
     const int row2 = hf * 16 + lj;
 #pragma unroll
     for (int ks = 0; ks < MK; ++ks)
-      krow_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ (SWZ * (((row2 >> 2) & 1) << 5)));
+      krow_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ tile_swz<MD>(row2));
   }
   const int lgo = lg * 16;
 
@@ -611,7 +610,6 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   constexpr int M = 16 * MD;
   constexpr int MK = (MD + 1) / 2;
   constexpr int VCH = 2 * MD;
-  constexpr int SWZ = (MD % 2 == 0) ? 1 : 0;
   constexpr bool PIPE = VIL_KV_PIPE && MD == 2 && KT == 2;   // software pipeline over steps (two score / dP tile sets, two LDS Q / dO tiles)
   constexpr int PF = PIPE ? 2 : (MD == 2 ? VIL_KV_PF : 1);   // depth of the Q / dO prefetch ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -654,7 +652,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   for (int it = 0; it < MD; ++it) {
     const int cid = it * 64 + lane;
     const int row = cid / VCH, chn = cid % VCH;
-    st_off[it] = row * (M * 2) + ((chn * 16) ^ (SWZ * (((row >> 2) & 1) << 5)));
+    st_off[it] = row * (M * 2) + ((chn * 16) ^ tile_swz<MD>(row));
     ld_off[it] = chn * 16;
   }
 #pragma unroll
@@ -662,11 +660,11 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     const int row = hf * 16 + lg * 4 + (lj >> 2);
 #pragma unroll
     for (int dt = 0; dt < MD; ++dt)
-      tr_off[hf][dt] = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ (SWZ * (((row >> 2) & 1) << 5)));
+      tr_off[hf][dt] = row * (M * 2) + ((dt * 32 + (lj & 3) * 8) ^ tile_swz<MD>(row));
     const int row2 = hf * 16 + lj;
 #pragma unroll
     for (int ks = 0; ks < MK; ++ks)
-      row_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ (SWZ * (((row2 >> 2) & 1) << 5)));
+      row_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ tile_swz<MD>(row2));
   }
 
   const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const T*)p.q + b * p.q_sb + h * p.q_sh);

@@ -117,6 +117,22 @@ __device__ __forceinline__ __attribute__((address_space(3))) int* lds_i32(unsign
 // three-operand maximum (v_max3_f32)
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
+// XOR swizzle (bytes, a multiple of 32) of the wave-private [32 rows][16 MD elements] LDS tiles of the sliding-chunk kernels.
+// The tiles are read three ways: ds_read_b64_tr_b16 (two 32-lane groups, lane (j, g) -> row 4g + j/4, 8 bytes of a 32-byte
+// run), ds_read_b128 along rows (four 16-lane groups), ds_write_b128 (eight 8-lane groups); banks are (a / 4) mod 64
+// for all three (MI355X_MICROARCH.md, LDS).  64-byte rows (head_dim 32): rows r and r + 4 share their banks -> flip the
+// 32-byte half with bit 2 of the row.  128-byte rows (head_dim 64): rows r and r + 2 share their banks, so the four
+// even (odd) rows of a group need four different 32-byte quarters: bits 1-2 of the row (round 4: it had been bit 2 only,
+// as for 64-byte rows -- SQ_LDS_BANK_CONFLICT 26 / 43 / 32 % of the forward / dQ / dK,dV LDS cycles at head_dim 64).
+// Odd MD (96-byte rows): no swizzle.
+template <int MD> __device__ __forceinline__ constexpr int tile_swz(int row) {
+#ifdef VIL_TILE_SWZ_OLD
+  return (MD % 2 == 0) ? (((row >> 2) & 1) << 5) : 0;
+#else
+  return MD == 4 ? (((row >> 1) & 3) << 5) : (MD == 2 ? (((row >> 2) & 1) << 5) : 0);
+#endif
+}
+
 // XCD-aware bijective remap: consecutive logical workgroups (same image/head, neighbouring
 // chunks -> shared K/V) land on the same XCD's L2 (hardware places block b on XCD b % 8)
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
