@@ -318,6 +318,11 @@ int vil_linear_wgrad_tune(const void* dy, const void* x, int64_t T, int CO, int 
  * the cost model.  For restoring an earlier selection, measurements and tests.  VIL_E_SHAPE for a plan that does not
  * fit the problem. */
 int vil_linear_wgrad_set_plan(int64_t T, int CO, int CI, int gen, int mi, int nj, int m);
+/* Reads the plan vil_linear_wgrad would run: plan = {gen, mi, nj, m, tuned} (tuned = 1: measured by
+ * vil_linear_wgrad_tune or written by _set_plan; 0: the cost model's choice).  With _set_plan this lets a host keep the
+ * summation order of dW fixed across runs and equal across ranks (linear.export_plans / import_plans; under DDP rank 0's
+ * measured plans are broadcast). */
+int vil_linear_wgrad_get_plan(int64_t T, int CO, int CI, int* plan);
 
 /* ---- fused residual add + LayerNorm on the fp32 residual stream (block glue of msvit.py:313-316,336-340:
  * `x = x + drop_path(branch)` of one block fused with `norm(x)` of the next).  Contiguous (rows, C) tensors.

@@ -250,3 +250,55 @@ def test_mlp_autograd_nodes_match_plain_torch_on_cpu():
     # without the pre-computed activation the second node computes it itself: same result
     h2, _ = _LinearGeluOutFn.apply(x.detach(), w1.detach(), b1.detach())
     assert torch.equal(_GeluLinearFn.apply(h2, w2.detach(), b2.detach()), _GeluLinearFn.apply(h2, w2.detach(), b2.detach(), _))
+
+
+def test_wgrad_plan_export_import_and_deterministic_mode():
+    """The plan cache of the weight gradient through the C ABI (no GPU compute): get / set, export / import across a
+    'resume', and the switch that turns timing-based selection off (dW summation order must be reproducible)."""
+    from vision_longformer_amd import _lib, linear
+    L = _lib.lib()
+    T, co, ci = 25216, 1536, 384
+    _lib.check(L.vil_linear_wgrad_set_plan(T, co, ci, 0, 0, 0, 0))
+    default = linear._wg_get_plan(T, co, ci)
+    assert default[4] == 0 and default[0] in (1, 2)                       # the cost model's choice, not tuned
+    assert linear._wg_get_plan(T, co, ci) == default                      # ... and it is a pure function of the problem
+    linear.import_plans({(T, co, ci): (2, 6, 3, 1)}, device="cpu")
+    assert linear._wg_get_plan(T, co, ci) == (2, 6, 3, 1, 1)
+    assert linear.export_plans()[(T, co, ci)] == (2, 6, 3, 1)
+    assert (torch.device("cpu"), T, co, ci) in linear._WG_TUNED            # no timing run will replace it
+    _lib.check(L.vil_linear_wgrad_set_plan(T, co, ci, 0, 0, 0, 0))
+    assert (T, co, ci) not in linear.export_plans()
+    linear._WG_TUNED.discard((torch.device("cpu"), T, co, ci))
+    # a plan that does not divide the problem is refused, and the reader checks its arguments
+    assert L.vil_linear_wgrad_set_plan(T, 100, ci, 2, 3, 3, 1) != 0
+    import ctypes
+    assert L.vil_linear_wgrad_get_plan(T, co, ci, None) != 0
+    was = linear._DETERMINISTIC_PLANS
+    try:
+        linear.deterministic_plans(True)
+        assert linear._DETERMINISTIC_PLANS is True
+    finally:
+        linear.deterministic_plans(was)
+
+
+def _plan_share_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from vision_longformer_amd import _lib, linear
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, co, ci = 25216, 1536, 384
+    mine = (2, 6, 3, 1) if rank == 0 else (2, 3, 6, 2)                     # what each rank's own timing "selected"
+    _lib.check(_lib.lib().vil_linear_wgrad_set_plan(T, co, ci, *mine))
+    linear._share_rank0_plan(T, co, ci, torch.device("cpu"))
+    ret[rank] = linear._wg_get_plan(T, co, ci)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_weight_gradient_plan_of_rank0_is_shared_over_gloo():
+    """Two ranks whose timing picked different plans end up on rank 0's (same summation order of dW on every rank)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_plan_share_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0] == (2, 6, 3, 1, 1) and ret[1] == (2, 6, 3, 1, 1)

@@ -36,7 +36,7 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_glo_attn_fwd", "vil_glo_attn_bwd", "vil_attn_bwd_full",
            "vil_dense_attn_supported", "vil_dense_attn_workspace_bytes", "vil_dense_attn_fwd", "vil_dense_attn_bwd",
            "vil_colsum_workspace_bytes", "vil_colsum_bf16", "vil_colsum_f32",
-           "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad", "vil_linear_wgrad_tune", "vil_linear_wgrad_set_plan",
+           "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad", "vil_linear_wgrad_tune", "vil_linear_wgrad_set_plan", "vil_linear_wgrad_get_plan",
            "vil_resln_fwd", "vil_resln_bwd", "vil_gemm_workspace_bytes", "vil_gemm_bf16", "vil_gemm_tune", "vil_gemm_dgelu_bf16", "vil_gemm_gelu_bf16", "vil_gemm_skinny_bf16", "vil_gemm_skinny_gelu_bf16",
            "vil_sc2d_qk", "vil_sc2d_av", "vil_sc2d_agrad", "vil_sc2d_mask",
            "vil_optim_plan_bytes", "vil_optim_plan_build", "vil_optim_adamw_step", "vil_optim_qhm_step")
@@ -145,6 +145,9 @@ def lib():
         L.vil_linear_wgrad_tune.argtypes = L.vil_linear_wgrad.argtypes
         L.vil_linear_wgrad_set_plan.restype = ctypes.c_int
         L.vil_linear_wgrad_set_plan.argtypes = [ctypes.c_int64] + [ctypes.c_int] * 6
+        if hasattr(L, "vil_linear_wgrad_get_plan"):
+            L.vil_linear_wgrad_get_plan.restype = ctypes.c_int
+            L.vil_linear_wgrad_get_plan.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         L.vil_resln_fwd.restype = ctypes.c_int
         L.vil_resln_fwd.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int64, vp, vp, vp, vp, ctypes.c_int, vp, vp,
                                     ctypes.c_int64, ctypes.c_int, ctypes.c_float, vp]

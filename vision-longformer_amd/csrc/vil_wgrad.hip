@@ -579,6 +579,21 @@ extern "C" int vil_linear_wgrad_set_plan(int64_t T, int CO, int CI, int gen, int
   return 0;
 }
 
+// The plan vil_linear_wgrad would run for a problem with 8-element-aligned strides: the measured one when the problem
+// was tuned (plan[4] = 1), the cost model's otherwise (plan[4] = 0).  plan = {gen, mi, nj, m, tuned}.
+extern "C" int vil_linear_wgrad_get_plan(int64_t T, int CO, int CI, int* plan) {
+  if (!plan) return VIL_E_NULL;
+  if (T <= 0 || CO <= 0 || CI <= 0) return VIL_E_SHAPE;
+  bool tuned;
+  {
+    std::lock_guard<std::mutex> lk(g_wg_mu);
+    tuned = g_wg_plans.count(std::make_tuple(T, CO, CI)) != 0;
+  }
+  const WgPlan q = wgrad_choose(T, CO, CI, CO, CI);
+  plan[0] = q.gen; plan[1] = q.mi; plan[2] = q.nj; plan[3] = q.m; plan[4] = tuned ? 1 : 0;
+  return 0;
+}
+
 template <int MI, int NJ>
 static int wgrad2_launch(const WgradParams& p, int m, hipStream_t s) {
   const size_t lds = (size_t)3 * 32 * (32 * MI + 32 * NJ) * 2 + 1024;

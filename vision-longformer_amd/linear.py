@@ -11,6 +11,8 @@ On device tensors each of the three GEMMs of a projection goes through libvilatt
 No bias / cls-token gradient is left to PyTorch's multi-block reductions (they replay wrongly under hipGraph on this
 stack, see `_colsum`).  Operands that do not fit a kernel's contract (fp32, odd sizes, CPU) take the PyTorch path;
 the `torch.bmm` split-K fallback is what the fused kernel replaced (3-4x faster than the unsplit library call)."""
+import os
+
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -54,6 +56,59 @@ def _colsum(dy2):
 _WG_WS = {}
 _WG_TUNED = set()
 
+# Plan selection by measurement (the weight gradient's kernel / slice count, hipBLASLt's algorithm) makes the summation
+# order of dW depend on a one-off timing.  deterministic_plans(True) -- or VIL_DETERMINISTIC_PLANS=1 in the
+# environment -- switches the timing off: the library's cost model / hipBLASLt's first heuristic choice run, the same in
+# every run and on every rank.  With measurement left on, export_plans() / import_plans() carry the selection across a
+# resume (put the dict next to the checkpoint), and under torch.distributed with world size > 1 every rank takes rank 0's
+# measured weight-gradient plan (one small broadcast per problem, in the eager warm-up step that precedes capture).
+_DETERMINISTIC_PLANS = os.environ.get("VIL_DETERMINISTIC_PLANS", "0") not in ("", "0")
+
+
+def deterministic_plans(enable=True):
+    """No timing-based plan selection from here on (problems already tuned keep their plan; see import_plans)."""
+    global _DETERMINISTIC_PLANS
+    _DETERMINISTIC_PLANS = bool(enable)
+
+
+def _wg_get_plan(T, co, ci):
+    import ctypes
+    from . import _lib
+    buf = (ctypes.c_int * 5)()
+    _lib.check(_lib.lib().vil_linear_wgrad_get_plan(T, co, ci, buf))
+    return tuple(buf)
+
+
+def export_plans():
+    """{(T, C_out, C_in): (gen, mi, nj, m)} of every weight-gradient problem whose plan was measured or imported."""
+    out = {}
+    for (_, T, co, ci) in _WG_TUNED:
+        gen, mi, nj, m, tuned = _wg_get_plan(T, co, ci)
+        if tuned:
+            out[(T, co, ci)] = (gen, mi, nj, m)
+    return out
+
+
+def import_plans(plans, device=None):
+    """Restores export_plans(): the problems are marked as tuned, so no timing run replaces the imported plan."""
+    from . import _lib
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    for (T, co, ci), (gen, mi, nj, m) in plans.items():
+        _lib.check(_lib.lib().vil_linear_wgrad_set_plan(T, co, ci, gen, mi, nj, m))
+        _WG_TUNED.add((dev, T, co, ci))
+
+
+def _share_rank0_plan(T, co, ci, device):
+    """Under a process group of more than one rank: every rank runs rank 0's measured plan (same dW summation order)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    from . import _lib
+    t = torch.tensor(_wg_get_plan(T, co, ci)[:4], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=0)
+    gen, mi, nj, m = (int(v) for v in t.tolist())
+    _lib.check(_lib.lib().vil_linear_wgrad_set_plan(T, co, ci, gen, mi, nj, m))
+
 
 def _wgrad(dy2, x2, want_db):
     """(dW, db) of y = x W^T + b through libvilattn's fused MFMA weight/bias-gradient kernel, or None
@@ -78,10 +133,11 @@ def _wgrad(dy2, x2, want_db):
             vp(dw.data_ptr()), vp(db.data_ptr()) if want_db else None, 1, vp(ws.data_ptr()),
             vp(torch.cuda.current_stream(dy2.device).cuda_stream))
     key = (dy2.device, T, co, ci)
-    if key not in _WG_TUNED and not torch.cuda.is_current_stream_capturing():
+    if key not in _WG_TUNED and not _DETERMINISTIC_PLANS and not torch.cuda.is_current_stream_capturing():
         # one-off plan selection per problem by measurement (synchronises; never inside a captured region)
         _WG_TUNED.add(key)
         _lib.check(L.vil_linear_wgrad_tune(*args))
+        _share_rank0_plan(T, co, ci, dy2.device)
     _lib.check(L.vil_linear_wgrad(*args))
     return dw, db
 
@@ -195,7 +251,7 @@ def _gemm(op, inp2, w, bias):
             vp(out.data_ptr()), T, K, N, inp2.stride(0), N, vp(ws.data_ptr()), ws.numel(),
             vp(torch.cuda.current_stream(inp2.device).cuda_stream))
     key = (inp2.device, op, T, K, N, inp2.stride(0), bias is not None)
-    if key not in _GEMM_TUNED and not torch.cuda.is_current_stream_capturing():
+    if key not in _GEMM_TUNED and not _DETERMINISTIC_PLANS and not torch.cuda.is_current_stream_capturing():
         # explicit, one-off algorithm selection per problem (synchronises; never inside a captured region):
         # the launch call itself stays asynchronous
         _GEMM_TUNED.add(key)
