@@ -196,6 +196,11 @@ size_t vil_dense_attn_workspace_bytes(const VilAttnDesc* d, int pass);
 int vil_dense_attn_fwd(const VilAttnDesc* d, const void* q, const void* k, const void* v,
                        const float* bias_table, const float* g2l, const float* g2g,
                        void* out, float* lse, void* stream);
+/* Launch shape of vil_dense_attn_fwd: -1 (default) chooses per problem -- workgroups of up to 8 waves on a 64-row K/V ring,
+ * or of up to 4 waves on a 32-row ring where that needs fewer rounds of workgroups on the device (24 x 24 tokens at
+ * B H >= 171) --, 0 / 1 force the wide / narrow shape.  Results are bit-identical across shapes (a wave's unit and its
+ * 32-key steps do not change).  Process-global; for tests and measurements. */
+int vil_dense_attn_set_fwd_shape(int mode);
 int vil_dense_attn_bwd(const VilAttnDesc* d, const void* q, const void* k, const void* v,
                        const void* out, const void* dout, const float* lse,
                        const float* bias_table, const float* g2l, const float* g2g,

@@ -580,6 +580,28 @@ def test_dense_family_bias_gradients_bit_reproducible(dev):
         assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("nx,ny,G,H,B", [(24, 24, 1, 6, 2), (14, 14, 1, 6, 3), (21, 19, 2, 2, 1), (7, 7, 0, 12, 2), (32, 32, 1, 1, 1)])
+def test_dense_forward_launch_shapes_agree_bit_for_bit(dev, nx, ny, G, H, B):
+    """k_dense_fwd runs in two launch shapes (<= 8 waves per workgroup on a 64-row K/V ring; <= 4 waves on a 32-row ring,
+    taken by itself only where it saves a round of workgroups: 24 x 24 at B H >= 171).  A wave's unit and its 32-key steps
+    are the same in both, so outputs, lse and everything the backward derives from them must be identical bits -- and the
+    narrow shape is checked against the oracle like the wide one."""
+    from vision_longformer_amd import _lib
+    L = _lib.lib()
+    res = {}
+    try:
+        for mode in (0, 1):
+            _lib.check(L.vil_dense_attn_set_fwd_shape(mode))
+            res[mode] = _dense_family_case(dev, nx, ny, G, H, B, True, torch.bfloat16)
+    finally:
+        _lib.check(L.vil_dense_attn_set_fwd_shape(-1))
+    for k in res[0][0]:
+        assert torch.equal(res[0][0][k], res[1][0][k]), k
+    tol = {k: LOW_TOL[k] for k in ("out", "dqkv", "dtable", "dg2l", "dg2g")}
+    compare(f"dense family, narrow forward {nx}x{ny} G{G} H{H}", res[1][0], res[1][1], tol)
+    assert L.vil_dense_attn_set_fwd_shape(2) != 0
+
+
 @pytest.mark.parametrize("nx,W,M,H", [(16, 4, 32, 2), (20, 7, 64, 3), (21, 6, 32, 2)])
 def test_device_side_random_shift_mode(dev, nx, W, M, H):
     """VilAttnDesc.mode_dev: the neighbour read from a device word must give exactly the result of the same

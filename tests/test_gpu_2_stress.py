@@ -210,3 +210,11 @@ def test_soak_dense_attention_family(dev, nx, ny, G, H, B):
 
     nbad = _soak(dev, launch, lambda: res["o"], launches=LAUNCHES // 2, poke_every=20)
     assert nbad == 0, f"{nbad} of {LAUNCHES // 2} forward+backward passes differ"
+    # the forward's narrow launch shape (4-wave workgroups, 32-row ring blocks; round 4) under the same soak
+    L = _lib.lib()
+    try:
+        _lib.check(L.vil_dense_attn_set_fwd_shape(1))
+        nbad = _soak(dev, launch, lambda: res["o"], launches=LAUNCHES // 2, poke_every=20)
+    finally:
+        _lib.check(L.vil_dense_attn_set_fwd_shape(-1))
+    assert nbad == 0, f"narrow forward: {nbad} of {LAUNCHES // 2} forward+backward passes differ"

@@ -34,7 +34,7 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_layernorm_workspace_bytes", "vil_layernorm_fwd", "vil_layernorm_bwd",
            "vil_layernorm_fwd_tokens", "vil_layernorm_bwd_tokens", "vil_patchify_fwd", "vil_patchify_bwd",
            "vil_glo_attn_fwd", "vil_glo_attn_bwd", "vil_attn_bwd_full",
-           "vil_dense_attn_supported", "vil_dense_attn_workspace_bytes", "vil_dense_attn_fwd", "vil_dense_attn_bwd",
+           "vil_dense_attn_supported", "vil_dense_attn_workspace_bytes", "vil_dense_attn_fwd", "vil_dense_attn_bwd", "vil_dense_attn_set_fwd_shape",
            "vil_colsum_workspace_bytes", "vil_colsum_bf16", "vil_colsum_f32",
            "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad", "vil_linear_wgrad_tune", "vil_linear_wgrad_set_plan", "vil_linear_wgrad_get_plan",
            "vil_resln_fwd", "vil_resln_bwd", "vil_gemm_workspace_bytes", "vil_gemm_bf16", "vil_gemm_tune", "vil_gemm_dgelu_bf16", "vil_gemm_gelu_bf16", "vil_gemm_skinny_bf16", "vil_gemm_skinny_gelu_bf16",
@@ -128,6 +128,9 @@ def lib():
         L.vil_dense_attn_workspace_bytes.argtypes = [dp, ctypes.c_int]
         L.vil_dense_attn_fwd.restype = ctypes.c_int
         L.vil_dense_attn_fwd.argtypes = [dp] + [vp] * 9
+        if hasattr(L, "vil_dense_attn_set_fwd_shape"):
+            L.vil_dense_attn_set_fwd_shape.restype = ctypes.c_int
+            L.vil_dense_attn_set_fwd_shape.argtypes = [ctypes.c_int]
         L.vil_dense_attn_bwd.restype = ctypes.c_int
         L.vil_dense_attn_bwd.argtypes = [dp] + [vp] * 17
         L.vil_colsum_workspace_bytes.restype = ctypes.c_size_t

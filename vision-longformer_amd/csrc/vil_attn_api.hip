@@ -203,10 +203,9 @@ int vil_ensure_dyn_lds(const void* kernel, size_t bytes) {
   return 0;
 }
 
-int vil_persistent_grid(int waves_per_simd, int waves_per_wg, size_t lds, int H, int64_t units_total) {
-  // resident workgroups per CU from the kernel's own launch bounds (waves per SIMD the register allocation was held
-  // to: 4 SIMDs per CU) and its LDS footprint (160 KB per CU) -- deterministic, so that workspace layouts and the
-  // fixed-point scale of the dQ histogram do not depend on a driver query; the CU count is the device's
+// CU count of the current device, queried once per device (a device-attribute query is not a legal call while another
+// thread's stream capture is in global mode: grid sizes must not cost an API call per launch)
+int vil_cu_count() {
   static int cus_of[64] = {0};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -215,6 +214,14 @@ int vil_persistent_grid(int waves_per_simd, int waves_per_wg, size_t lds, int H,
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     if (dev >= 0 && dev < 64) cus_of[dev] = cus;
   }
+  return cus;
+}
+
+int vil_persistent_grid(int waves_per_simd, int waves_per_wg, size_t lds, int H, int64_t units_total) {
+  // resident workgroups per CU from the kernel's own launch bounds (waves per SIMD the register allocation was held
+  // to: 4 SIMDs per CU) and its LDS footprint (160 KB per CU) -- deterministic, so that workspace layouts and the
+  // fixed-point scale of the dQ histogram do not depend on a driver query; the CU count is the device's
+  const int cus = vil_cu_count();
   int per_cu = waves_per_simd * 4 / (waves_per_wg > 0 ? waves_per_wg : 1);
   const int by_lds = lds > 0 ? (int)((160 * 1024) / lds) : per_cu;
   if (per_cu > by_lds) per_cu = by_lds;

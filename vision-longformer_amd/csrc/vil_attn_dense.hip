@@ -121,11 +121,12 @@ struct DnDma {
     const int row = lane >> 3, chunk = (lane & 7) ^ (((row >> 1) & 3) << 1);     // LDS slot lane%8 of row lane/8 holds this chunk
     va0 = row * sa + chunk * 16; vb0 = row * sb + chunk * 16;
   }
-  __device__ __forceinline__ void issue(int blk, int slot) {
-    for (int pc = wave; pc < 16; pc += nwaves) {
-      const int m = pc >> 3, piece = pc & 7;
-      const int r0 = blk * DN_BLK + piece * 8;
-      char* dst = (m ? lb : la) + slot * (DN_BLK * 128) + piece * 1024;
+  template <int BLK = DN_BLK> __device__ __forceinline__ void issue(int blk, int slot) {
+    constexpr int PPM = BLK / 8;                        // pieces per matrix and block
+    for (int pc = wave; pc < 2 * PPM; pc += nwaves) {
+      const int m = pc / PPM, piece = pc % PPM;
+      const int r0 = blk * BLK + piece * 8;
+      char* dst = (m ? lb : la) + slot * (BLK * 128) + piece * 1024;
       if (m) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)dst, 16, vb0 + r0 * sb_b, 0, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, va0 + r0 * sa_b, 0, 0, 0);
     }
@@ -168,8 +169,12 @@ struct DnDma {
 
 // ===================================================================== forward
 // lse: (B*H, N + 1) floats -- [N] = max_k |v_k|^2 of the (image, head), which the backward's histogram scale needs
-template <typename T, int QT>
+// BLK: rows of a ring block.  64 everywhere but where the 32 KB ring keeps a launch from fitting the chip in one round of
+// workgroups (round 4: at 24 x 24 the 576 seven-wave workgroups need 52.7 KB each -- two per CU, 512 slots, a second
+// round of 64 workgroups that costs 0.64 of the first; with 32-row blocks they need 36.7 KB, four per CU, one round).
+template <typename T, int QT, int BLK>
 __global__ __launch_bounds__(64 * DN_MAXW_F, DN_OCC_F) void k_dense_fwd(VilParams p, DenseCfg c) {
+  constexpr int RING = 2 * BLK * 128, SPB = BLK / 32;  // bytes of one matrix's ring; 32-key steps per block
   typedef typename V16<T>::x8 X8;
   typedef typename V16<T>::x4 X4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(64 * DN_MAXW_F, DN_OCC_F) void k_dense_fwd(VilParam
   float* ggl = (float*)(akey + c.NSP);
   unsigned* misc = (unsigned*)(ggl + DN_GGL);
   char* Kl = (char*)(misc + 16);
-  char* Vl = Kl + DN_RING;
+  char* Vl = Kl + RING;
   const unsigned tab_lds = lds_addr(smem);
 
   const int N = c.N, G = c.G;
@@ -210,8 +215,8 @@ __global__ __launch_bounds__(64 * DN_MAXW_F, DN_OCC_F) void k_dense_fwd(VilParam
     dma.init(make_rsrc_n((const T*)p.k + b * p.k_sb + h * p.k_sh, kbytes), (int)p.k_st * 2, Kl,
              make_rsrc_n((const T*)p.v + b * p.v_sb + h * p.v_sh, vbytes), (int)p.v_st * 2, Vl, lane, wave, nthr >> 6);
   }
-  const int nsteps = c.NSP >> 5, nblk = (nsteps + 1) >> 1;
-  dma.issue(0, 0);
+  const int nsteps = c.NSP >> 5, nblk = (nsteps + SPB - 1) / SPB;
+  dma.template issue<BLK>(0, 0);
   int qtok[QT];
   X8 qf[2][QT];
 #pragma unroll
@@ -257,8 +262,8 @@ __global__ __launch_bounds__(64 * DN_MAXW_F, DN_OCC_F) void k_dense_fwd(VilParam
   auto step = [&](auto glo_, int st, int slot) {
     constexpr bool GLO = decltype(glo_)::value;
     constexpr int NQ = (GLO && QT > 1) ? 1 : QT;          // the global-token wave's unit is one tile
-    const char* kp = Kl + slot * (DN_BLK * 128) + (st & 1) * (32 * 128);
-    const char* vp = Vl + slot * (DN_BLK * 128) + (st & 1) * (32 * 128);
+    const char* kp = Kl + slot * (BLK * 128) + (st & (SPB - 1)) * (32 * 128);
+    const char* vp = Vl + slot * (BLK * 128) + (st & (SPB - 1)) * (32 * 128);
     // ---- S^T = K Q^T + bias: the accumulator starts as the gathered bias
     i32x4 ak[2];
 #pragma unroll
@@ -350,11 +355,11 @@ __global__ __launch_bounds__(64 * DN_MAXW_F, DN_OCC_F) void k_dense_fwd(VilParam
 
   auto run = [&](auto glo_) {
     for (int j = 0; j < nblk; ++j) {
-      if (j + 1 < nblk) dma.issue(j + 1, (j + 1) & 1);      // its slot was released by the barrier that ended block j-1
+      if (j + 1 < nblk) dma.template issue<BLK>(j + 1, (j + 1) & 1);      // its slot was released by the barrier that ended block j-1
       {
         // squared row norms of this V block (for the backward's histogram scale): one 16-byte chunk per thread
-        const char* vb_ = Vl + (j & 1) * (DN_BLK * 128);
-        for (int i = tid; i < DN_BLK * 8; i += nthr) {
+        const char* vb_ = Vl + (j & 1) * (BLK * 128);
+        for (int i = tid; i < BLK * 8; i += nthr) {
           const X8 e = *(const X8*)(vb_ + i * 16);
           float s2 = 0.f;
 #pragma unroll
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(64 * DN_MAXW_F, DN_OCC_F) void k_dense_fwd(VilParam
       }
       if (active) {
 #pragma unroll 1
-        for (int st = 2 * j; st < min(2 * j + 2, nsteps); ++st) step(glo_, st, j & 1);
+        for (int st = SPB * j; st < min(SPB * j + SPB, nsteps); ++st) step(glo_, st, j & 1);
       }
       lds_dma_wait();                                      // this wave's LDS-DMA requests (vil_mfma_common.h)
       __syncthreads();
@@ -949,8 +954,8 @@ static bool dense_cfg(const VilAttnDesc* d, int rows_per_wave, int maxw, DenseCf
   c.m_nwg = vil_magic((unsigned)c.nwg_bh);
   return true;
 }
-static size_t dense_lds(const DenseCfg& c, int pass) {   // 0 forward, 1 dQ, 2 dK/dV: see the kernels' LDS maps
-  if (pass == 0) return (size_t)c.tabsize * 4 + (size_t)c.NSP * 4 + DN_GGL * 4 + 64 + 2 * DN_RING;
+static size_t dense_lds(const DenseCfg& c, int pass, int blk = DN_BLK) {   // 0 forward, 1 dQ, 2 dK/dV: see the kernels' LDS maps
+  if (pass == 0) return (size_t)c.tabsize * 4 + (size_t)c.NSP * 4 + DN_GGL * 4 + 64 + 2 * (size_t)(2 * blk * 128);
   if (pass == 1) return (size_t)c.tabsize * 8 + (size_t)c.NSP * 4 + DN_GGL * 4 + 64 + 2 * DN_RING;
   return (size_t)c.tabsize * 4 + DN_GGL * 4 + 3 * (size_t)c.NSP * 4 + 2 * DN_RING;
 }
@@ -1010,12 +1015,21 @@ static void dense_params(VilParams& p, const VilAttnDesc* d, const float* table,
     if (d->dtype == VIL_DTYPE_F16) DN_LAUNCH_T(KERNEL, _Float16, grid, wpw_, lds, s, __VA_ARGS__)         \
     else DN_LAUNCH_T(KERNEL, __bf16, grid, wpw_, lds, s, __VA_ARGS__)                                     \
   }
-#define DN_K_FWD(T) k_dense_fwd<T, VIL_DENSE_QT>
+#define DN_K_FWD(T) k_dense_fwd<T, VIL_DENSE_QT, 64>
+#define DN_K_FWD32(T) k_dense_fwd<T, VIL_DENSE_QT, 32>
 #define DN_K_DQ1_H(T) k_dense_bwd_dq<T, 1, true>
 #define DN_K_DQ1_N(T) k_dense_bwd_dq<T, 1, false>
 #define DN_K_DQ2_H(T) k_dense_bwd_dq<T, 2, true>
 #define DN_K_DQ2_N(T) k_dense_bwd_dq<T, 2, false>
 #define DN_K_DKDV(T) k_dense_bwd_dkdv<T, VIL_DENSE_KT>
+
+// launch shape of the forward: -1 the rule below, 0 always the wide shape, 1 always the narrow one (tests, measurements)
+static int g_dense_fwd_shape = -1;
+extern "C" int vil_dense_attn_set_fwd_shape(int mode) {
+  if (mode < -1 || mode > 1) return VIL_E_SHAPE;
+  g_dense_fwd_shape = mode;
+  return VIL_OK;
+}
 
 extern "C" int vil_dense_attn_fwd(const VilAttnDesc* d, const void* q, const void* k, const void* v,
                                   const float* bias_table, const float* g2l, const float* g2g,
@@ -1034,8 +1048,27 @@ extern "C" int vil_dense_attn_fwd(const VilAttnDesc* d, const void* q, const voi
   vil_prof_tag(d->B, d->H, d->M, d->nx, d->ny, d->nx > d->ny ? d->nx : d->ny, d->G, -1);
   const double n = c.N, ce = (double)d->H * d->M * 2;
   vil_prof_begin(VIL_K_DENSE_FWD, s, d->B * (4 * n * ce + 4.0 * d->H * n), d->B * 4.0 * n * n * d->H * d->M);
-  const size_t lds = dense_lds(c, 0);
-  DN_LAUNCH(DN_K_FWD, (unsigned)(d->B * d->H * c.nwg_bh), c.wpw, lds, s, p, c);
+  // Two launch shapes: workgroups of up to DN_MAXW_F waves on the 64-row ring, or of up to 4 waves on a 32-row ring.  The
+  // kernel runs at 120 registers = 16 waves per CU: two 7-wave workgroups, or four 4-wave ones when their LDS allows
+  // (36.7 instead of 52.7 KB at 24 x 24).  Every workgroup streams all of K / V, so the narrow shape (more workgroups per
+  // (image, head)) is taken only where it needs fewer ROUNDS of workgroups: 24 x 24, B H = 192: 960 workgroups on 1024
+  // slots instead of 576 on 512 -- the second round of 64 cost 0.64 of the first.
+  DenseCfg cn;
+  dense_cfg(d, 16 * VIL_DENSE_QT, 4, cn, true);
+  auto rounds = [&](const DenseCfg& cc, size_t lds_) {
+    int per_cu = (int)((155 * 1024) / lds_);
+    if (per_cu > 16 / cc.wpw) per_cu = 16 / cc.wpw;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t slots = (int64_t)per_cu * vil_cu_count(), wgs = (int64_t)d->B * d->H * cc.nwg_bh;
+    return (wgs + slots - 1) / slots;
+  };
+  const size_t lds64 = dense_lds(c, 0, 64), lds32 = dense_lds(cn, 0, 32);
+  const bool narrow = g_dense_fwd_shape < 0 ? rounds(cn, lds32) < rounds(c, lds64) : g_dense_fwd_shape == 1;
+  if (narrow) {
+    DN_LAUNCH(DN_K_FWD32, (unsigned)(d->B * d->H * cn.nwg_bh), cn.wpw, lds32, s, p, cn);
+  } else {
+    DN_LAUNCH(DN_K_FWD, (unsigned)(d->B * d->H * c.nwg_bh), c.wpw, lds64, s, p, c);
+  }
   vil_prof_end(s);
   return (int)hipGetLastError();
 }

@@ -81,6 +81,7 @@ static inline void vil_prof_tag_desc(const VilAttnDesc* d) {
 // Raises a kernel's dynamic-LDS limit above 64 KB once per (device, kernel, size) instead of on every launch
 // (hipFuncSetAttribute is a driver call; the remembered maxima are an idempotent process-global cache).
 int vil_ensure_dyn_lds(const void* kernel, size_t bytes);
+int vil_cu_count();                                  // CUs of the current device (cached per device)
 
 // algorithmic (minimum) HBM bytes / flops of one launch over the whole batch; SURVEY.md 8(d)
 struct VilWork {
