@@ -158,6 +158,13 @@ int vil_attn_bwd_full(const VilAttnDesc* d, const void* q_all, const void* k, co
  * N % 128 == 0; VIL_E_BACKEND outside that contract. */
 int vil_gemm_dgelu_bf16(const void* dy, const void* w, const void* h, void* dh, int64_t T, int K, int N,
                         int64_t dy_row_stride, int64_t h_row_stride, int64_t dh_row_stride, void* stream);
+/* The two tile kernels above without their activation epilogues -- op 0: out[T][N] = in[T][K] * w[N][K]^T (+ bias[N]) (the
+ * forward of nn.Linear), op 1: out[T][N] = in[T][K] * w[K][N] (its input gradient) -- for the projections of the dense
+ * stages (reference msvit.py:91-120 qkv / proj, :17-34 fc2; T = 6 k ... 25 k tokens), where the tuned library GEMM runs
+ * at 13-31 % of the matrix peak.  bf16, fp32 accumulate, row strides in elements; K % 32 == 0, N % 128 == 0, 16-byte
+ * aligned; VIL_E_BACKEND outside that contract (the caller then uses vil_gemm_bf16). */
+int vil_gemm_tile_bf16(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
+                       int64_t in_row_stride, int64_t out_row_stride, void* stream);
 /* The forward counterpart: fc1 with nn.GELU() in its epilogue (reference msvit.py:29-31),
  *   h[t][n] = sum_k x[t][k] * w[n][k] + bias[n],   a[t][n] = gelu(h[t][n])  (exact erf form, of the rounded bf16 h)
  * one launch that writes both (the unfused pair writes h, reads it again and writes a).  w = fc1.weight (N rows of K),

@@ -428,6 +428,46 @@ def test_tile_gemm_gelu_epilogue_vs_fp64(dev, T, K, N):
         linear._GELU_TILE_MIN_K = old
 
 
+@pytest.mark.parametrize("T,K,N", [(25216, 384, 1152), (25216, 384, 384), (6400, 768, 768), (18464, 384, 384), (1031, 160, 128),
+                                   (4099, 1536, 384), (2048, 96, 256)])
+def test_plain_tile_gemm_vs_fp64(dev, T, K, N):
+    """vil_gemm_tile_bf16 (the loader-wave tile kernels without their activation epilogues): forward with / without bias
+    and the input gradient against fp64 on sampled rows; ragged last tile, K not a multiple of the 64-deep ring block,
+    strided input, and the routing rule of linear._gemm_tile"""
+    import ctypes
+    from vision_longformer_amd import _lib, linear
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(47)
+    wide = torch.randn(T, K + 24, generator=g).bfloat16().to(dev)
+    x = wide[:, 24:]
+    w = (torch.randn(N, K, generator=g) * 0.1).bfloat16().to(dev)
+    b = torch.randn(N, generator=g).bfloat16().to(dev)
+    dy = torch.randn(T, N, generator=g).bfloat16().to(dev)
+    rows = torch.cat([torch.arange(0, 200), torch.arange(T - 200, T), torch.randint(0, T, (200,), generator=g)]).unique()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for bias in (b, None):
+        out = torch.full((T, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        _lib.check(L.vil_gemm_tile_bf16(0, vp(x), vp(w), vp(bias), vp(out), T, K, N, x.stride(0), N, st))
+        want = x[rows].double() @ w.double().t() + (bias.double() if bias is not None else 0)
+        assert (out[rows].double() - want).abs().max().item() <= 1.2e-2 * max(1.0, want.abs().max().item())
+        assert bool(torch.isfinite(out.float()).all())
+    dx = torch.full((T, K), float("nan"), dtype=torch.bfloat16, device=dev)
+    if K % 128 == 0:
+        _lib.check(L.vil_gemm_tile_bf16(1, vp(dy), vp(w), None, vp(dx), T, N, K, N, K, st))
+        want = dy[rows].double() @ w.double()
+        assert (dx[rows].double() - want).abs().max().item() <= 1.2e-2 * max(1.0, want.abs().max().item())
+        assert bool(torch.isfinite(dx.float()).all())
+    else:
+        assert L.vil_gemm_tile_bf16(1, vp(dy), vp(w), None, vp(dx), T, N, K, N, K, st) == _lib.VIL_E_BACKEND
+    # contract violations
+    assert L.vil_gemm_tile_bf16(1, vp(dy), vp(w), vp(b), vp(dx), T, N, K, N, K, st) != 0           # a bias with the input gradient
+    assert L.vil_gemm_tile_bf16(2, vp(x), vp(w), None, vp(dx), T, K, N, x.stride(0), N, st) != 0
+    # the host routes exactly the shapes of its rule here
+    got = linear._gemm_tile(0, x, w, b)
+    assert (got is not None) == (linear._tile_gemm_takes(0, K, N) and K % 32 == 0 and N % 128 == 0 and T >= 1024)
+
+
 @pytest.mark.parametrize("B,N,C", [(3, 3137, 96), (2, 785, 192)])
 def test_mlp_block_with_gelu_epilogue_matches_unfused(dev, B, N, C):
     """msvit.Mlp with fc1 + GELU as ONE launch (vil_linear_gelu -> vil_gemm_skinny_gelu_bf16) against the same module

@@ -136,6 +136,28 @@ def test_soak_tile_gemm_gelu(dev, T, K, N):
     assert nbad == 0, f"{nbad} of {LAUNCHES} launches differ"
 
 
+@pytest.mark.parametrize("op,T,K,N", [(0, 6400, 384, 1152), (0, 9001, 384, 384), (0, 3200, 768, 768), (1, 6400, 384, 384), (1, 3200, 768, 768),
+                                      (1, 9001, 1152, 384)])
+def test_soak_plain_tile_gemm(dev, op, T, K, N):
+    """vil_gemm_tile_bf16 (k_fwd_gelu<false> / k_dgrad_dgelu<false>): the persistent loader-wave tile kernels as plain GEMMs"""
+    from vision_longformer_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(T, K, generator=g).bfloat16().to(dev)
+    w = (torch.randn(*((N, K) if op == 0 else (K, N)), generator=g) * 0.1).bfloat16().to(dev)
+    b = torch.randn(N, generator=g).bfloat16().to(dev) if op == 0 else None
+    out = torch.empty(T, N, dtype=torch.bfloat16, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def launch():
+        _lib.check(L.vil_gemm_tile_bf16(op, _vp(x), _vp(w), _vp(b), _vp(out), T, K, N, K, N, st))
+
+    nbad = _soak(dev, launch, lambda: [out])
+    assert nbad == 0, f"{nbad} of {LAUNCHES} launches differ"
+    want = x.double() @ (w.double().t() if op == 0 else w.double()) + (b.double() if b is not None else 0)
+    assert (out.double() - want).abs().max().item() <= 1.2e-2 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("T,K,N", [(6400, 384, 1536), (3200, 768, 3072), (12007, 96, 384), (9001, 192, 768)])
 def test_soak_dgrad_dgelu(dev, T, K, N):
     """k_dgrad_dgelu (vil_gemm_dgelu_bf16): fc2's input gradient with the GELU backward in its epilogue"""

@@ -37,7 +37,7 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_dense_attn_supported", "vil_dense_attn_workspace_bytes", "vil_dense_attn_fwd", "vil_dense_attn_bwd", "vil_dense_attn_set_fwd_shape",
            "vil_colsum_workspace_bytes", "vil_colsum_bf16", "vil_colsum_f32",
            "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad", "vil_linear_wgrad_tune", "vil_linear_wgrad_set_plan", "vil_linear_wgrad_get_plan",
-           "vil_resln_fwd", "vil_resln_bwd", "vil_gemm_workspace_bytes", "vil_gemm_bf16", "vil_gemm_tune", "vil_gemm_dgelu_bf16", "vil_gemm_gelu_bf16", "vil_gemm_skinny_bf16", "vil_gemm_skinny_gelu_bf16",
+           "vil_resln_fwd", "vil_resln_bwd", "vil_gemm_workspace_bytes", "vil_gemm_bf16", "vil_gemm_tune", "vil_gemm_dgelu_bf16", "vil_gemm_gelu_bf16", "vil_gemm_tile_bf16", "vil_gemm_skinny_bf16", "vil_gemm_skinny_gelu_bf16",
            "vil_sc2d_qk", "vil_sc2d_av", "vil_sc2d_agrad", "vil_sc2d_mask",
            "vil_optim_plan_bytes", "vil_optim_plan_build", "vil_optim_adamw_step", "vil_optim_qhm_step")
 
@@ -119,6 +119,10 @@ def lib():
         L.vil_gemm_gelu_bf16.restype = ctypes.c_int
         L.vil_gemm_gelu_bf16.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                          ctypes.c_int64, vp]
+        if hasattr(L, "vil_gemm_tile_bf16"):
+            L.vil_gemm_tile_bf16.restype = ctypes.c_int
+            L.vil_gemm_tile_bf16.argtypes = [ctypes.c_int, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int64, ctypes.c_int64, vp]
         L.vil_gemm_skinny_gelu_bf16.restype = ctypes.c_int
         L.vil_gemm_skinny_gelu_bf16.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                                 ctypes.c_int64, vp]

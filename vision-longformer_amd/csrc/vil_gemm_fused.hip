@@ -81,6 +81,8 @@ __device__ __forceinline__ void gf_tiles(int ntiles, int& first, int& end, int& 
   first = lo + (int)(blockIdx.x >> 3);
 }
 
+// DGELU = false: the plain input gradient dx = dy . w (vil_gemm_tile_bf16 op 1): no h loads, no derivative.
+template <bool DGELU>
 __global__ __launch_bounds__(GF_THREADS, 4) void k_dgrad_dgelu(DgParams p) {
   typedef __bf16 T_;
   typedef typename V16<T_>::x8 X8;
@@ -152,10 +154,12 @@ __global__ __launch_bounds__(GF_THREADS, 4) void k_dgrad_dgelu(DgParams p) {
       return *(const X8*)((const char*)hb + (unsigned)(t * p.h_rs + n0 + wn * 64 + pr * 32 + lg * 8) * 2u);
     };
     X8 ha[2][2];
+    if (DGELU) {
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) ha[tt][pr] = load_h(tt, pr);
+        for (int pr = 0; pr < 2; ++pr) ha[tt][pr] = load_h(tt, pr);
+    }
     f32x4 acc[4][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -208,16 +212,18 @@ __global__ __launch_bounds__(GF_THREADS, 4) void k_dgrad_dgelu(DgParams p) {
     // of tiles 0, 1 -> tiles 2, 3.  No wait hipcc places for a load may follow a store of this tile: its counted
     // waits count the untracked stores too and would drain them.
     X8 hl[2][2];
+    if (DGELU) {
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) hl[tt][pr] = load_h(2 + tt, pr);
+        for (int pr = 0; pr < 2; ++pr) hl[tt][pr] = load_h(2 + tt, pr);
+    }
     auto result = [&](int tt, int pr, const X8& h) {
       X8 o8;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        o8[r] = (T_)(acc[2 * pr][tt][r] * gelu_grad((float)h[r]));
-        o8[4 + r] = (T_)(acc[2 * pr + 1][tt][r] * gelu_grad((float)h[4 + r]));
+        o8[r] = (T_)(DGELU ? acc[2 * pr][tt][r] * gelu_grad((float)h[r]) : acc[2 * pr][tt][r]);
+        o8[4 + r] = (T_)(DGELU ? acc[2 * pr + 1][tt][r] * gelu_grad((float)h[4 + r]) : acc[2 * pr + 1][tt][r]);
       }
       return o8;
     };
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(GF_THREADS, 4) void k_dgrad_dgelu(DgParams p) {
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) oe[tt][pr] = result(tt, pr, ha[tt][pr]);
-    {   // (the held results are operands too: otherwise the claim -- and its s_waitcnt vmcnt(0) -- is scheduled above them)
+    if (DGELU) {   // (the held results are operands too: otherwise the claim -- and its s_waitcnt vmcnt(0) -- is scheduled above them)
       gf_u32x4 q[4], r[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { q[i] = __builtin_bit_cast(gf_u32x4, hl[i >> 1][i & 1]); r[i] = __builtin_bit_cast(gf_u32x4, oe[i >> 1][i & 1]); }
@@ -273,6 +279,8 @@ __device__ __forceinline__ float gelu_fwd(float x) {
   return x * (x < 0.f ? hc : 1.0f - hc);
 }
 
+// GELU = false: the plain forward h = x W^T + b (vil_gemm_tile_bf16 op 0): one output.
+template <bool GELU>
 __global__ __launch_bounds__(GF_THREADS, 3) void k_fwd_gelu(FgParams p) {
   typedef __bf16 T_;
   typedef typename V16<T_>::x8 X8;
@@ -378,12 +386,14 @@ __global__ __launch_bounds__(GF_THREADS, 3) void k_fwd_gelu(FgParams p) {
           o8[r] = (T_)(acc[2 * pr][tt][r] + (float)bias8[pr][r]);
           o8[4 + r] = (T_)(acc[2 * pr + 1][tt][r] + (float)bias8[pr][4 + r]);
         }
+        if (GELU) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a8[r] = (T_)gelu_fwd((float)o8[r]);         // GELU of the rounded pre-activation
+          for (int r = 0; r < 8; ++r) a8[r] = (T_)gelu_fwd((float)o8[r]);       // GELU of the rounded pre-activation
+        }
         const unsigned o = (unsigned)(t * p.o_rs + n0 + wn * 64 + pr * 32 + lg * 8) * 2u;
         if (t < p.T) {
           gf_store16(hb, o, o8);
-          gf_store16(ab, o, a8);
+          if (GELU) gf_store16(ab, o, a8);
         }
       }
     }
@@ -410,8 +420,8 @@ extern "C" int vil_gemm_gelu_bf16(const void* x, const void* w, const void* bias
   p.ntiles = (int)(((T + 127) / 128) * p.nn_tiles);
   const size_t lds = 2 * GF_SLOT;
   const unsigned grid = (unsigned)vil_persistent_grid(3, GF_THREADS / 64, lds, 1, (int64_t)p.ntiles * (GF_THREADS / 64));
-  if (int he = vil_ensure_dyn_lds((const void*)k_fwd_gelu, lds)) return he;
-  k_fwd_gelu<<<dim3(grid), dim3(GF_THREADS), lds, (hipStream_t)stream>>>(p);
+  if (int he = vil_ensure_dyn_lds((const void*)k_fwd_gelu<true>, lds)) return he;
+  k_fwd_gelu<true><<<dim3(grid), dim3(GF_THREADS), lds, (hipStream_t)stream>>>(p);
   return (int)hipGetLastError();
 }
 
@@ -437,7 +447,45 @@ extern "C" int vil_gemm_dgelu_bf16(const void* dy, const void* w, const void* h,
   p.ntiles = (int)(((T + 127) / 128) * p.nn_tiles);
   const size_t lds = 2 * GF_SLOT;
   const unsigned grid = (unsigned)vil_persistent_grid(3, GF_THREADS / 64, lds, 1, (int64_t)p.ntiles * (GF_THREADS / 64));
-  if (int he = vil_ensure_dyn_lds((const void*)k_dgrad_dgelu, lds)) return he;
-  k_dgrad_dgelu<<<dim3(grid), dim3(GF_THREADS), lds, (hipStream_t)stream>>>(p);
+  if (int he = vil_ensure_dyn_lds((const void*)k_dgrad_dgelu<true>, lds)) return he;
+  k_dgrad_dgelu<true><<<dim3(grid), dim3(GF_THREADS), lds, (hipStream_t)stream>>>(p);
+  return (int)hipGetLastError();
+}
+
+// The same two kernels without their activation epilogues: op 0: out[T][N] = in[T][K] . w[N][K]^T (+ bias[N]); op 1:
+// out[T][N] = in[T][K] . w[K][N] (the input gradient; w = the weight as stored).  bf16, fp32 accumulate, row strides in
+// elements.  K % 32 == 0, N % 128 == 0; VIL_E_BACKEND outside that contract (the caller then uses the library GEMM).
+// For the projections of the dense stages (T = 6 k ... 25 k, K, N = 384 ... 3072), where the tuned hipBLASLt kernels run at
+// 13 - 31 % of the matrix peak.
+extern "C" int vil_gemm_tile_bf16(int op, const void* in, const void* w, const void* bias, void* out, int64_t T, int K, int N,
+                                  int64_t in_row_stride, int64_t out_row_stride, void* stream) {
+  if (!in || !w || !out) return VIL_E_NULL;
+  if (T <= 0 || K <= 0 || N <= 0 || op < 0 || op > 1 || (op == 1 && bias)) return VIL_E_SHAPE;
+  if ((K & 31) || (N & 127)) return VIL_E_BACKEND;
+  if ((in_row_stride & 7) || (out_row_stride & 7) || (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out) & 15) ||
+      (bias && ((uintptr_t)bias & 15))) return VIL_E_ALIGN;
+  if (in_row_stride < K || out_row_stride < N) return VIL_E_SHAPE;
+  if ((T + 128) * in_row_stride * 2 >= (1ll << 31) || (int64_t)K * N * 2 >= (1ll << 31) || T * (N / 128) >= (1ll << 30)) return VIL_E_BACKEND;
+  if ((T + 128) * out_row_stride * 2 >= (1ll << 32)) return VIL_E_BACKEND;
+  const size_t lds = 2 * GF_SLOT;
+  const int nn_tiles = N / 128, ntiles = (int)(((T + 127) / 128) * nn_tiles);
+  const unsigned grid = (unsigned)vil_persistent_grid(3, GF_THREADS / 64, lds, 1, (int64_t)ntiles * (GF_THREADS / 64));
+  if (op == 0) {
+    FgParams p;
+    p.x = in; p.w = w; p.bias = bias; p.h = out; p.a = nullptr;
+    p.T = (int)T; p.K = K; p.N = N;
+    p.x_rs = (int)in_row_stride; p.o_rs = (int)out_row_stride;
+    p.nn_tiles = nn_tiles; p.ntiles = ntiles;
+    if (int he = vil_ensure_dyn_lds((const void*)k_fwd_gelu<false>, lds)) return he;
+    k_fwd_gelu<false><<<dim3(grid), dim3(GF_THREADS), lds, (hipStream_t)stream>>>(p);
+  } else {
+    DgParams p;
+    p.dy = in; p.w = w; p.h = nullptr; p.dh = out;
+    p.T = (int)T; p.K = K; p.N = N;
+    p.dy_rs = (int)in_row_stride; p.h_rs = (int)out_row_stride; p.dh_rs = (int)out_row_stride;
+    p.nn_tiles = nn_tiles; p.ntiles = ntiles;
+    if (int he = vil_ensure_dyn_lds((const void*)k_dgrad_dgelu<false>, lds)) return he;
+    k_dgrad_dgelu<false><<<dim3(grid), dim3(GF_THREADS), lds, (hipStream_t)stream>>>(p);
+  }
   return (int)hipGetLastError();
 }

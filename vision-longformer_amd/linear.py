@@ -265,16 +265,58 @@ def _gemm(op, inp2, w, bias):
     return out
 
 
+_TILE_GEMM = True             # plain projections of the dense stages through vil_gemm_tile_bf16 where it beats the tuned library GEMM
+                              # (tools/tile_gemm_probe.py, profiles/r04_tile_gemm_probe.txt; in-step A/B: tools/ab_bench.py)
+
+
+def _tile_gemm_takes(op, K, N):
+    """op 0: K = in_features, N = out_features; op 1: K = out_features (the contraction), N = in_features.  The shapes the
+    persistent tile kernel wins at the dense stages' token counts: forward with a contraction <= 384 (qkv, proj of stage 3)
+    or <= 768 into <= 768 features (proj of stage 4); input gradient of the square projections (<= 768 x 768).  The long
+    contractions (fc2 forward, qkv / fc1 input gradients) stay with hipBLASLt: 34-37 us against 45-56 here."""
+    if op == 0:
+        return K <= 384 or (K <= 768 and N <= 768)
+    return K <= 768 and N <= 768
+
+
+def _gemm_tile(op, inp2, w, bias):
+    """vil_gemm_tile_bf16 (csrc/vil_gemm_fused.hip: the loader-wave tile kernels without their activation epilogues), or
+    None outside its contract / the shapes it is taken for."""
+    T, K = inp2.shape
+    N = w.shape[0] if op == 0 else w.shape[1]
+    if not (_TILE_GEMM and _tile_gemm_takes(op, K, N) and K % 32 == 0 and N % 128 == 0 and T >= 1024
+            and inp2.is_cuda and inp2.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.is_contiguous()
+            and (w.shape[1] if op == 0 else w.shape[0]) == K and inp2.stride(1) == 1 and inp2.stride(0) % 8 == 0
+            and inp2.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and (bias is None or (op == 0 and bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.data_ptr() % 16 == 0))):
+        return None
+    import ctypes
+    from . import _lib
+    out = torch.empty(T, N, dtype=torch.bfloat16, device=inp2.device)
+    vp = ctypes.c_void_p
+    rc = _lib.lib().vil_gemm_tile_bf16(op, vp(inp2.data_ptr()), vp(w.data_ptr()), vp(bias.data_ptr()) if bias is not None else None,
+                                       vp(out.data_ptr()), T, K, N, inp2.stride(0), N,
+                                       vp(torch.cuda.current_stream(inp2.device).cuda_stream))
+    if rc == _lib.VIL_E_BACKEND:
+        return None
+    _lib.check(rc)
+    return out
+
+
 def _fwd_gemm(x2, weight, bias):
     """x2 @ weight.T (+ bias): the weights-in-registers kernel for the short-K / huge-T projections of stages 1-2
     (csrc/vil_gemm_skinny.hip), the tuned library GEMM otherwise; None when neither takes the operands."""
     y = _gemm_skinny(0, x2, weight, bias)
+    if y is None:
+        y = _gemm_tile(0, x2, weight, bias)
     return y if y is not None else _gemm(0, x2, weight, bias)
 
 
 def _bwd_gemm(dy2, weight):
     """dy2 @ weight (the input gradient): the weights-in-registers kernel where it applies, else the library GEMM"""
     dx = _gemm_skinny(1, dy2, weight, None)
+    if dx is None:
+        dx = _gemm_tile(1, dy2, weight, None)
     return dx if dx is not None else _gemm(1, dy2, weight, None)
 
 
