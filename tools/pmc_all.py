@@ -1,7 +1,7 @@
 """One process that launches every hand-written hot kernel at its bench shapes, for `rocprofv3 --pmc` passes
 (tools/pmc_all.sh): the sliding-chunk attention family at 56x56 (M 32) and 28x28 / 48x48 (M 64), the dense family at 14x14
 and 24x24, the weights-in-registers GEMM (forward, input gradient), the weight gradient, fc2's input gradient with the GELU
-backward, fc1 with the GELU epilogue.  Between two cases a marker kernel (a torch.sign whose grid size grows with the case
+backward, fc1 with the GELU epilogue, the same tile kernels as plain GEMMs.  Between two cases a marker kernel (a torch.sign whose grid size grows with the case
 index) is launched, so that tools/pmc_all_summary.py can cut the dispatch stream into cases without any other side channel.
 
     python tools/pmc_all.py [--reps 2] [--only case,case]      (prints the case list as JSON on the last line)
@@ -36,6 +36,8 @@ GEMM = {  # kind, T, K, N
     "fwd_gelu_s3": ("gelu", 25216, 384, 1536),
     "dgrad_dgelu_s3": ("dgelu", 25216, 384, 1536),
     "dgrad_dgelu_s1": ("dgelu", 401536, 96, 384),
+    "tile_fwd_s3_qkv": ("tile0", 25216, 384, 1152),
+    "tile_dgrad_s3_proj": ("tile1", 25216, 384, 384),
     "wgrad_s1_fc1": ("wgrad", 401536, 384, 96),
     "wgrad_s3_fc1": ("wgrad", 25216, 1536, 384),
 }
@@ -86,6 +88,13 @@ def gemm_case(name, dev):
         b = torch.randn(N, generator=g).bfloat16().to(dev) if op == 0 else None
         out = torch.empty(T, N, dtype=torch.bfloat16, device=dev)
         return lambda: _lib.check(L.vil_gemm_skinny_bf16(op, vp(x), vp(w), vp(b), vp(out), T, K, N, x.stride(0), N, st()))
+    if kind in ("tile0", "tile1"):
+        op = int(kind[-1])
+        x = torch.randn(T, K, generator=g).bfloat16().to(dev)
+        w = (torch.randn(*((N, K) if op == 0 else (K, N)), generator=g) * 0.1).bfloat16().to(dev)
+        b = torch.randn(N, generator=g).bfloat16().to(dev) if op == 0 else None
+        out = torch.empty(T, N, dtype=torch.bfloat16, device=dev)
+        return lambda: _lib.check(L.vil_gemm_tile_bf16(op, vp(x), vp(w), vp(b), vp(out), T, K, N, x.stride(0), N, st()))
     if kind == "gelu":
         x = torch.randn(T, K, generator=g).bfloat16().to(dev)
         w = (torch.randn(N, K, generator=g) * 0.1).bfloat16().to(dev)
