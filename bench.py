@@ -23,7 +23,7 @@ Extra objects on the same line:
                 tagged with its problem shape); achieved = ALGORITHMIC bytes of the launch /
                 its average duration.  `traffic` = PMC HBM bytes per launch of
                 that kernel at that shape, collected inside the real step (tools/pmc_step.sh ->
-                profiles/r04_pmc_traffic.json) and attached ONLY when the kernel sources'
+                profiles/r05_pmc_traffic.json) and attached ONLY when the kernel sources'
                 fingerprint matches the build that is running.
   roofline_by_shape   the same for fwd / dQ / dK+dV / delta at every hot-path shape of the
                 workload, plus `backward_unit`: SURVEY 8(d)'s whole-backward definition
@@ -42,6 +42,13 @@ Extra objects on the same line:
 Every roofline entry carries three roofs: hbm (8.0 TB/s), mfma (2.5 PFLOP/s bf16 dense) and valu -- scores per second
 against the vector pipes' rate for the minimum per-score work (one quarter-rate v_exp_f32 + the multiply-adds, packing and
 row maximum around it: VALU_SLOTS_PER_SCORE below), the practical limiter at head_dim 32.
+
+OUTPUT CONTRACT (round 5).  The LAST stdout line is ONE compact JSON object of at most LINE_LIMIT (4 000) bytes --
+`compact_line()` below: the contract keys, `config`, `roofline`, `cpu_baseline`, and one-number summaries of `secondary`,
+`tertiary`, `eval`, `wgrad_roofline`, `comm`.  Everything else (`roofline_by_shape`, `kernels`, the full secondary / tertiary
+records, the CPU thread sweep and per-layer times) goes to the DETAIL FILE (`--detail`, default
+gpurun_out/bench_detail.json; nothing but the line is printed to stdout).  Round 4's line carried all of it inline
+(29 KB) and the driver could not parse it; tests/test_bench_line_cpu.py pins the size and the required keys.
 """
 import argparse
 import json
@@ -56,21 +63,110 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy rate)
-MFMA_BF16_PEAK_TFLOPS = 2500.0
-F32_VALU_PEAK_TFLOPS = 157.3
-# VALU roof of the attention kernels: lane-slots per second of the vector pipes (256 CUs x 4 SIMD-32 x 2.4 GHz =
-# F32_VALU_PEAK / 2 flops per FMA) over the MINIMUM lane-slots one score costs: v_exp_f32 at quarter rate = 4, plus
-#   forward  fma (scale, -max) 1 + cvt_pk 1/2 + v_max3 1/3                                       -> ~5.8
-#   dQ       fma 1 + mul (P * (dP - delta)) 1 + cvt_pk 1/2 + cvt_i32 + ds_add (histogram) 1      -> ~7.5
-#   dK/dV    fma 1 + mul 1 + 2 x cvt_pk 1/2                                                      -> ~7.0
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md "Chip-level parameters": 8.0 TB/s spec (6.29 TB/s measured copy rate)
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # same table: ~2.5 PF dense bf16 (2495 TF measured)
+F32_VALU_PEAK_TFLOPS = 157.3       # same table: peak FP32 (vector)
+# VALU roof of the attention kernels, stated from MI355X_MICROARCH.md:
+#   "Wave scheduling": a CU has 4 SIMD-32 units and a wave issues each VALU instruction over 2 cycles (32 lanes / cycle),
+#       so the vector pipes retire 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-slots / s (= F32 peak / 2 flops per
+#       FMA).  None of the per-score instructions below is a packed-f32 op (the guide's constants table prices
+#       v_pk_*_f32 beside MFMAs as an anti-lever), so no packing factor is applied.
+#   "Two waves per SIMD", item 3: a transcendental costs ~5/3 of a plain VALU issue, everything else 1.
+# Per-score instruction counts are the ones the compiled loops contain (tools/isa_mix.py --per-score over the
+# -save-temps listing of each kernel, 2048 scores per wave step; profiles/r05_isa_mix.txt), restricted to the
+# instructions no formulation of the step can drop:
+#   forward  v_exp 5/3 + fma (scale, -max) 1 + v_cvt_pk 1/2 + v_max3 1/3                          -> 3.5
+#   dQ       v_exp 5/3 + fma 1 + mul (P * (dP - delta)) 1 + v_cvt_pk 1/2 + v_cvt_i32 (histogram) 1  -> 5.17
+#   dK/dV    v_exp 5/3 + fma 1 + mul 1 + 2 x v_cvt_pk 1/2                                          -> 4.67
 VALU_LANE_SLOTS_PER_S = F32_VALU_PEAK_TFLOPS * 1e12 / 2
-VALU_SLOTS_PER_SCORE = {"k_mfma_fwd": 5.8, "k_dense_fwd": 5.8, "k_mfma_bwd_dq": 7.5, "k_dense_bwd_dq": 7.5,
-                        "k_mfma_bwd_dkdv": 7.0, "k_dense_bwd_dkdv": 7.0}
+TRANSCENDENTAL_SLOTS = 5.0 / 3.0
+VALU_SLOTS_PER_SCORE = {"k_mfma_fwd": round(TRANSCENDENTAL_SLOTS + 1 + 0.5 + 1 / 3, 2),
+                        "k_mfma_bwd_dq": round(TRANSCENDENTAL_SLOTS + 1 + 1 + 0.5 + 1, 2),
+                        "k_mfma_bwd_dkdv": round(TRANSCENDENTAL_SLOTS + 1 + 1 + 1, 2)}
+for _k in ("fwd", "bwd_dq", "bwd_dkdv"):
+    VALU_SLOTS_PER_SCORE["k_dense_" + _k] = VALU_SLOTS_PER_SCORE["k_mfma_" + _k]
 FLOPS_PER_SCORE = {"k_mfma_fwd": 4, "k_dense_fwd": 4, "k_mfma_bwd_dq": 6, "k_dense_bwd_dq": 6, "k_mfma_bwd_dkdv": 8,
                    "k_dense_bwd_dkdv": 8}       # x head_dim: the library's algorithmic flops are 4 / 6 / 8 * scores * M
 # the reference's published evaluation costs (README.md:211-221; unstated GPU, fp16 AMP): seconds per image
 REFERENCE_EVAL_S_PER_IMAGE = {"vil_tiny_224": 0.0022, "vil_small_224": 0.0029}
+
+
+LINE_LIMIT = 4000        # bytes of the final stdout line (the driver keeps an 8 KB tail; round 4's 29 KB line did not parse)
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data")
+ROOFLINE_KEYS = ("kernel", "shape", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                 "avg_launch_ms", "backward_unit_frac")
+
+
+def _short_roofline(r, full=True):
+    if not r:
+        return None
+    out = {k: r.get(k) for k in (ROOFLINE_KEYS if full else ("kernel", "shape", "bound", "frac", "traffic", "backward_unit_frac"))}
+    if full:
+        out["mfma_frac"] = (r.get("mfma") or {}).get("frac")
+        out["valu_frac"] = (r.get("valu") or {}).get("frac")
+    return out
+
+
+def _short_leg(leg):
+    """one secondary / tertiary record -> its headline numbers"""
+    cfg = leg.get("config") or {}
+    return {"metric": leg.get("metric"), "value": leg.get("value"), "unit": leg.get("unit"), "steps": leg.get("steps"),
+            "ms_per_step": leg.get("ms_per_step"), "global_batch": cfg.get("global_batch"),
+            "hot_path_ms_per_step": leg.get("hot_path_ms_per_step"), "roofline": _short_roofline(leg.get("roofline"), full=False)}
+
+
+def compact_line(full, detail_path=None):
+    """The driver-facing line: the bench contract's keys + `roofline` + `cpu_baseline` + one-number summaries of the other
+    legs, at most LINE_LIMIT bytes when serialised.  `full` is the complete record (what goes to the detail file)."""
+    out = {k: full.get(k) for k in CONTRACT_KEYS}
+    cfg = dict(full.get("config") or {})
+    out["config"] = {k: cfg.get(k) for k in ("workload", "global_batch", "per_gpu_batch", "parallelism", "launch", "precision")}
+    out["roofline"] = _short_roofline(full.get("roofline"))
+    out["hot_path_ms_per_step"] = full.get("hot_path_ms_per_step")
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+    if full.get("secondary"):
+        out["secondary"] = _short_leg(full["secondary"])
+    if full.get("tertiary"):
+        out["tertiary"] = [{"metric": t.get("metric"), "value": t.get("value"), "ms_per_step": t.get("ms_per_step"),
+                            "roofline_frac": (t.get("roofline") or {}).get("frac")} for t in full["tertiary"]]
+    if full.get("eval"):
+        out["eval_images_per_s"] = {k: v.get("images_per_s") for k, v in full["eval"].items()}
+    wg = full.get("wgrad_roofline")
+    if wg:
+        out["wgrad"] = {k: wg.get(k) for k in ("ms_per_step", "reduce_ms_per_step", "frac_hbm", "frac_mfma")}
+    cm = full.get("comm")
+    if cm:
+        out["comm"] = {k: cm.get(k) for k in ("ranks_in_communicator", "exposed_bytes_per_step", "bytes_per_step",
+                                               "allreduce_alone_ms_per_segment") if k in cm}
+    out["final_loss"] = full.get("final_loss")
+    out["detail"] = detail_path
+    # never exceed the limit: drop the optional summaries, then shorten the free-text fields
+    for victim in ("comm", "wgrad", "eval_images_per_s", "tertiary"):
+        if len(json.dumps(out)) <= LINE_LIMIT:
+            break
+        out.pop(victim, None)
+    if len(json.dumps(out)) > LINE_LIMIT:
+        for holder, key in ((out["config"], "precision"), (out["config"], "launch"), (out.get("cpu_baseline") or {}, "sample"),
+                            (out["config"], "workload")):
+            if isinstance(holder.get(key), str):
+                holder[key] = holder[key][:160]
+    assert len(json.dumps(out)) <= LINE_LIMIT, "bench line over the limit"
+    return out
+
+
+def write_detail(full, path):
+    """the complete record -> `path` (never stdout); returns the path written, or None"""
+    try:
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f)
+        return path
+    except OSError as exc:
+        print(f"bench.py: could not write the detail file {path}: {exc}", file=sys.stderr)
+        return None
 
 
 def _host_cpu():
@@ -252,16 +348,20 @@ def pmc_traffic(config, B, kernel, label):
     """PMC HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X guide), collected inside the real step by
     tools/pmc_step.sh; only for the build whose kernel sources it was collected on."""
     from vision_longformer_amd import _lib
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
-        if pm.get("source_fingerprint") != _lib.source_fingerprint():
-            return None
-        e = pm["configs"][config]
-        if e["per_gpu_batch"] != B:
-            return None
-        return round(e["kernels"][kernel][label]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+    import glob
+    fp = _lib.source_fingerprint()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):   # newest round first
+        try:
+            pm = json.load(open(path))
+            if pm.get("source_fingerprint") != fp:
+                continue
+            e = pm["configs"][config]
+            if e["per_gpu_batch"] != B:
+                continue
+            return round(e["kernels"][kernel][label]["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def roofline_of(config, B, shapes, tags, kernel="k_mfma_bwd_dkdv"):
@@ -274,13 +374,14 @@ def roofline_of(config, B, shapes, tags, kernel="k_mfma_bwd_dkdv"):
             "mfma": {"achieved": k["TFLOPs"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": k["frac_mfma"]},
             "valu": {"achieved": k.get("Gscores_per_s"), "unit": "Gscores/s", "frac": k.get("frac_valu"),
                      "peak": round(VALU_LANE_SLOTS_PER_S / VALU_SLOTS_PER_SCORE[kernel] / 1e9, 1),
-                     "model": f"{VALU_SLOTS_PER_SCORE[kernel]} vector lane-slots per score (v_exp_f32 at quarter rate = 4)"},
+                     "model": f"{VALU_SLOTS_PER_SCORE[kernel]} vector issue slots per score (transcendental = 5/3, MI355X_MICROARCH.md), "
+                              f"{VALU_LANE_SLOTS_PER_S / 1e12:.1f} T lane-slots/s"},
             "algorithmic_bytes_per_launch": k["bytes_per_launch"], "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
             "achieved_tflops": k["TFLOPs"], "frac_of_bf16_mfma_peak": k["frac_mfma"],
             "backward_unit_frac": shapes[lab].get("backward_unit", {}).get("frac_hbm")}
 
 
-def wgrad_stats(recs):
+def wgrad_stats(recs, nprof=1):
     rows = [(ms, by, fl, tag) for name, ms, by, fl, tag in recs if name == "k_wgrad"]
     red = sum(ms for name, ms, by, fl, tag in recs if name == "k_wgrad_reduce")
     if not rows:
@@ -288,6 +389,7 @@ def wgrad_stats(recs):
     t = sum(r[0] for r in rows) * 1e-3
     by, fl = sum(r[1] for r in rows), sum(r[2] for r in rows)
     return {"kernel": "k_wgrad", "launches": len(rows), "total_ms": round(t * 1e3, 3), "reduce_total_ms": round(red, 3),
+            "ms_per_step": round(t * 1e3 / max(nprof, 1), 3), "reduce_ms_per_step": round(red / max(nprof, 1), 3),
             "GBps": round(by / t / 1e9, 1), "frac_hbm": round(by / t / 1e9 / HBM_PEAK_GBS, 4),
             "TFLOPs": round(fl / t / 1e12, 1), "frac_mfma": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "bound": "mfma" if fl / by > MFMA_BF16_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm"}
@@ -461,6 +563,9 @@ def main():
     ap.add_argument("--no-eval", action="store_true", help="skip the forward-only (evaluation) throughput leg")
     ap.add_argument("--no-tertiary", action="store_true",
                     help="skip the short runs of ViL-Medium-Deep@384 f8/f12 and ViL-Base-Deep@384 random shift")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="file that receives the complete record (per-shape rooflines, kernel table, full secondary / "
+                         "tertiary / eval / cpu_baseline objects); the stdout line is the compact summary")
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="start the ranks, join the process group, all-reduce a one per rank, print {n_gpus} and exit "
                          "(works without a GPU over gloo: the CPU test of the --gpus N launcher)")
@@ -525,7 +630,7 @@ def main():
                                  if m_["use_graph"] else "eager (DDP bucketed all-reduce)"},
             "roofline": roofline_of(config, B_, shapes, tags),
             "roofline_by_shape": shapes,
-            "wgrad_roofline": wgrad_stats(m_["recs"]),
+            "wgrad_roofline": wgrad_stats(m_["recs"], m_["nprof"]),
             "hot_path_ms_per_step": round(hot_ms / m_["nprof"], 3),
             "kernels": ks,
             "comm": m_["comm"],
@@ -592,7 +697,8 @@ def main():
     except OSError:
         pass
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        detail = write_detail(out, args.detail)
+        print(json.dumps(compact_line(out, detail and os.path.relpath(detail, ROOT))), flush=True)
 
 
 if __name__ == "__main__":
