@@ -419,12 +419,7 @@ def measure(args, config, B, steps, warmup, rank, world, device):
             return ok
         ok = 1
         try:
-            if world > 1:      # same initial weights on every rank (what DDP's constructor would do)
-                for p_ in model.parameters():
-                    dist.broadcast(p_.data, 0)
-                if use_master:
-                    for m_ in opt.master:
-                        dist.broadcast(m_, 0)
+            # (replica consistency -- rank 0's weights, masters, optimizer state, tuned plans -- is GraphedTrainStep's own job)
             gstep = GraphedTrainStep(model, opt, *data.next(), world=world, force_segments=args.force_segments)
         except Exception as exc:          # capture refused: every rank falls back to the eager DDP step together
             print(f"[rank {rank}] hipGraph capture failed ({exc!r}); falling back to the eager step", file=sys.stderr)

@@ -116,11 +116,13 @@ def compare(tag, got, ref, tols):
 
 
 F32_TOL = dict(out=(2e-5, 1e-4), dq=(1e-4, 1e-3), dkv=(1e-4, 1e-3), dtable=(5e-4, 1e-3), dg2l=(5e-4, 1e-3))
-LOW_TOL = dict(out=(2e-2, 5e-2), dq=("rms", 0.10, 5e-2), dkv=("rms", 0.10, 5e-2), dqkv=("rms", 0.10, 5e-2),
-               dtable=("rms", 8e-2, 3e-2), dg2l=("rms", 8e-2, 3e-2), dg2g=("rms", 8e-2, 3e-2))
+LOW_TOL = dict(out=(2e-2, 5e-2), dq=("rms", 0.06, 5e-2), dkv=("rms", 0.06, 5e-2), dqkv=("rms", 0.06, 5e-2),
+               dtable=("rms", 8e-2, 3e-2), dg2l=("rms", 6e-2, 3e-2), dg2g=("rms", 6e-2, 3e-2))
 BF16_TOL = LOW_TOL
-# measured on MI355X (gpurun_out/*/parity_report.txt prints err / bound per tensor): worst observed ratio over the
-# ~250 bf16 cases is ~0.45 for q/kv gradients and ~0.67 for the bias gradients under these bounds
+# Round 5: tightened to what is observed.  profiles/r04_parity_report.txt (err / bound per tensor over ~410 report
+# lines) has the q / kv gradients at <= 0.42 of the round-4 bound (0.10 rms): now 0.06 rms.  d(g2l) / d(g2g) were at
+# 0.20 / 0.04 of 0.08 rms: now 0.06.  d(table) stays at 0.08 rms: its worst case sits at 0.79 of it (a 240-entry table
+# whose gradient sums ~10^5 bf16-rounded products per bin), so 0.06 would be red without being wrong.
 
 SMALL = [
     case(2, 16, 4, 8, 8, 1), case(2, 16, 4, 8, 8, 1, rpe=False), case(2, 16, 4, 10, 9, 1),

@@ -267,3 +267,112 @@ def test_graphed_step_observes_lr_schedule(dev):
     report(f"     lr schedule under hipGraph (fp32 step): |graph - eager| {d_sched:.3e}; |scheduled - constant lr| {d_const:.3e}")
     assert d_sched < 2e-3
     assert d_const > 1e-2 and d_const > 5 * d_sched          # the captured step really read the new lr
+
+
+def test_graphed_step_follows_python_float_lr_assignments(dev):
+    """a torch LR scheduler assigns param_group["lr"] = float between iterations (the reference's
+    pattern).  With a Python-float lr (capturable=False) the captured optimizer launch reads a device mirror of it;
+    GraphedTrainStep refreshes the mirror before every replay -- no engine.set_lr call here."""
+    from vision_longformer_amd.engine import make_optimizer, train_step, GraphedTrainStep
+    from vision_longformer_amd.msvit import MsViT
+    arch = "l1,h1,d32,n1,s1,g1,p4,f4,a0_l2,h2,d64,n1,s1,g1,p2,f4,a0_l3,h2,d64,n1,s0,g1,p2,f7,a0"
+    g = torch.Generator().manual_seed(7)
+    xs = [torch.randn(8, 3, 64, 64, generator=g).to(dev) for _ in range(4)]
+    ts = [torch.softmax(torch.randn(8, 10, generator=g), -1).to(dev) for _ in range(4)]
+    lrs = [1e-3, 4e-3, 2e-2, 5e-4]
+
+    def run(graphed, schedule):
+        torch.manual_seed(0)
+        m = MsViT(arch, img_size=64, num_classes=10, drop_path_rate=0.0, norm_embed=True, sharew=True).to(dev).train()
+        opt = make_optimizer(m, lr=lrs[0], capturable=False)          # Python-float lr in the param groups
+        assert not torch.is_tensor(opt.param_groups[0]["lr"])
+        if graphed:
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+            gs = GraphedTrainStep(m, opt, xs[0], ts[0], warmup=2, amp_dtype=None)
+            with torch.no_grad():
+                for k, v in m.state_dict().items():
+                    v.copy_(sd[k])
+            _reset(opt)
+        for i, (x, t) in enumerate(zip(xs, ts)):
+            if schedule:
+                for gr in opt.param_groups:
+                    gr["lr"] = lrs[i]                                 # what torch.optim.lr_scheduler does
+            gs(x, t) if graphed else train_step(m, opt, x, t, amp_dtype=None)
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().float().reshape(-1) for p in m.parameters()]).cpu()
+
+    pe, pg, pg_const = run(False, True), run(True, True), run(True, False)
+    d_sched = float((pe - pg).abs().max())
+    d_const = float((pg - pg_const).abs().max())
+    report(f"     float-lr schedule under hipGraph (fp32 step): |graph - eager| {d_sched:.3e}; |scheduled - constant lr| {d_const:.3e}")
+    assert d_sched < 2e-3
+    assert d_const > 1e-2 and d_const > 5 * d_sched
+
+
+def test_master_weight_step_captured_without_warmup(dev):
+    """allocate() must also create the state of fp32 MASTERS (requires_grad=False; their gradient is
+    the bound bf16 copy's).  GraphedTrainStep(warmup=0) with MasterWeightAdamW used to raise 'optimizer state would be
+    created inside a stream capture'.  The un-warmed graph must train like the eager step."""
+    from vision_longformer_amd.engine import MasterWeightAdamW, train_step, GraphedTrainStep
+    from vision_longformer_amd.msvit import MsViT
+    from vision_longformer_amd import linear
+    arch = "l1,h1,d32,n1,s1,g1,p4,f4,a0_l2,h2,d64,n1,s0,g1,p2,f8,a0"
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(8, 3, 64, 64, generator=g).to(dev) for _ in range(3)]
+    ts = [torch.softmax(torch.randn(8, 10, generator=g), -1).to(dev) for _ in range(3)]
+
+    def run(graphed):
+        torch.manual_seed(0)
+        m = MsViT(arch, img_size=64, num_classes=10, drop_path_rate=0.0, norm_embed=True, sharew=True).to(dev).train()
+        opt = MasterWeightAdamW(m, lr=1e-3, capturable=graphed)
+        if graphed:
+            gs = GraphedTrainStep(m, opt, xs[0], ts[0], warmup=0)
+            inner = opt.opt
+            assert all("exp_avg" in inner.state[mp_] for mp_ in opt.master)
+        losses = [float(gs(x, t) if graphed else train_step(m, opt, x, t)) for x, t in zip(xs, ts)]
+        torch.cuda.synchronize()
+        return losses, torch.cat([p.detach().float().reshape(-1) for p in m.parameters()]).cpu()
+
+    was = linear._DETERMINISTIC_PLANS
+    linear.deterministic_plans(True)           # (no timing-based plan selection: warmup=0 never reaches a tuning call anyway)
+    try:
+        le, pe = run(False)
+        lg, pg = run(True)
+    finally:
+        linear.deterministic_plans(was)
+    dl = max(abs(a - b) for a, b in zip(le, lg))
+    dp = float((pe - pg).abs().max())
+    report(f"     MasterWeightAdamW captured with warmup=0 vs eager: max|dloss| {dl:.3e} max|dparam| {dp:.3e}")
+    assert dl < 2e-2 and dp < 2e-2
+
+
+def test_graphed_step_makes_differently_seeded_replicas_identical(dev, tmp_path):
+    """Review r04 item 7: replica consistency is the engine's job.  Two ranks (sharing cuda:0 over gloo) build their
+    models from DIFFERENT seeds and construct GraphedTrainStep(world=2) with no broadcast of their own; after three
+    steps their parameters must be bit-identical (rank 0's initial weights, the same averaged gradients)."""
+    import socket
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    out = str(tmp_path / "rank0.pt")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VIL_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", VIL_TEST_SEED_PER_RANK="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_graph_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p_ in procs:
+        try:
+            o, _ = p_.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p_.returncode == 0 for p_ in procs), "\n".join(logs)[-4000:]
+    got = torch.load(out)
+    assert got["seeded_per_rank"] and got["differed_before"], "the ranks did not start from different weights"
+    assert got["same"], "ranks diverged although the engine synchronised them"
+    report(f"     differently seeded replicas after GraphedTrainStep(world=2) + 3 steps: identical = {got['same']}")

@@ -283,22 +283,53 @@ def test_wgrad_plan_export_import_and_deterministic_mode():
 
 def _plan_share_worker(rank, world, port, ret):
     import torch.distributed as dist
-    from vision_longformer_amd import _lib, linear
+    from vision_longformer_amd import linear
+    from vision_longformer_amd.engine import sync_replicas, assert_replicas_identical, replica_checksum
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     T, co, ci = 25216, 1536, 384
     mine = (2, 6, 3, 1) if rank == 0 else (2, 3, 6, 2)                     # what each rank's own timing "selected"
-    _lib.check(_lib.lib().vil_linear_wgrad_set_plan(T, co, ci, *mine))
-    linear._share_rank0_plan(T, co, ci, torch.device("cpu"))
-    ret[rank] = linear._wg_get_plan(T, co, ci)
+    plans = {(T, co, ci): mine}
+    if rank == 1:
+        plans[(T, 768, 384)] = (2, 3, 6, 2)                                # a problem only this rank has met
+    linear.import_plans(plans, device="cpu")
+    # replicas built from different seeds (a caller that forgot to seed): the engine's sync makes them rank 0's
+    torch.manual_seed(100 + rank)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.LayerNorm(8))
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    model(torch.randn(4, 8)).sum().backward()
+    opt.step()                                                             # momentum buffers exist and differ per rank
+    lo, hi = replica_checksum(model)
+    differed = not torch.equal(lo, hi)
+    sync_replicas(model, opt)                                              # parameters, optimizer state, plans: ONE entry point
+    assert_replicas_identical(model)
+    mom = torch.cat([opt.state[p]["momentum_buffer"].reshape(-1) for p in model.parameters()])
+    both = [torch.zeros_like(mom) for _ in range(world)]
+    dist.all_gather(both, mom)
+    ret[rank] = (linear._wg_get_plan(T, co, ci), linear._wg_get_plan(T, 768, 384), differed, bool(torch.equal(both[0], both[1])))
+    # a diverged replica is reported, by every rank
+    if rank == 1:
+        with torch.no_grad():
+            next(model.parameters()).add_(1e-3)
+    try:
+        assert_replicas_identical(model, what="test")
+        ret[f"raised{rank}"] = False
+    except RuntimeError:
+        ret[f"raised{rank}"] = True
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_weight_gradient_plan_of_rank0_is_shared_over_gloo():
-    """Two ranks whose timing picked different plans end up on rank 0's (same summation order of dW on every rank)."""
+def test_replica_sync_and_rank0_plans_over_gloo():
+    """engine.sync_replicas (what GraphedTrainStep(world > 1) runs itself): two ranks that differ in parameters,
+    optimizer state and measured weight-gradient plans end up on rank 0's; a problem only one rank has met keeps its
+    local plan and the collective still completes (round 4 broadcast from inside backward); a replica that
+    diverges afterwards is detected on every rank."""
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_plan_share_worker, args=(2, port, ret), nprocs=2, join=True)
-    assert ret[0] == (2, 6, 3, 1, 1) and ret[1] == (2, 6, 3, 1, 1)
+    assert ret[0][0] == (2, 6, 3, 1, 1) and ret[1][0] == (2, 6, 3, 1, 1)
+    assert ret[1][1] == (2, 3, 6, 2, 1) and ret[0][1][4] == 0              # rank 1 keeps its own; rank 0 never had one
+    assert ret[0][2] and ret[1][2] and ret[0][3] and ret[1][3]
+    assert ret["raised0"] and ret["raised1"]

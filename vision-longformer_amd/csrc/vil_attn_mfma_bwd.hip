@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
   // chunk) units (UnitList, vil_mfma_common.h); the workgroup leaves ONE histogram partial (64-bit bins)
   const int h = (int)(blockIdx.x >> 3) % p.H;
   __shared__ int s_started;                                   // units started by the workgroup's waves (histogram drain trigger)
-  if (tid == 0) s_started = 0;
+  __shared__ int s_drained;                                   // ticket of the last COMPLETED drain (a multiple of hist_flush)
+  if (tid == 0) { s_started = 0; s_drained = 0; }
 
   float* tab = (float*)smem;
   int* hist = (int*)(tab + c.tabsize);
@@ -139,15 +140,25 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
       if (lane == 0) started = __hip_atomic_fetch_add(&s_started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       started = __builtin_amdgcn_readfirstlane(started);
     }
+    if (bc.do_hist) {
+      // The bound behind the fixed-point scale (hist_nmax = per-unit contributions x (hist_flush + 2 * waves)) is ENFORCED,
+      // not assumed: a wave may not start unit `started` while the last completed drain lies hist_flush + waves or more
+      // tickets back.  Then a bin holds, between two exchanges, at most the units started since the last completed drain
+      // (< hist_flush + waves) plus the units that were already running when their bins were exchanged (< waves).
+      // Drains are thereby serialised (ticket k * flush waits for drain (k-1) * flush, whose owner never waits), so there
+      // is no deadlock; in practice a drain is ~25 loop trips against ~40 k cycles per unit and the wait never spins.
+      while (started - __hip_atomic_load(&s_drained, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= bc.hist_flush + bc.dq_wpw)
+        __builtin_amdgcn_s_sleep(4);
+    }
     if (bc.do_hist && started > 0 && started % bc.hist_flush == 0) {
       // Every hist_flush units the workgroup starts, the wave that starts that unit first drains the 32-bit bins into the
       // workgroup's 64-bit bins: an atomic exchange per bin, so the other waves keep adding meanwhile and nothing is lost.
-      // A bin therefore receives at most (hist_flush + 2 * waves) units' worth of contributions between two exchanges --
-      // the bound the fixed-point scale is derived from (hist_nmax) -- however long the workgroup lives.
       for (int i = lane; i < c.tabsize; i += 64) {
         const int v = __hip_atomic_exchange(hist + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (v) __hip_atomic_fetch_add(hist64 + i, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+      wave_lds_fence();
+      if (lane == 0) __hip_atomic_store(&s_drained, started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     const int b = fdiv(cur, bc.uq_dq.m_units_bh), urank = cur - b * bc.uq_dq.units_bh;
     const int bh = b * p.H + h;

@@ -357,50 +357,57 @@ __global__ __launch_bounds__(256) void k_f32_vmax(VilParams p, unsigned* vnorm) 
   if (threadIdx.x == 0) atomicMax(vnorm, __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]))));
 }
 
-// d(table)[idx*H + h] and d(g2l)[h*G + g] from the dQ workgroups' records.  grid (ceil(tabsize / 64), H), 1024 threads =
-// 64 bins x 16 record groups; the records of head h are logical workgroups j*H + h.  Every bin is summed in a fixed order
-// in double with its record's scale: bit-reproducible (d(g2l) sums a region of bins: one float atomic per block).
+// d(table)[idx*H + h] and d(g2l)[h*G + g] from the dQ workgroups' records.  grid (ceil(trows * P / 64) + G, H), 1024
+// threads = 64 bins x 16 record groups; the records of head h are logical workgroups j*H + h.  Every bin is summed in a
+// fixed order in double with its record's scale.  d(g2l)[h][g] sums a REGION of gsz bins: the last G blocks of the grid
+// own one global token each and walk its region 64 bins at a time, so that sum has a fixed order too (round 4 added one
+// float atomic per 64-bin block: the order, and the last bits, varied from run to run -- ADVICE r04).  Bit-reproducible.
 __global__ __launch_bounds__(1024) void k_f32_hist_reduce(VilParams p, MfmaCfg c, F32Cfg fc) {
   __shared__ double red[16][64];
-  const int h = blockIdx.y, bin = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  const int ntb = (c.trows * c.P + 63) >> 6;                 // blocks that own table bins
+  const int h = blockIdx.y, grp = threadIdx.x >> 6, ln = threadIdx.x & 63;
   const int nrec = p.B * fc.wg_per_bh, stride = 2 * c.tabsize + 4;
+  const bool owner_g = (int)blockIdx.x >= ntb;
+  const int g_ = (int)blockIdx.x - ntb;
+  if (owner_g && !p.dg2l) return;
+  const int lo = owner_g ? c.glo0 + g_ * c.gsz : blockIdx.x * 64;
+  const int hi = owner_g ? lo + c.gsz : min(lo + 64, c.trows * c.P);
   double s = 0.0;
-  if (bin < c.tabsize)
-    for (int j0 = grp; j0 < nrec; j0 += 64) {
-      int vh[4], vl[4], lf[4];
+  for (int base = lo; base < hi; base += 64) {               // (one trip for a table block)
+    const int bin = base + ln;
+    if (bin < hi)
+      for (int j0 = grp; j0 < nrec; j0 += 64) {
+        int vh[4], vl[4], lf[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = min(j0 + 16 * u, nrec - 1);
-        const int* r = fc.hist_parts + ((int64_t)j * p.H + h) * stride;
-        const bool ok = j0 + 16 * u < nrec;
-        vh[u] = ok ? r[bin] : 0; vl[u] = ok ? r[c.tabsize + bin] : 0;
-        lf[u] = r[2 * c.tabsize];
+        for (int u = 0; u < 4; ++u) {
+          const int j = min(j0 + 16 * u, nrec - 1);
+          const int* r = fc.hist_parts + ((int64_t)j * p.H + h) * stride;
+          const bool ok = j0 + 16 * u < nrec;
+          vh[u] = ok ? r[bin] : 0; vl[u] = ok ? r[c.tabsize + bin] : 0;
+          lf[u] = r[2 * c.tabsize];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += ldexp((double)vh[u] * 65536.0 + (double)vl[u], -lf[u]);
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) s += ldexp((double)vh[u] * 65536.0 + (double)vl[u], -lf[u]);
-    }
-  red[grp][threadIdx.x & 63] = s;
+  }
+  red[grp][ln] = s;
   __syncthreads();
   if (grp != 0) return;
   double t = 0.0;
 #pragma unroll
-  for (int u = 0; u < 16; ++u) t += red[u][threadIdx.x];
-  const float sf = (float)t;
-  int gg = -1;
-  if (bin < c.trows * c.P) {
+  for (int u = 0; u < 16; ++u) t += red[u][ln];
+  if (owner_g) {
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2, 64);     // (fixed butterfly: same order every run)
+    if (ln == 0) p.dg2l[h * p.G + g_] = (float)t;
+    return;
+  }
+  const int bin = lo + ln;
+  if (bin < hi) {
     const int row = bin / c.P, col = bin % c.P - VIL_CPAD;
     const int dx = row - c.tcen, dy = col - c.tcen, o = p.bias_off;
     if (col >= 0 && col < c.trows && p.dtable && dx >= -o && dx <= o && dy >= -o && dy <= o)
-      p.dtable[(int64_t)((dx + o) * p.bias_S + (dy + o)) * p.H + h] = sf;
-  } else if (bin >= c.glo0 && bin < c.tabsize && p.dg2l) {
-    gg = (bin - c.glo0) / c.gsz;
-  }
-  for (int g_ = 0; g_ < p.G; ++g_) {
-    if (!__any(gg == g_)) continue;
-    float v = gg == g_ ? sf : 0.f;
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2, 64);
-    if (threadIdx.x == 0 && v != 0.f) atomicAdd(&p.dg2l[h * p.G + g_], v);
+      p.dtable[(int64_t)((dx + o) * p.bias_S + (dy + o)) * p.H + h] = (float)t;
   }
 }
 
@@ -780,7 +787,7 @@ int vil_f32_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   }
   if (hist) {
     vil_prof_begin(VIL_K_REDUCE_BIAS, s, 0, 0);
-    k_f32_hist_reduce<<<dim3((unsigned)((c.tabsize + 63) / 64), (unsigned)p.H), dim3(1024), 0, s>>>(p, c, fc);
+    k_f32_hist_reduce<<<dim3((unsigned)((c.trows * c.P + 63) / 64 + p.G), (unsigned)p.H), dim3(1024), 0, s>>>(p, c, fc);
     vil_prof_end(s);
     e = (int)hipGetLastError();
   }

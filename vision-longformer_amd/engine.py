@@ -349,6 +349,67 @@ def train_step(model, optimizer, images, targets, amp_dtype=torch.bfloat16):
     return loss.detach()
 
 
+def _dist_on(world=None):
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() if world is None else world) > 1
+
+
+def _optimizer_tensors(optimizer):
+    """every tensor a replica's optimizer owns, in a rank-independent order: fp32 masters, then the state tensors of the
+    parameters in param-group order (moments / momentum buffers), then tensor learning rates"""
+    out = []
+    inner = getattr(optimizer, "opt", optimizer)
+    out += list(getattr(optimizer, "master", []))
+    for group in inner.param_groups:
+        for p in group["params"]:
+            st = inner.state.get(p, {})
+            out += [st[k] for k in sorted(st) if torch.is_tensor(st[k])]
+        if torch.is_tensor(group.get("lr")):
+            out.append(group["lr"])
+    for bucket in getattr(inner, "_plans", {}).values():       # device step counters of the HIP optimizer
+        out.append(bucket.steps)
+    return out
+
+
+@torch.no_grad()
+def sync_replicas(model, optimizer=None, src=0):
+    """What DistributedDataParallel's constructor does for the reference (src/run_experiment.py:146-153), for the
+    graphed step: every rank takes rank `src`'s parameters, buffers, fp32 masters, optimizer state and tuned
+    weight-gradient plans.  A collective: every rank of the default process group must call it at the same point."""
+    if not _dist_on():
+        return
+    tensors = [p.data for p in model.parameters()] + [b for b in model.buffers()]
+    if optimizer is not None:
+        tensors += _optimizer_tensors(optimizer)
+    for t in tensors:
+        dist.broadcast(t, src)
+    from . import linear
+    linear.sync_plans(src)
+
+
+@torch.no_grad()
+def replica_checksum(model, optimizer=None):
+    """(min over ranks, max over ranks) of an fp64 checksum of this replica's parameters (+ masters): equal <=> the
+    replicas hold the same values (bit for bit up to checksum collisions)."""
+    ts = [p.data for p in model.parameters()] + list(getattr(optimizer, "master", []) if optimizer is not None else [])
+    dev = ts[0].device
+    acc = torch.zeros(2, dtype=torch.float64, device=dev)
+    for i, t in enumerate(ts):
+        f = t.detach().double().reshape(-1)
+        acc[0] += f.sum()
+        acc[1] += (f * f).sum() * (1.0 + (i % 7))
+    lo, hi = acc.clone(), acc.clone()
+    if _dist_on():
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return lo, hi
+
+
+def assert_replicas_identical(model, optimizer=None, what="parameters"):
+    lo, hi = replica_checksum(model, optimizer)
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"data-parallel replicas diverged ({what}): checksum range {lo.tolist()} .. {hi.tolist()}")
+
+
 class GraphedTrainStep:
     """The training step as hipGraphs (HIP streams + graphs instead of per-op eager launches).
 
@@ -368,8 +429,14 @@ class GraphedTrainStep:
     kernels (VilAttnDesc.mode_dev), refreshed from the host before every replay."""
 
     def __init__(self, model, optimizer, images, targets, world=1, amp_dtype=torch.bfloat16, warmup=3, segments=3,
-                 force_segments=False):
+                 force_segments=False, sync=True):
         self.model, self.opt, self.world, self.amp = model, optimizer, world, amp_dtype
+        # Replica consistency is the step's own job (DistributedDataParallel's constructor does it for the reference,
+        # src/run_experiment.py:146-153): rank 0's parameters, buffers, masters and optimizer state before the warm-up
+        # steps; rank 0's tuned plans after them; and a checksum over ranks before anything is captured.
+        self._sync = bool(sync) and _dist_on(world)
+        if self._sync:
+            sync_replicas(model, optimizer)
         # force_segments: the multi-rank structure (segment graphs, flat-gradient all-reduce per segment on the process
         # group's stream, optimizer graph) with world == 1 -- exercises the RCCL path on a single GPU
         self.segmented = world > 1 or bool(force_segments)
@@ -436,6 +503,10 @@ class GraphedTrainStep:
                 self._body(eager=True)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        if self._sync:
+            from . import linear
+            linear.sync_plans(0)                  # plans measured during the warm-up steps: rank 0's, on every rank
+            assert_replicas_identical(model, optimizer, "after the warm-up steps, before capture")
         settle = getattr(self.opt, "settle", None) or getattr(self.opt, "after_capture", None)
         if hasattr(self.opt, "allocate"):
             self.opt.allocate()
@@ -570,9 +641,18 @@ class GraphedTrainStep:
                 self._allreduce(self.seg_flats[k])
         self.opt.step()
 
+    def _sync_lr(self):
+        """A scheduler that assigns param_group["lr"] = float between replays (the reference's pattern,
+        src/engine.py:60-135 with its per-iteration scheduler step) is followed: changed Python-float learning rates are
+        written into the device scalars the captured optimizer launch reads (one tiny fill per changed group)."""
+        for o in (self.opt, getattr(self.opt, "opt", None)):
+            if hasattr(o, "sync_lr"):
+                o.sync_lr()
+
     def __call__(self, images, targets):
         self.x.copy_(images, non_blocking=True)
         self.t.copy_(targets, non_blocking=True)
+        self._sync_lr()
         self._draw_modes()
         if self.opt_graph is None:
             self.graphs[0].replay()

@@ -61,7 +61,7 @@ _WG_TUNED = set()
 # environment -- switches the timing off: the library's cost model / hipBLASLt's first heuristic choice run, the same in
 # every run and on every rank.  With measurement left on, export_plans() / import_plans() carry the selection across a
 # resume (put the dict next to the checkpoint), and under torch.distributed with world size > 1 every rank takes rank 0's
-# measured weight-gradient plan (one small broadcast per problem, in the eager warm-up step that precedes capture).
+# measured weight-gradient plans through sync_plans() -- ONE collective outside autograd, after the eager warm-up steps.
 _DETERMINISTIC_PLANS = os.environ.get("VIL_DETERMINISTIC_PLANS", "0") not in ("", "0")
 
 
@@ -98,16 +98,23 @@ def import_plans(plans, device=None):
         _WG_TUNED.add((dev, T, co, ci))
 
 
-def _share_rank0_plan(T, co, ci, device):
-    """Under a process group of more than one rank: every rank runs rank 0's measured plan (same dW summation order)."""
+def sync_plans(src=0, device=None):
+    """Every rank takes rank `src`'s weight-gradient plans (same dW summation order on every rank, and -- with
+    export_plans() saved next to the checkpoint -- across a resume).  A COLLECTIVE on the default process group, called
+    outside autograd at a point every rank reaches together: engine.sync_replicas() and GraphedTrainStep call it after
+    the warm-up steps.  (Round 4 broadcast a plan from inside the backward pass whenever a rank tuned a new problem; a
+    rank that had imported its plans, or saw another token count, would have skipped that collective and hung the
+    others.)  import_plans() / deterministic_plans() must be applied identically on every rank; problems only some
+    ranks have met keep their local plan."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return
-    from . import _lib
-    t = torch.tensor(_wg_get_plan(T, co, ci)[:4], dtype=torch.int64, device=device)
-    dist.broadcast(t, src=0)
-    gen, mi, nj, m = (int(v) for v in t.tolist())
-    _lib.check(_lib.lib().vil_linear_wgrad_set_plan(T, co, ci, gen, mi, nj, m))
+    box = [export_plans() if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    if dist.get_rank() != src and box[0]:
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        import_plans(box[0], device)
 
 
 def _wgrad(dy2, x2, want_db):
@@ -137,7 +144,6 @@ def _wgrad(dy2, x2, want_db):
         # one-off plan selection per problem by measurement (synchronises; never inside a captured region)
         _WG_TUNED.add(key)
         _lib.check(L.vil_linear_wgrad_tune(*args))
-        _share_rank0_plan(T, co, ci, dy2.device)
     _lib.check(L.vil_linear_wgrad(*args))
     return dw, db
 

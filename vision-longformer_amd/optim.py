@@ -118,7 +118,9 @@ class _VilOptimizer(Optimizer):
             for gr in groups:
                 self._lr_mirror(gr, ps[0].device)
                 for p in gr["params"]:
-                    if p.requires_grad:
+                    # (fp32 masters are requires_grad=False: their gradient is the bound 16-bit copy's -- the same
+                    # rule step() applies through _grad_of)
+                    if p.requires_grad or id(p) in self._bound:
                         self._state_for(p, gr)
 
     def _new_state(self, p):
