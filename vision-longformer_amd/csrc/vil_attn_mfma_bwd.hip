@@ -568,6 +568,9 @@ __device__ __forceinline__ void kv_slots_block(const VilParams& p, const MfmaCfg
       const int nvalid = min(W, g.ny - qc0);
       int tok = qr * g.ny + qc0;
       int aq = glo ? 0 : ((xl - dr * W) * c.P - dc * W + c.aconst) * 4;
+      // kv_gspare: bit 0 marks the slots of the key chunk's OWN query chunk -- the only ones that count for the global
+      // key riding in the unit's spare column (every query must meet the global key exactly once)
+      if (bc.kv_gspare && !glo && dr == 0 && dc == 0) aq |= 1;
       int s = ci * W2 + xl * W;
       for (int yl = 0; yl < nvalid; ++yl) {
         s_tok[s] = tok; s_aq[s] = aq;
@@ -651,6 +654,9 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   float* s_dlt = s_lse + bc.nqs;                  // [nqs] delta
   char* s_q = (char*)(s_dlt + bc.nqs);            // [32][M] bf16 Q tile, then the [32][M] dO tile (PIPE: two such pairs)
   char* s_gq = s_q + (PIPE ? 4 : 2) * 32 * M * 2;   // [G][3][M] bf16: q, dO, out rows of the global queries
+  float* s_gs = (float*)(s_gq + p.G * 3 * M * 2);   // [G][4] lse_g * log2e, g2l[0] * log2e, g2g[..][0] * log2e of the global queries (staged at unit start)
+  int* s_aqg = (int*)(s_gs + 4 * p.G);            // [nqs] (kv_gspare) address term of the GLOBAL key's column: its g2l region for the
+                                                  //       own chunk's queries, the all-masked guard region for every other slot
 
   const int Nloc = g.nx * g.ny;
   const int qstride_b = (int)p.q_st * 2, dostride_b = (int)p.do_st * 2;
@@ -697,8 +703,14 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     // ---- this lane's key slots: column j of key-tile kt is key (x, y = KT*hq + KT-1 - kt)
     const int jj = wp * 16 + lj;
     const int kx = fdiv(jj, bc.m_kv_HQ), khq = jj - kx * bc.kv_HQ;
-    const unsigned akl = (unsigned)(glo ? -(c.glo0 + min(lj, max(p.G - 1, 0)) * c.gsz) * 4
-                                        : (min(kx, W - 1) * c.P + KT * khq + KT - 1) * 4) - tab_lds;
+    // kv_gspare (G == 1): key tile 0 of the chunk's first unused (x, hq) pair is the GLOBAL key.  Its scores use the g2l
+    // region of the table for the own chunk's queries and the guard region (-1e30 -> P = dS = 0) for the other streamed
+    // chunks (s_aqg), so every query meets it once over the pass; its dK / dV partial goes to glo_parts[chunk].  The
+    // pair's other key tiles are junk columns (finite, never stored): key columns are independent in this pass.
+    const bool gcol = bc.kv_gspare && !glo && jj == bc.kv_gjj;
+    const unsigned akl = (unsigned)((glo || gcol) ? -(c.glo0 + (gcol ? 0 : min(lj, max(p.G - 1, 0))) * c.gsz) * 4
+                                                  : (min(kx, W - 1) * c.P + KT * khq + KT - 1) * 4) - tab_lds;
+    const int* aqsel = gcol ? s_aqg : s_aq;
     int ktok[KT];
     bool kreal[KT];
 #pragma unroll
@@ -711,6 +723,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
         const int kr = km * W + kx, kc = kn * W + ky;
         kreal[kt] = kx < W && ky < W && kr < g.nx && kc < g.ny;
         ktok[kt] = p.G + (kreal[kt] ? kr * g.ny + kc : (km * W) * g.ny + kn * W);
+        if (gcol && kt == 0) ktok[kt] = 0;            // (kreal stays false: the local epilogue skips it)
       }
     }
     // The K / V fragments of these slots: at head_dim 64 they are requested HERE, so that their round trip runs under
@@ -741,6 +754,14 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
                                     : (const T*)p.o_g + b * p.o_sb + (int64_t)gq * p.o_st + h * p.o_sh;
         *(X8*)(s_gq + i * 16) = *(const X8*)(src + c8 * 8);
       }
+      // ... and the three scalars per global query the tail needs (they used to be loaded THERE: a dependent HBM / L2
+      // round trip at the end of every unit, with nothing left to hide it)
+      for (int gq = 0; gq < p.G; ++gq) {           // (wave-uniform addresses: scalar loads, no address registers)
+        const float l_ = p.lse_g[(int64_t)bh * p.G + gq];
+        const float b0_ = p.g2l0 ? p.g2l0[h * p.G + gq] : 0.f;
+        const float b1_ = p.g2g ? p.g2g[((int64_t)h * p.G + gq) * p.G] : 0.f;
+        if (lane == 0) *(f32x4*)(s_gs + 4 * gq) = (f32x4){l_ * LOG2E, b0_ * LOG2E, b1_ * LOG2E, 0.f};
+      }
     }
     const int tix = glo ? bc.nch + split : ch;
     const int nchunks = __builtin_amdgcn_readfirstlane(bc.kv_nchunks[tix]);
@@ -764,7 +785,9 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           const int sl = s0 + u * 64 + lane;
           if (sl < bc.nqs) {
             const bool real = e[u].x >= 0;
-            s_tok[sl] = max(e[u].x, 0); s_aq[sl] = e[u].y;
+            const int aq_ = e[u].y & ~3;
+            s_tok[sl] = max(e[u].x, 0); s_aq[sl] = aq_;
+            if (bc.kv_gspare) s_aqg[sl] = (e[u].y & 1) ? aq_ : aq_ - (c.glo0 - c.guard0) * 4;
             s_lse[sl] = real ? l4[u] * LOG2E : LSE_PAD; s_dlt[sl] = real ? d4[u] : 0.f;
           }
         }
@@ -816,7 +839,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       f32x4 nd4[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const i32x4 aq4 = *(const i32x4*)(s_aq + st * 32 + hf * 16 + lg * 4);
+        const i32x4 aq4 = *(const i32x4*)(aqsel + st * 32 + hf * 16 + lg * 4);
         nd4[hf] = -*(const f32x4*)(s_dlt + st * 32 + hf * 16 + lg * 4);   // dP - delta rides in the accumulator
         lds_cvf tb[4];
 #pragma unroll
@@ -931,7 +954,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     // fill), dK/dV added straight into the accumulators, the unit's share of dq_g / d(bias) to a partial
     // record.  Replaces a separate pass that re-read k, v, dk, dv and rewrote dk, dv.
     if (p.glo_rows && (!glo || split == 0)) {
-      float* rec = bc.gq_parts + ((int64_t)bh * (nown + 1) + (glo ? nown : unit)) * p.G * (M + 4);
+      float* rec = bc.gq_parts + ((int64_t)bh * bc.gq_nrec + (glo ? nown : unit)) * p.G * (M + 4);
       for (int gq = 0; gq < p.G; ++gq) {
         const T* qg = (const T*)(s_gq + gq * 3 * M * 2);
         const T* dg = qg + M;
@@ -951,11 +974,12 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           }
         }
         dl += __shfl_xor(dl, 16, 64); dl += __shfl_xor(dl, 32, 64);
-        const float lg2 = p.lse_g[(int64_t)bh * p.G + gq] * LOG2E;
+        const float lg2 = s_gs[4 * gq];
         float bias = 0.f;
-        if (glo) { if (p.g2g) bias = p.g2g[((int64_t)h * p.G + gq) * p.G + min(lj, p.G - 1)]; }
-        else if (p.g2l0) bias = p.g2l0[h * p.G + gq];
-        bias *= LOG2E;
+        if (glo) { if (p.g2g) bias = p.g2g[((int64_t)h * p.G + gq) * p.G + min(lj, p.G - 1)] * LOG2E; }
+        else bias = s_gs[4 * gq + 1];
+        // kv_gspare: the (global query, global key) pair is counted by chunk 0's unit alone, with the g2g bias
+        const bool gpair = gcol && ch == 0;
         // (staged so that few values are live at once: this kernel has no registers to spare)
         float pr[KT], ds[KT], bsum = 0.f;
 #pragma unroll
@@ -970,11 +994,13 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
             }
           sc += __shfl_xor(sc, 16, 64); sc += __shfl_xor(sc, 32, 64);
           dp += __shfl_xor(dp, 16, 64); dp += __shfl_xor(dp, 32, 64);
-          pr[kt] = kreal[kt] ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc, c1, bias - lg2)) : 0.f;
+          const bool gk_ = kt == 0 && gpair;
+          pr[kt] = (kreal[kt] || gk_) ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc, c1, (gk_ ? s_gs[4 * gq + 2] : bias) - lg2)) : 0.f;
           ds[kt] = pr[kt] * (dp - dl);
-          if (!glo) bsum += ds[kt];
+          if (!glo && !gk_) bsum += ds[kt];
         }
         if (glo && kreal[0] && lg == 0 && p.dg2g) atomicAdd(&p.dg2g[((int64_t)h * p.G + gq) * p.G + lj], ds[0]);
+        if (gpair && lg == 0 && p.dg2g) atomicAdd(&p.dg2g[((int64_t)h * p.G + gq) * p.G], ds[0]);
         float dqp[MK][8];
 #pragma unroll
         for (int ks = 0; ks < MK; ++ks)
@@ -1027,6 +1053,10 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     }
 
     // ---- epilogue
+    // (the store addresses are derived from ktok HERE: left to itself the compiler forms the eight 64-bit row addresses
+    //  before the step loop and carries -- or, one register over the budget, spills -- them through it)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) asm volatile("" : "+v"(ktok[kt]));
     if (!glo) {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
@@ -1043,6 +1073,16 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
             *(X4*)(dvb + (int64_t)ktok[kt] * p.dv_st + dt * 16 + lg * 4) = wv;
           }
         }
+      if (gcol) {              // the global key's dK / dV partial of this chunk (reduced by reduce_glo_block)
+        float* out = bc.glo_parts + (((int64_t)bh * bc.glo_nrec + ch) * p.G) * 2 * M;
+#pragma unroll
+        for (int dt = 0; dt < MD; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            out[dt * 16 + lg * 4 + r] = dk[dt][0][r] * p.scale;
+            out[M + dt * 16 + lg * 4 + r] = dv[dt][0][r];
+          }
+      }
     } else if (kreal[0]) {
       const int rec_ = bc.glo_from_dq ? bc.glo_nrec - 1 : split;       // (the dQ pass wrote records 0 .. glo_nrec-2)
       float* out = bc.glo_parts + ((((int64_t)bh * bc.glo_nrec + rec_) * p.G + lj) * 2) * M;
@@ -1254,17 +1294,28 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
 #define VIL_GLO_FROM_DQ 0
 #endif
   bc.glo_from_dq = VIL_GLO_FROM_DQ && d->G > 0 && d->G <= 4 && d->M <= 32 && bc.nch >= 32;
-  bc.nsplit = d->G > 0 ? (bc.glo_from_dq ? 1 : (bc.nch + 8) / 9) : 0;
   bc.kv_KT = d->M >= 48 ? 2 : (d->M == 32 ? VIL_KV_KT32 : 4);
   bc.kv_HQ = (g.W + bc.kv_KT - 1) / bc.kv_KT;
   bc.kv_NWP = (g.W * bc.kv_HQ + 15) / 16;
+  // Round 5: with ONE global token (every published model) and an unused (x, hq) pair in the chunk's last wave (W = 7:
+  // 14 of 16 pairs used), the global key rides in that pair's key tile 0 of every chunk's unit, live only against the
+  // chunk's own queries.  The owner units this replaces -- (nch + 8) / 9 per (image, head), each streaming a ninth of
+  // all queries through four key tiles with ONE useful column -- were 11-12 % of the pass's units.
+  // W = 8 / head_dim 32 (16 of 16 pairs used) and G > 1 keep the owner units.
+#ifndef VIL_KV_GSPARE
+#define VIL_KV_GSPARE 1
+#endif
+  bc.kv_gjj = g.W * bc.kv_HQ;
+  bc.kv_gspare = VIL_KV_GSPARE && d->G == 1 && !d->only_glo && !bc.glo_from_dq && bc.kv_gjj < 16 * bc.kv_NWP;
+  bc.nsplit = d->G > 0 ? (bc.kv_gspare ? 0 : (bc.glo_from_dq ? 1 : (bc.nch + 8) / 9)) : 0;
   bc.units_kv_bh = bc.nch * bc.kv_NWP + bc.nsplit;
+  bc.gq_nrec = bc.nch * bc.kv_NWP + (bc.kv_gspare ? 0 : 1);
   // streamed query slots: an own-key unit sees <= nact query chunks, a global-key unit its share of all chunks
-  const int qch = (d->G > 0 && !bc.glo_from_dq) ? (bc.nch + bc.nsplit - 1) / bc.nsplit : 0;
+  const int qch = (d->G > 0 && !bc.glo_from_dq && bc.nsplit > 0) ? (bc.nch + bc.nsplit - 1) / bc.nsplit : 0;
   bc.nqs = ((qch > g.nact ? qch : g.nact) * g.W2 + 31) & ~31;
   // slot tables + Q/dO tiles + the q / dO / out rows of the G global queries (vil_attn_bwd_full)
   const int kv_tiles = (VIL_KV_PIPE && d->M == 32 && bc.kv_KT == 2) ? 4 : 2;       // Q + dO tiles (pipelined kernel: two pairs)
-  bc.kv_wave_lds = ((bc.nqs * 16 + kv_tiles * 32 * d->M * 2 + d->G * 3 * d->M * 2 + 15) / 16) * 16;
+  bc.kv_wave_lds = ((bc.nqs * 16 + kv_tiles * 32 * d->M * 2 + d->G * 3 * d->M * 2 + d->G * 16 + (bc.kv_gspare ? bc.nqs * 4 : 0) + 15) / 16) * 16;
   bc.kv_wpw = 4;
   while (bc.kv_wpw > 1 && (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
   const int groups = (bc.units_kv_bh + bc.kv_wpw - 1) / bc.kv_wpw;
@@ -1281,7 +1332,7 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   bc.dq_HQ = (g.W + bc.dq_QT - 1) / bc.dq_QT;
   bc.dq_NWP = (g.W * bc.dq_HQ + 15) / 16;
   bc.dq_units_bh = bc.nch * bc.dq_NWP;
-  bc.glo_nrec = bc.glo_from_dq ? bc.dq_units_bh + 1 : bc.nsplit;
+  bc.glo_nrec = bc.kv_gspare ? bc.nch : (bc.glo_from_dq ? bc.dq_units_bh + 1 : bc.nsplit);
   bc.dq_wpw = 4;
   while (bc.dq_wpw > 1 && (size_t)c.tabsize * 16 + (size_t)bc.dq_wpw * bc.dq_wave_lds > 160 * 1024) bc.dq_wpw >>= 1;
   {
@@ -1341,7 +1392,7 @@ static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& 
   off[2] = off[1] + (size_t)d->H * c.tabsize;
   off[3] = off[2] + (size_t)bc.dq_nwg * c.tabsize * 2;                              // 64-bit histogram records
   off[4] = off[3] + (size_t)d->B * d->H * bc.glo_nrec * d->G * 2 * d->M;
-  off[5] = (off[4] + (size_t)d->B * d->H * (bc.nch * bc.kv_NWP + 1) * d->G * (d->M + 4) + 3) & ~(size_t)3;
+  off[5] = (off[4] + (size_t)d->B * d->H * bc.gq_nrec * d->G * (d->M + 4) + 3) & ~(size_t)3;
   off[6] = off[5] + (size_t)(bc.nch + bc.nsplit) * bc.nqs * 2;                    // dK/dV slot tables (int2)
   off[7] = off[6] + (((size_t)(bc.nch + bc.nsplit) + 3) & ~(size_t)3);             // their chunk counts
   off[8] = off[7] + vil_key_slots_floats(c, bc.nch);                               // key-slot tables of the dQ pass
@@ -1443,9 +1494,9 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     if (nglo + nh > 0) {
       vil_prof_begin(VIL_K_REDUCE_GLO, s, 0, 0);
       if (d->dtype == VIL_DTYPE_F16)
-        k_mfma_post_bwd<_Float16><<<dim3((unsigned)(nglo + nh)), dim3(1024), 0, s>>>(p, c, bc, bc.nch * bc.kv_NWP + 1, nglo, nhx);
+        k_mfma_post_bwd<_Float16><<<dim3((unsigned)(nglo + nh)), dim3(1024), 0, s>>>(p, c, bc, bc.gq_nrec, nglo, nhx);
       else
-        k_mfma_post_bwd<__bf16><<<dim3((unsigned)(nglo + nh)), dim3(1024), 0, s>>>(p, c, bc, bc.nch * bc.kv_NWP + 1, nglo, nhx);
+        k_mfma_post_bwd<__bf16><<<dim3((unsigned)(nglo + nh)), dim3(1024), 0, s>>>(p, c, bc, bc.gq_nrec, nglo, nhx);
       vil_prof_end(s);
     }
   }

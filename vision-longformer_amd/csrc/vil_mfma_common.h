@@ -426,6 +426,9 @@ struct BwdCfg {
   UnitQueue uq_dq, uq_kv;   // units of the two passes (persistent workgroups, see UnitQueue)
   int kv_nwg;         // workgroups of the dK/dV launch
   int hist_flush;     // dQ pass: the LDS histogram is drained into the workgroup's 64-bit bins every hist_flush started units
+  int kv_gspare;      // dK/dV pass, G == 1: the global key rides in a spare key column of every chunk's last wave (no owner units)
+  int kv_gjj;         // ... that column's (x, hq) pair index within the chunk (= W * kv_HQ, the first unused pair)
+  int gq_nrec;        // records per (image, head) in gq_parts: nch * kv_NWP (+ 1: the owner unit's, without kv_gspare)
 };
 
 struct PrepZero { unsigned* ptr[5]; int n[5]; int total; };
