@@ -506,6 +506,9 @@ __device__ __forceinline__ void reduce_hist_block(const VilParams& p, const Mfma
 #ifndef VIL_KV_WAVES
 #define VIL_KV_WAVES 2     // waves per SIMD of the head_dim 32 instantiation
 #endif
+#ifndef VIL_KV_FASTPRO
+#define VIL_KV_FASTPRO 1   // unit prologue as two memory round trips instead of seven (0: the round-4 order, for A/B builds)
+#endif
 // Streamed-query slot tables of the dK/dV pass.  Which query rows a key chunk is attended by, and the bias-table address
 // term of each, depend on the chunk position only -- not on the (image, head) -- so one wave per key
 // chunk (and per global-key split) builds the table ONCE per call (a role of k_mfma_prep_bwd); the dK/dV waves used to rebuild it per (image, head,
@@ -641,11 +644,13 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   const unsigned tab_lds = lds_addr(smem);
 
   float* tab = (float*)smem;
+#if !VIL_KV_FASTPRO
   {
     const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
     for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
   }
   __syncthreads();
+#endif
 
   char* wbase = smem + (size_t)c.tabsize * 4 + (size_t)wave * bc.kv_wave_lds;
   int* s_tok = (int*)wbase;                       // [nqs] token index of each streamed query slot (Q / dO row)
@@ -655,8 +660,10 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   char* s_q = (char*)(s_dlt + bc.nqs);            // [32][M] bf16 Q tile, then the [32][M] dO tile (PIPE: two such pairs)
   char* s_gq = s_q + (PIPE ? 4 : 2) * 32 * M * 2;   // [G][3][M] bf16: q, dO, out rows of the global queries
   float* s_gs = (float*)(s_gq + p.G * 3 * M * 2);   // [G][4] lse_g * log2e, g2l[0] * log2e, g2g[..][0] * log2e of the global queries (staged at unit start)
-  int* s_aqg = (int*)(s_gs + 4 * p.G);            // [nqs] (kv_gspare) address term of the GLOBAL key's column: its g2l region for the
-                                                  //       own chunk's queries, the all-masked guard region for every other slot
+  int* s_aqg = (int*)(s_gs + 4 * p.G);            // [nqs] (kv_gspare) address term of the GLOBAL key's column, relative to its g2l region:
+                                                  //       the query's position in the own chunk ((x * P + y) * 4 -- the region is as wide
+                                                  //       as that range, like the forward's global key slots), or, for every slot of another
+                                                  //       chunk, the distance to the all-masked guard region
 
   const int Nloc = g.nx * g.ny;
   const int qstride_b = (int)p.q_st * 2, dostride_b = (int)p.do_st * 2;
@@ -693,8 +700,16 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   const float* lse_bh = p.lse + (int64_t)bh * Nloc;
   const float* dlt_bh = p.delta + (int64_t)bh * Nloc;
   for (int gi = 0; gi < bc.kv_gpw; ++gi) {
+#if VIL_KV_FASTPRO
+    // A wave whose first unit lies beyond the range still copies its share of the bias image before it leaves
+    const int unit_ = (wgi * bc.kv_gpw + gi) * bc.kv_wpw + wave;
+    const bool valid = unit_ < bc.units_kv_bh;
+    if (!valid && gi > 0) break;
+    const int unit = valid ? unit_ : 0;
+#else
     const int unit = (wgi * bc.kv_gpw + gi) * bc.kv_wpw + wave;
     if (unit >= bc.units_kv_bh) break;
+#endif
     const bool glo = unit >= nown;                 // global-key owner unit
     const int split = unit - nown;
     const int ch = glo ? 0 : fdiv(unit, bc.m_kv_NWP), wp = glo ? 0 : unit - ch * bc.kv_NWP;
@@ -742,6 +757,90 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           vfb[ks][kt] = d0 < M ? *(const X8*)(vb + (int64_t)ktok[kt] * p.v_st + d0) : z;
         }
     };
+#if VIL_KV_FASTPRO
+    // ---- unit prologue in TWO memory round trips (round 5).  It used to be a chain of seven: bias image -> barrier ->
+    // global-query rows -> chunk count -> slot entries -> lse / delta gathers (twice at 448 slots) -> own K / V -> first
+    // Q / dO rows, ~12-15 % of a unit's life (tools/kv_timing.py, round 2).  Now everything that depends on nothing is
+    // requested first -- slot entries (EPRE rounds of 64), own K / V fragments, global-query rows, scalars, and LAST the
+    // bias image, whose copy loop waits for its own loads and therefore (loads return in order) for all of the above --
+    // then everything that depends on the slot entries: lse / delta gathers and the first Q / dO rows.
+    constexpr int EPRE = 9;                          // 576 slots: W <= 8 in one pass
+    const int tix = glo ? bc.nch + split : ch;
+    const int2* slots = bc.kv_slots + (int64_t)tix * bc.nqs;
+    // (a laundered copy of the lane id for the unit's one-off addresses: derived from `lane` they are invariants of the
+    //  unit loop, and the compiler hoists all of them out of it and then spills them around the step loop)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    int2 e[EPRE];
+#pragma unroll
+    for (int u = 0; u < EPRE; ++u) e[u] = slots[min(u * 64 + ln, bc.nqs - 1)];
+    load_own();
+    const int ngq8 = p.glo_rows ? p.G * 3 * (M / 8) : 0;
+    auto gq_src = [&](int i) {
+      const int c8 = i % (M / 8), wh = (i / (M / 8)) % 3, gq = i / (3 * (M / 8));
+      const T* src = wh == 0 ? (const T*)p.q_g + b * p.q_sb + (int64_t)gq * p.q_st + h * p.q_sh
+                        : wh == 1 ? (const T*)p.do_g + b * p.do_sb + (int64_t)gq * p.do_st + h * p.do_sh
+                                  : (const T*)p.o_g + b * p.o_sb + (int64_t)gq * p.o_st + h * p.o_sh;
+      return src + c8 * 8;
+    };
+    X8 gqr = {};
+    if (ln < ngq8) gqr = *(const X8*)gq_src(ln);
+    const int nchunks = __builtin_amdgcn_readfirstlane(bc.kv_nchunks[tix]);
+    if (gi == 0) {
+      const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
+      for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
+    }
+    if (!valid) break;
+    float l8[EPRE], d8[EPRE];
+#pragma unroll
+    for (int u = 0; u < EPRE; ++u) {
+      const int t = max(e[u].x, 0);
+      l8[u] = lse_bh[t]; d8[u] = dlt_bh[t];
+    }
+#pragma unroll
+    for (int u = 0; u < EPRE; ++u) {
+      const int sl = u * 64 + ln;
+      if (sl < bc.nqs) {
+        const int aq_ = e[u].y & ~3;
+        s_tok[sl] = max(e[u].x, 0); s_aq[sl] = aq_;
+        if (bc.kv_gspare) s_aqg[sl] = (e[u].y & 1) ? aq_ - c.aconst * 4 : (c.guard0 - c.glo0) * 4;
+      }
+    }
+    if (ln < ngq8) *(X8*)(s_gq + ln * 16) = gqr;
+    for (int i = ln + 64; i < ngq8; i += 64) *(X8*)(s_gq + i * 16) = *(const X8*)gq_src(i);      // (G > 5: rare)
+    if (p.glo_rows)
+      for (int gq = 0; gq < p.G; ++gq) {           // (wave-uniform addresses: scalar loads, no address registers)
+        const float l_ = p.lse_g[(int64_t)bh * p.G + gq];
+        const float b0_ = p.g2l0 ? p.g2l0[h * p.G + gq] : 0.f;
+        const float b1_ = p.g2g ? p.g2g[((int64_t)h * p.G + gq) * p.G] : 0.f;
+        if (lane == 0) *(f32x4*)(s_gs + 4 * gq) = (f32x4){l_ * LOG2E, b0_ * LOG2E, b1_ * LOG2E, 0.f};
+      }
+    // slots beyond the first EPRE rounds (W > 8): the old three-phase loop
+    for (int s0 = EPRE * 64; s0 < bc.nqs; s0 += 256) {
+      int2 e4[4];
+      float l4[4], d4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) e4[u] = slots[min(s0 + u * 64 + ln, bc.nqs - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = max(e4[u].x, 0);
+        l4[u] = lse_bh[t]; d4[u] = dlt_bh[t];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int sl = s0 + u * 64 + ln;
+        if (sl < bc.nqs) {
+          const bool real = e4[u].x >= 0;
+          const int aq_ = e4[u].y & ~3;
+          s_tok[sl] = max(e4[u].x, 0); s_aq[sl] = aq_;
+          if (bc.kv_gspare) s_aqg[sl] = (e4[u].y & 1) ? aq_ - c.aconst * 4 : (c.guard0 - c.glo0) * 4;
+          s_lse[sl] = real ? l4[u] * LOG2E : LSE_PAD; s_dlt[sl] = real ? d4[u] : 0.f;
+        }
+      }
+    }
+    if (gi == 0) __syncthreads(); else wave_lds_fence();      // bias image (whole workgroup) and this wave's s_tok visible
+    const int nsteps = (nchunks * W2 + 31) >> 5;
+#else
     if constexpr (MD > 2) load_own();
     // ---- streamed query slot table: the (token, bias address) columns come from the prologue kernel (kv_slots_block: one table per key chunk /
     // global-key split, built once per call); this wave adds the lse / delta of ITS (image, head).  256 slots per
@@ -787,7 +886,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
             const bool real = e[u].x >= 0;
             const int aq_ = e[u].y & ~3;
             s_tok[sl] = max(e[u].x, 0); s_aq[sl] = aq_;
-            if (bc.kv_gspare) s_aqg[sl] = (e[u].y & 1) ? aq_ : aq_ - (c.glo0 - c.guard0) * 4;
+            if (bc.kv_gspare) s_aqg[sl] = (e[u].y & 1) ? aq_ - c.aconst * 4 : (c.guard0 - c.glo0) * 4;
             s_lse[sl] = real ? l4[u] * LOG2E : LSE_PAD; s_dlt[sl] = real ? d4[u] : 0.f;
           }
         }
@@ -796,6 +895,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     const int nsteps = (nchunks * W2 + 31) >> 5;
 
     if constexpr (MD <= 2) load_own();
+#endif
     f32x4 dk[MD][KT], dv[MD][KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
@@ -924,6 +1024,18 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     typedef std::integral_constant<int, PF - 1> S1;
     if (nsteps > 0) load_step(S0{}, 0);
     if constexpr (PF == 2) { if (nsteps > 1) load_step(S1{}, 1); }
+#if VIL_KV_FASTPRO
+    // (the lse / delta gathers were requested before the first Q / dO rows: they land first)
+#pragma unroll
+    for (int u = 0; u < EPRE; ++u) {
+      const int sl = u * 64 + ln;
+      if (sl < bc.nqs) {
+        const bool real = e[u].x >= 0;
+        s_lse[sl] = real ? l8[u] * LOG2E : LSE_PAD; s_dlt[sl] = real ? d8[u] : 0.f;
+      }
+    }
+    wave_lds_fence();
+#endif
     if constexpr (PIPE) {
       // software pipeline over steps (see k_mfma_fwd): score / dP MFMAs of step st+1 issued before the VALU of step st
       f32x4 sA[2][KT], dA[2][KT], sB[2][KT], dB[2][KT];
@@ -1057,6 +1169,8 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     //  before the step loop and carries -- or, one register over the budget, spills -- them through it)
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) asm volatile("" : "+v"(ktok[kt]));
+    int lge = lg;
+    asm volatile("" : "+v"(lge));
     if (!glo) {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
@@ -1069,8 +1183,8 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
               wk[r] = (T)(dk[dt][kt][r] * p.scale);
               wv[r] = (T)dv[dt][kt][r];
             }
-            *(X4*)(dkb + (int64_t)ktok[kt] * p.dk_st + dt * 16 + lg * 4) = wk;
-            *(X4*)(dvb + (int64_t)ktok[kt] * p.dv_st + dt * 16 + lg * 4) = wv;
+            *(X4*)(dkb + (int64_t)ktok[kt] * p.dk_st + dt * 16 + lge * 4) = wk;
+            *(X4*)(dvb + (int64_t)ktok[kt] * p.dv_st + dt * 16 + lge * 4) = wv;
           }
         }
       if (gcol) {              // the global key's dK / dV partial of this chunk (reduced by reduce_glo_block)
