@@ -316,7 +316,7 @@ def test_master_weight_step_captured_without_warmup(dev):
     from vision_longformer_amd.engine import MasterWeightAdamW, train_step, GraphedTrainStep
     from vision_longformer_amd.msvit import MsViT
     from vision_longformer_amd import linear
-    arch = "l1,h1,d32,n1,s1,g1,p4,f4,a0_l2,h2,d64,n1,s0,g1,p2,f8,a0"
+    arch = "l1,h1,d32,n1,s1,g1,p4,f4,a0_l2,h2,d64,n1,s1,g1,p2,f4,a0_l3,h2,d64,n1,s0,g1,p2,f7,a0"
     g = torch.Generator().manual_seed(11)
     xs = [torch.randn(8, 3, 64, 64, generator=g).to(dev) for _ in range(3)]
     ts = [torch.softmax(torch.randn(8, 10, generator=g), -1).to(dev) for _ in range(3)]

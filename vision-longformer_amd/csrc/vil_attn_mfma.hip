@@ -58,6 +58,9 @@ __global__ __launch_bounds__(256) void k_mfma_prep(VilParams p, MfmaCfg c, int r
 #ifndef VIL_FWD_WAVES
 #define VIL_FWD_WAVES 3    // waves per SIMD the register allocation is held to (2: 256, 3: 168, 4: 128 VGPRs)
 #endif
+#ifndef VIL_FWD_FASTPRO
+#define VIL_FWD_FASTPRO 1  // unit prologue as two memory round trips (0: round 4's four, for A/B builds)
+#endif
 constexpr int fwd_waves(int MD) { return MD <= 2 ? VIL_FWD_WAVES : 2; }
 template <typename T, int MD>
 __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, MfmaCfg c) {
@@ -83,11 +86,13 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   const int bh = b * p.H + h;
 
   float* tab = (float*)smem;
+#if !VIL_FWD_FASTPRO
   {
     const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
     for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
   }
   __syncthreads();
+#endif
   const unsigned tab_lds = lds_addr(smem);
 
   char* wbase = smem + (size_t)c.tabsize * 4 + (size_t)wave * c.wave_lds;
@@ -130,8 +135,16 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   const int lgo = lg * 16;
 
   for (int gi = 0; gi < c.gpw; ++gi) {
+#if VIL_FWD_FASTPRO
+    // (a wave whose first unit lies beyond the range still copies its share of the bias image before it leaves)
+    const int unit_ = (wgi * c.gpw + gi) * c.wpw + wave;
+    const bool valid = unit_ < c.units_bh;
+    if (!valid && gi > 0) break;
+    const int unit = valid ? unit_ : 0;
+#else
     const int unit = (wgi * c.gpw + gi) * c.wpw + wave;
     if (unit >= c.units_bh) break;
+#endif
     const int ch = fdiv(unit, c.m_NWP), wp = unit - ch * c.NWP;
     const int cm = fdiv(ch, c.m_my), cn = ch - cm * g.my;
 
@@ -157,9 +170,45 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
         X8 z = {};
         qf[ks][qt] = d0 < M ? *(const X8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
       }
+#if VIL_FWD_FASTPRO
+    // Unit prologue in two memory round trips (round 5; it was four: bias image -> barrier -> slot count -> slot table ->
+    // first K / V): the Q fragments above, the chunk's slot count and EPRE rounds of its slot table are requested with
+    // nothing between them, then the workgroup's bias image, whose copy loop waits for all of them (loads return in
+    // order); the first K / V rows follow.  Table entries beyond the chunk's slot count are never walked.
+    constexpr int EPRE = 7;                          // 448 slots: W <= 7 with one global token in one pass
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                     // (keeps the one-off addresses below out of the unit loop's invariants)
+    const int2* ksrc = c.key_slots + (int64_t)ch * c.NSP;
+    int2 e[EPRE];
+#pragma unroll
+    for (int u = 0; u < EPRE; ++u) e[u] = ksrc[min(u * 64 + ln, c.NSP - 1)];
+    const int nslots = __builtin_amdgcn_readfirstlane(c.key_nslots[ch]);
+    if (gi == 0) {
+      const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
+      for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
+    }
+    if (!valid) break;
+#pragma unroll
+    for (int u = 0; u < EPRE; ++u) {
+      const int sl = u * 64 + ln;
+      if (sl < c.NSP) { s_koff[sl] = e[u].x; s_akey[sl] = e[u].y; }
+    }
+    for (int s0 = EPRE * 64; s0 < nslots; s0 += 512) {      // (W > 7)
+      int2 e8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) e8[u] = ksrc[min(s0 + u * 64 + ln, nslots - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sl = s0 + u * 64 + ln;
+        if (sl < nslots) { s_koff[sl] = e8[u].x; s_akey[sl] = e8[u].y; }
+      }
+    }
+    if (gi == 0) __syncthreads(); else wave_lds_fence();
+#else
     // (the Q fragments above are requested BEFORE the chunk's key-slot table is fetched: a unit's prologue used to be
     //  table -> Q -> first K/V, three dependent round trips; the table's and Q's now overlap)
     const int nslots = load_key_slots(c, ch, lane, s_koff, s_akey);
+#endif
 
     f32x4 o[MD][4], lacc[4];
     float mrow[4];

@@ -198,8 +198,11 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
           qf[ks][qt] = d0 < M ? *(const X8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
           dof[ks][qt] = d0 < M ? *(const X8*)(dob + (int64_t)qtok[qt] * p.do_st + d0) : z;
         }
-      // (requested after this wave's own rows, so that the table's round trip overlaps theirs: see k_mfma_fwd)
-      const int nslots = load_key_slots(c, ch, lane, s_koff, s_akey);
+      // (requested after this wave's own rows, so that the table's round trip overlaps theirs: see k_mfma_fwd; round 5: the
+      //  slot count and the table entries in ONE round trip)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int nslots = load_key_slots_once<7>(c, ch, ln, s_koff, s_akey);
       if (bc.glo_from_dq) {
         // dK / dV of the G global keys as a by-product of this pass: the wave holds the Q / dO rows, lse and delta of its
         // queries; its share of dK_g = scale * sum_q dS[q,g] Q[q] and dV_g = sum_q P[q,g] dO[q] is ~250 VALU instructions
@@ -1065,7 +1068,10 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     // K / V fragments are still in registers: scores by VALU dot products (G is 1..4, no MFMA tile to
     // fill), dK/dV added straight into the accumulators, the unit's share of dq_g / d(bias) to a partial
     // record.  Replaces a separate pass that re-read k, v, dk, dv and rewrote dk, dv.
-    if (p.glo_rows && (!glo || split == 0)) {
+#ifndef VIL_KV_ABL_NOTAIL
+#define VIL_KV_ABL_NOTAIL 0     // timing ablation only (wrong results): skip the global-query tail
+#endif
+    if (!VIL_KV_ABL_NOTAIL && p.glo_rows && (!glo || split == 0)) {
       float* rec = bc.gq_parts + ((int64_t)bh * bc.gq_nrec + (glo ? nown : unit)) * p.G * (M + 4);
       for (int gq = 0; gq < p.G; ++gq) {
         const T* qg = (const T*)(s_gq + gq * 3 * M * 2);
