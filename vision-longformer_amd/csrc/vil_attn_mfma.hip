@@ -415,7 +415,10 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   c.NSP = (c.NS + 31) & ~31;
   c.units_bh = g.mx * g.my * c.NWP;
   c.wave_lds = ((c.NSP * 8 + ((VIL_FWD_PIPE && d->M <= 32) ? 2 : 1) * 32 * d->M * 2 + 15) / 16) * 16;   // slot tables + V tile(s) (PIPE: two)
-  c.wpw = 4;
+#ifndef VIL_FWD_WPW
+#define VIL_FWD_WPW 4
+#endif
+  c.wpw = VIL_FWD_WPW;
   while (c.wpw > 1 && (size_t)c.tabsize * 8 + (size_t)c.wpw * c.wave_lds > 160 * 1024) c.wpw >>= 1;
   const int groups = (c.units_bh + c.wpw - 1) / c.wpw;
 #ifndef VIL_FWD_WGS

@@ -509,8 +509,8 @@ __device__ __forceinline__ void reduce_hist_block(const VilParams& p, const Mfma
 #ifndef VIL_KV_WAVES
 #define VIL_KV_WAVES 2     // waves per SIMD of the head_dim 32 instantiation
 #endif
-#ifndef VIL_KV_FASTPRO
-#define VIL_KV_FASTPRO 1   // unit prologue as two memory round trips instead of seven (0: the round-4 order, for A/B builds)
+#ifndef VIL_KV_ABL_NOTAIL
+#define VIL_KV_ABL_NOTAIL 0     // timing ablation only (wrong results): skip the global queries' dq tail
 #endif
 // Streamed-query slot tables of the dK/dV pass.  Which query rows a key chunk is attended by, and the bias-table address
 // term of each, depend on the chunk position only -- not on the (image, head) -- so one wave per key
@@ -585,6 +585,19 @@ __device__ __forceinline__ void kv_slots_block(const VilParams& p, const MfmaCfg
     }
   }
   wave_lds_fence();
+  // vil_attn_bwd_full: the G global QUERY rows close the stream -- the last G slots of its last 32-slot step (fixed rows
+  // 31 - g, which the dK/dV waves rely on).  token = -(2 + g); address term: local-key columns land in region g2l0[g]
+  // whatever their key term (<= kv_span), an owner unit's global-key columns (lane gk: -(glo0 + gk * gsz)) in g2g[g][gk].
+  // Only the first owner unit streams them (the pair (global query, global key) is counted once).
+  if (p.glo_rows && (!glo || split == 0)) {
+    const int last = (((nchunks * W2 + p.G + 31) >> 5) << 5) - 1;
+    if (lane < p.G) {
+      s_tok[last - lane] = -(2 + lane);
+      s_aq[last - lane] = glo ? (c.tabsize + (p.G + lane * p.G) * c.gsz - c.glo0) * 4
+                              : (c.tabsize + lane * c.gsz + bc.kv_span) * 4;
+    }
+    wave_lds_fence();
+  }
   int2* out = bc.kv_slots + (int64_t)t * bc.nqs;
   for (int s = lane; s < bc.nqs; s += 64) out[s] = make_int2(s_tok[s], s_aq[s]);
   if (lane == 0) bc.kv_nchunks[t] = nchunks;
@@ -645,25 +658,19 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   const int wgi = fdiv(rem_, c.m_H), h = rem_ - wgi * p.H;
   const int bh = b * p.H + h;
   const unsigned tab_lds = lds_addr(smem);
+  const int Gq = p.glo_rows ? p.G : 0;            // global QUERY rows riding in the stream (vil_attn_bwd_full)
+  const int tabx = c.tabsize + bc.kv_xsize;       // bias image + the global queries' constant regions
 
   float* tab = (float*)smem;
-#if !VIL_KV_FASTPRO
-  {
-    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
-    for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
-  }
-  __syncthreads();
-#endif
-
-  char* wbase = smem + (size_t)c.tabsize * 4 + (size_t)wave * bc.kv_wave_lds;
-  int* s_tok = (int*)wbase;                       // [nqs] token index of each streamed query slot (Q / dO row)
-  int* s_aq = s_tok + bc.nqs;                     // [nqs] bias-table address term (bytes)
-  float* s_lse = (float*)(s_aq + bc.nqs);         // [nqs] lse * log2(e)   (+big for padding slots)
-  float* s_dlt = s_lse + bc.nqs;                  // [nqs] delta
-  char* s_q = (char*)(s_dlt + bc.nqs);            // [32][M] bf16 Q tile, then the [32][M] dO tile (PIPE: two such pairs)
-  char* s_gq = s_q + (PIPE ? 4 : 2) * 32 * M * 2;   // [G][3][M] bf16: q, dO, out rows of the global queries
-  float* s_gs = (float*)(s_gq + p.G * 3 * M * 2);   // [G][4] lse_g * log2e, g2l[0] * log2e, g2g[..][0] * log2e of the global queries (staged at unit start)
-  int* s_aqg = (int*)(s_gs + 4 * p.G);            // [nqs] (kv_gspare) address term of the GLOBAL key's column, relative to its g2l region:
+  char* wbase = smem + (size_t)tabx * 4 + (size_t)wave * bc.kv_wave_lds;
+  const int nqsa = max((bc.nqs + 63) & ~63, 7 * 64);   // (arrays hold whole rounds of 64 slots, at least the EPRE rounds the prologue fills without bounds)
+  int* s_tok = (int*)wbase;                       // [nqsa] row index of each streamed query slot in the Q / dO descriptors
+  int* s_aq = s_tok + nqsa;                       // [nqsa] bias-table address term (bytes)
+  float* s_lse = (float*)(s_aq + nqsa);           // [nqsa] lse * log2(e)   (+big for padding slots)
+  float* s_dlt = s_lse + nqsa;                    // [nqsa] delta
+  char* s_q = (char*)(s_dlt + nqsa);              // [32][M] bf16 Q tile, then the [32][M] dO tile (PIPE: two such pairs)
+  float* s_gd = (float*)(s_q + (PIPE ? 4 : 2) * 32 * M * 2);   // [1 or 4][64][4] dS of the step's last query rows 31 - g (the global queries' in the last step)
+  int* s_aqg = (int*)(s_gd + (p.G > 1 ? 4 : 1) * 64 * 4);      // [nqs] (kv_gspare) address term of the GLOBAL key's column, relative to its g2l region:
                                                   //       the query's position in the own chunk ((x * P + y) * 4 -- the region is as wide
                                                   //       as that range, like the forward's global key slots), or, for every slot of another
                                                   //       chunk, the distance to the all-masked guard region
@@ -694,8 +701,10 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       row_off[hf][ks] = row2 * (M * 2) + (((ks * 32 + lg * 8) * 2) ^ tile_swz<MD>(row2));
   }
 
-  const __amdgpu_buffer_rsrc_t qrs = make_rsrc((const T*)p.q + b * p.q_sb + h * p.q_sh);
-  const __amdgpu_buffer_rsrc_t drs = make_rsrc((const T*)p.dout + b * p.do_sb + h * p.do_sh);
+  // With global-query rows the Q / dO descriptors start at token 0 of the all-token tensors (the G global rows; the local
+  // rows follow them: vil_attn_bwd_full), and a streamed slot's row index is G + its local token, or g.
+  const __amdgpu_buffer_rsrc_t qrs = make_rsrc((Gq ? (const T*)p.q_g : (const T*)p.q) + b * p.q_sb + h * p.q_sh);
+  const __amdgpu_buffer_rsrc_t drs = make_rsrc((Gq ? (const T*)p.do_g : (const T*)p.dout) + b * p.do_sb + h * p.do_sh);
   const T* kb = (const T*)p.k + b * p.k_sb + h * p.k_sh;
   const T* vb = (const T*)p.v + b * p.v_sb + h * p.v_sh;
   T* dkb = (T*)p.dk + b * p.dk_sb + h * p.dk_sh;
@@ -703,20 +712,16 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
   const float* lse_bh = p.lse + (int64_t)bh * Nloc;
   const float* dlt_bh = p.delta + (int64_t)bh * Nloc;
   for (int gi = 0; gi < bc.kv_gpw; ++gi) {
-#if VIL_KV_FASTPRO
     // A wave whose first unit lies beyond the range still copies its share of the bias image before it leaves
     const int unit_ = (wgi * bc.kv_gpw + gi) * bc.kv_wpw + wave;
     const bool valid = unit_ < bc.units_kv_bh;
     if (!valid && gi > 0) break;
     const int unit = valid ? unit_ : 0;
-#else
-    const int unit = (wgi * bc.kv_gpw + gi) * bc.kv_wpw + wave;
-    if (unit >= bc.units_kv_bh) break;
-#endif
     const bool glo = unit >= nown;                 // global-key owner unit
     const int split = unit - nown;
     const int ch = glo ? 0 : fdiv(unit, bc.m_kv_NWP), wp = glo ? 0 : unit - ch * bc.kv_NWP;
     const int km = fdiv(ch, c.m_my), kn = ch - km * g.my;
+    const int Gu = (!glo || split == 0) ? Gq : 0;  // global queries at the end of THIS unit's stream
 
     // ---- this lane's key slots: column j of key-tile kt is key (x, y = KT*hq + KT-1 - kt)
     const int jj = wp * 16 + lj;
@@ -744,10 +749,6 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
         if (gcol && kt == 0) ktok[kt] = 0;            // (kreal stays false: the local epilogue skips it)
       }
     }
-    // The K / V fragments of these slots: at head_dim 64 they are requested HERE, so that their round trip runs under
-    // the slot-table -> lse / delta gather chain below (28x28 stage: dK/dV -1.5 %, dQ -3 %, forward -2 % from the same
-    // reordering); at head_dim <= 32 that measured +1 % on this pass (four key tiles: 32 more registers live across the
-    // chain), so there they are requested behind it as before
     X8 kfb[MK][KT], vfb[MK][KT];
     auto load_own = [&]() {
 #pragma unroll
@@ -760,14 +761,15 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           vfb[ks][kt] = d0 < M ? *(const X8*)(vb + (int64_t)ktok[kt] * p.v_st + d0) : z;
         }
     };
-#if VIL_KV_FASTPRO
     // ---- unit prologue in TWO memory round trips (round 5).  It used to be a chain of seven: bias image -> barrier ->
     // global-query rows -> chunk count -> slot entries -> lse / delta gathers (twice at 448 slots) -> own K / V -> first
     // Q / dO rows, ~12-15 % of a unit's life (tools/kv_timing.py, round 2).  Now everything that depends on nothing is
-    // requested first -- slot entries (EPRE rounds of 64), own K / V fragments, global-query rows, scalars, and LAST the
-    // bias image, whose copy loop waits for its own loads and therefore (loads return in order) for all of the above --
-    // then everything that depends on the slot entries: lse / delta gathers and the first Q / dO rows.
-    constexpr int EPRE = 9;                          // 576 slots: W <= 8 in one pass
+    // requested first -- slot entries (EPRE rounds of 64), own K / V fragments, the chunk count, the global queries'
+    // scalars, and LAST the bias image, whose copy loop waits for its own loads and therefore (loads return in order) for
+    // all of the above -- then everything that depends on the slot entries: lse / delta gathers and the first Q / dO rows.
+    // Same-box A/B at ViL-Small stage 1: 372 -> 358 us.
+    constexpr int EPRE = 7;                          // 448 slots: W <= 7 (+ global rows) in one straight-line pass -- no branch, so
+                                                     // that the compiler's counter waits stay where the data is first used
     const int tix = glo ? bc.nch + split : ch;
     const int2* slots = bc.kv_slots + (int64_t)tix * bc.nqs;
     // (a laundered copy of the lane id for the unit's one-off addresses: derived from `lane` they are invariants of the
@@ -778,127 +780,70 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
 #pragma unroll
     for (int u = 0; u < EPRE; ++u) e[u] = slots[min(u * 64 + ln, bc.nqs - 1)];
     load_own();
-    const int ngq8 = p.glo_rows ? p.G * 3 * (M / 8) : 0;
-    auto gq_src = [&](int i) {
-      const int c8 = i % (M / 8), wh = (i / (M / 8)) % 3, gq = i / (3 * (M / 8));
-      const T* src = wh == 0 ? (const T*)p.q_g + b * p.q_sb + (int64_t)gq * p.q_st + h * p.q_sh
-                        : wh == 1 ? (const T*)p.do_g + b * p.do_sb + (int64_t)gq * p.do_st + h * p.do_sh
-                                  : (const T*)p.o_g + b * p.o_sb + (int64_t)gq * p.o_st + h * p.o_sh;
-      return src + c8 * 8;
-    };
-    X8 gqr = {};
-    if (ln < ngq8) gqr = *(const X8*)gq_src(ln);
     const int nchunks = __builtin_amdgcn_readfirstlane(bc.kv_nchunks[tix]);
     if (gi == 0) {
+      // the global queries' constant regions behind the image: [G x gsz: g2l[0][h][g] / scale | G*G x gsz: g2g[h][gq][gk] / scale]
+      // (scalar loads; placed before the image copy so that they travel with everything else)
+      if (bc.kv_xsize) {
+        const float inv = 1.0f / p.scale;
+        for (int r = 0; r < p.G + p.G * p.G; ++r) {
+          float v = 0.f;
+          if (r < p.G) { if (p.g2l0) v = p.g2l0[h * p.G + r]; }
+          else if (p.g2g) v = p.g2g[(int64_t)h * p.G * p.G + (r - p.G)];
+          for (int i = tid; i < c.gsz; i += blockDim.x) tab[c.tabsize + r * c.gsz + i] = v * inv;
+        }
+      }
+      // the bias image, four 16-byte pieces per thread in flight (the plain copy loop waited for every piece in turn)
       const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
-      for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
+      const int n4 = c.tabsize >> 2;
+      const int nthr = blockDim.x;
+      for (int i0 = tid; i0 < n4; i0 += 4 * nthr) {
+        f32x4 t4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t4[u] = src[min(i0 + u * nthr, n4 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + u * nthr < n4) ((f32x4*)tab)[i0 + u * nthr] = t4[u];
+      }
     }
     if (!valid) break;
+    // LDS copy of the slot table -- row index into the Q / dO descriptors, address terms (the global key's column reads
+    // s_aqg: its g2l region for the own chunk's queries, the g2g region for a global query in chunk 0's unit, the guard
+    // region for everything else) -- and, in the same sweep, the request for the slot's {lse, delta}: the local token's,
+    // or, for a negative token (-1: padding, -(2 + g): global query g), entry G / g of this (image, head)'s xstat row.
+    // Nothing is conditional on the slot kind after this point, so no lane masks are carried to the stores below.
+    const float* xs_bh = p.xstat + (int64_t)bh * (p.G + 1) * 2;
+    auto put_slot = [&](int sl, int2 ev, float& l_, float& d_) {
+      const int aq_ = ev.y & ~3;
+      const bool neg = ev.x < 0, gq_slot = ev.x <= -2;
+      const int xi = gq_slot ? -2 - ev.x : p.G;
+      const float* lp = neg ? xs_bh + 2 * xi : lse_bh + ev.x;
+      const float* dp = neg ? xs_bh + 2 * xi + 1 : dlt_bh + ev.x;
+      l_ = *lp; d_ = *dp;
+      s_tok[sl] = gq_slot ? xi : max(ev.x, 0) + Gq;
+      s_aq[sl] = aq_;
+      if (bc.kv_gspare)
+        s_aqg[sl] = gq_slot ? ((ch == 0 ? c.tabsize + p.G * c.gsz : c.guard0) - c.glo0) * 4
+                            : ((ev.y & 1) ? aq_ - c.aconst * 4 : (c.guard0 - c.glo0) * 4);
+    };
     float l8[EPRE], d8[EPRE];
 #pragma unroll
-    for (int u = 0; u < EPRE; ++u) {
-      const int t = max(e[u].x, 0);
-      l8[u] = lse_bh[t]; d8[u] = dlt_bh[t];
-    }
-#pragma unroll
-    for (int u = 0; u < EPRE; ++u) {
-      const int sl = u * 64 + ln;
-      if (sl < bc.nqs) {
-        const int aq_ = e[u].y & ~3;
-        s_tok[sl] = max(e[u].x, 0); s_aq[sl] = aq_;
-        if (bc.kv_gspare) s_aqg[sl] = (e[u].y & 1) ? aq_ - c.aconst * 4 : (c.guard0 - c.glo0) * 4;
-      }
-    }
-    if (ln < ngq8) *(X8*)(s_gq + ln * 16) = gqr;
-    for (int i = ln + 64; i < ngq8; i += 64) *(X8*)(s_gq + i * 16) = *(const X8*)gq_src(i);      // (G > 5: rare)
-    if (p.glo_rows)
-      for (int gq = 0; gq < p.G; ++gq) {           // (wave-uniform addresses: scalar loads, no address registers)
-        const float l_ = p.lse_g[(int64_t)bh * p.G + gq];
-        const float b0_ = p.g2l0 ? p.g2l0[h * p.G + gq] : 0.f;
-        const float b1_ = p.g2g ? p.g2g[((int64_t)h * p.G + gq) * p.G] : 0.f;
-        if (lane == 0) *(f32x4*)(s_gs + 4 * gq) = (f32x4){l_ * LOG2E, b0_ * LOG2E, b1_ * LOG2E, 0.f};
-      }
-    // slots beyond the first EPRE rounds (W > 8): the old three-phase loop
+    for (int u = 0; u < EPRE; ++u) put_slot(u * 64 + ln, e[u], l8[u], d8[u]);
+    // slots beyond the first EPRE rounds (W > 8): three phases per four rounds
     for (int s0 = EPRE * 64; s0 < bc.nqs; s0 += 256) {
       int2 e4[4];
       float l4[4], d4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) e4[u] = slots[min(s0 + u * 64 + ln, bc.nqs - 1)];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int t = max(e4[u].x, 0);
-        l4[u] = lse_bh[t]; d4[u] = dlt_bh[t];
-      }
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u * 64 < bc.nqs) put_slot(s0 + u * 64 + ln, e4[u], l4[u], d4[u]);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int sl = s0 + u * 64 + ln;
-        if (sl < bc.nqs) {
-          const bool real = e4[u].x >= 0;
-          const int aq_ = e4[u].y & ~3;
-          s_tok[sl] = max(e4[u].x, 0); s_aq[sl] = aq_;
-          if (bc.kv_gspare) s_aqg[sl] = (e4[u].y & 1) ? aq_ - c.aconst * 4 : (c.guard0 - c.glo0) * 4;
-          s_lse[sl] = real ? l4[u] * LOG2E : LSE_PAD; s_dlt[sl] = real ? d4[u] : 0.f;
-        }
-      }
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u * 64 < bc.nqs) { s_lse[s0 + u * 64 + ln] = l4[u] * LOG2E; s_dlt[s0 + u * 64 + ln] = d4[u]; }
     }
     if (gi == 0) __syncthreads(); else wave_lds_fence();      // bias image (whole workgroup) and this wave's s_tok visible
-    const int nsteps = (nchunks * W2 + 31) >> 5;
-#else
-    if constexpr (MD > 2) load_own();
-    // ---- streamed query slot table: the (token, bias address) columns come from the prologue kernel (kv_slots_block: one table per key chunk /
-    // global-key split, built once per call); this wave adds the lse / delta of ITS (image, head).  256 slots per
-    // round: table loads, then all gathers, then the LDS stores -- nothing waits on a single round trip.
-    if (p.glo_rows) {       // staged now so that the unit's tail does not wait on HBM with one wave per SIMD
-      for (int i = lane; i < p.G * 3 * (M / 8); i += 64) {
-        const int c8 = i % (M / 8), wh = (i / (M / 8)) % 3, gq = i / (3 * (M / 8));
-        const T* src = wh == 0 ? (const T*)p.q_g + b * p.q_sb + (int64_t)gq * p.q_st + h * p.q_sh
-                          : wh == 1 ? (const T*)p.do_g + b * p.do_sb + (int64_t)gq * p.do_st + h * p.do_sh
-                                    : (const T*)p.o_g + b * p.o_sb + (int64_t)gq * p.o_st + h * p.o_sh;
-        *(X8*)(s_gq + i * 16) = *(const X8*)(src + c8 * 8);
-      }
-      // ... and the three scalars per global query the tail needs (they used to be loaded THERE: a dependent HBM / L2
-      // round trip at the end of every unit, with nothing left to hide it)
-      for (int gq = 0; gq < p.G; ++gq) {           // (wave-uniform addresses: scalar loads, no address registers)
-        const float l_ = p.lse_g[(int64_t)bh * p.G + gq];
-        const float b0_ = p.g2l0 ? p.g2l0[h * p.G + gq] : 0.f;
-        const float b1_ = p.g2g ? p.g2g[((int64_t)h * p.G + gq) * p.G] : 0.f;
-        if (lane == 0) *(f32x4*)(s_gs + 4 * gq) = (f32x4){l_ * LOG2E, b0_ * LOG2E, b1_ * LOG2E, 0.f};
-      }
-    }
-    const int tix = glo ? bc.nch + split : ch;
-    const int nchunks = __builtin_amdgcn_readfirstlane(bc.kv_nchunks[tix]);
-    {
-      const int2* slots = bc.kv_slots + (int64_t)tix * bc.nqs;
-      for (int s0 = 0; s0 < bc.nqs; s0 += 256) {
-        int2 e[4];
-        float l4[4], d4[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int sl = s0 + u * 64 + lane;
-          e[u] = slots[min(sl, bc.nqs - 1)];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int t = max(e[u].x, 0);
-          l4[u] = lse_bh[t]; d4[u] = dlt_bh[t];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int sl = s0 + u * 64 + lane;
-          if (sl < bc.nqs) {
-            const bool real = e[u].x >= 0;
-            const int aq_ = e[u].y & ~3;
-            s_tok[sl] = max(e[u].x, 0); s_aq[sl] = aq_;
-            if (bc.kv_gspare) s_aqg[sl] = (e[u].y & 1) ? aq_ - c.aconst * 4 : (c.guard0 - c.glo0) * 4;
-            s_lse[sl] = real ? l4[u] * LOG2E : LSE_PAD; s_dlt[sl] = real ? d4[u] : 0.f;
-          }
-        }
-      }
-    }
-    const int nsteps = (nchunks * W2 + 31) >> 5;
-
-    if constexpr (MD <= 2) load_own();
-#endif
+    const int nsteps = (nchunks * W2 + Gu + 31) >> 5;
     f32x4 dk[MD][KT], dv[MD][KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
@@ -981,6 +926,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       const char* sq = s_q + (PIPE ? (st & 1) * 2 * TILE : 0);
       const char* sd = sq + TILE;
       u32x4 pbw[KT], dsw[KT];       // the 8 packed 16-bit operand values of each key tile, as dwords (2 per query half)
+      f32x4 gds[4] = {};            // dS of query rows 28 .. 31 of the step, [row - 28][key tile]
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int sb = st * 32 + hf * 16 + lg * 4;
@@ -995,10 +941,20 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           for (int h2 = 0; h2 < 2; ++h2) {
             const f32x2 p2 = {pr[2 * h2], pr[2 * h2 + 1]};
             const f32x2 d2 = {dpacc[hf][kt][2 * h2], dpacc[hf][kt][2 * h2 + 1]};
+            const f32x2 ds2 = p2 * d2;
             pbw[kt][hf * 2 + h2] = pack2<T>(p2);
-            dsw[kt][hf * 2 + h2] = pack2<T>(p2 * d2);
+            dsw[kt][hf * 2 + h2] = pack2<T>(ds2);
+            if (hf == 1) { gds[2 * h2][kt] = ds2[0]; gds[2 * h2 + 1][kt] = ds2[1]; }
           }
         }
+      }
+      // dS (fp32) of the step's last query rows, per key column, to the wave's LDS: in the LAST step rows 31 - g are the
+      // global queries (kv_slots_block), whose dq = sum_k dS K the tail forms from them.  One 16-byte store per step for
+      // G == 1 (every step: no branch on the step index, no registers carried through the loop).
+      *(f32x4*)(s_gd + lane * 4) = gds[3];
+      if (Gq > 1) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) *(f32x4*)(s_gd + ((3 - r) * 64 + lane) * 4) = gds[r];
       }
       X8 pb[KT], dsb[KT];
 #pragma unroll
@@ -1027,18 +983,10 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     typedef std::integral_constant<int, PF - 1> S1;
     if (nsteps > 0) load_step(S0{}, 0);
     if constexpr (PF == 2) { if (nsteps > 1) load_step(S1{}, 1); }
-#if VIL_KV_FASTPRO
     // (the lse / delta gathers were requested before the first Q / dO rows: they land first)
 #pragma unroll
-    for (int u = 0; u < EPRE; ++u) {
-      const int sl = u * 64 + ln;
-      if (sl < bc.nqs) {
-        const bool real = e[u].x >= 0;
-        s_lse[sl] = real ? l8[u] * LOG2E : LSE_PAD; s_dlt[sl] = real ? d8[u] : 0.f;
-      }
-    }
+    for (int u = 0; u < EPRE; ++u) { s_lse[u * 64 + ln] = l8[u] * LOG2E; s_dlt[u * 64 + ln] = d8[u]; }
     wave_lds_fence();
-#endif
     if constexpr (PIPE) {
       // software pipeline over steps (see k_mfma_fwd): score / dP MFMAs of step st+1 issued before the VALU of step st
       f32x4 sA[2][KT], dA[2][KT], sB[2][KT], dB[2][KT];
@@ -1064,57 +1012,22 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
       }
     }
 
-    // ---- global-token QUERY rows (vil_attn_bwd_full): G extra queries that attend every key.  The unit's
-    // K / V fragments are still in registers: scores by VALU dot products (G is 1..4, no MFMA tile to
-    // fill), dK/dV added straight into the accumulators, the unit's share of dq_g / d(bias) to a partial
-    // record.  Replaces a separate pass that re-read k, v, dk, dv and rewrote dk, dv.
-#ifndef VIL_KV_ABL_NOTAIL
-#define VIL_KV_ABL_NOTAIL 0     // timing ablation only (wrong results): skip the global-query tail
-#endif
-    if (!VIL_KV_ABL_NOTAIL && p.glo_rows && (!glo || split == 0)) {
+    // ---- global-token QUERY rows (vil_attn_bwd_full).  Round 5: they are the last G slots of the unit's query stream, so
+    // their P / dS went through the step loop's MFMAs like every other query's and dK / dV already hold their share (the
+    // round-4 tail staged their q / dO / out rows, formed the scores by VALU dot products and ran 16 nearly empty MFMAs:
+    // 8-11 % of the pass by timing ablation, profiles/r05_attn_ab.txt).  What is left: the unit's share of
+    // dq_g = sum_k dS[g, k] K[k] and of d(g2l[0]) = sum_k dS[g, k] over its real local keys, from the dS row the last step
+    // left in LDS, to a partial record; d(g2g) from the global key's column.
+    if (!VIL_KV_ABL_NOTAIL && Gu) {
       float* rec = bc.gq_parts + ((int64_t)bh * bc.gq_nrec + (glo ? nown : unit)) * p.G * (M + 4);
+      const bool gpair = gcol && ch == 0;       // kv_gspare: the (global query, global key) pair is chunk 0's unit's
       for (int gq = 0; gq < p.G; ++gq) {
-        const T* qg = (const T*)(s_gq + gq * 3 * M * 2);
-        const T* dg = qg + M;
-        const T* og = dg + M;
-        X8 qf[MK], df[MK];
-        float dl = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < MK; ++ks) {
-          const int d0 = ks * 32 + lg * 8;
-          X8 z = {};
-          qf[ks] = z; df[ks] = z;
-          if (d0 < M) {
-            qf[ks] = *(const X8*)(qg + d0); df[ks] = *(const X8*)(dg + d0);
-            const X8 of = *(const X8*)(og + d0);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dl = __builtin_fmaf((float)df[ks][e], (float)of[e], dl);
-          }
-        }
-        dl += __shfl_xor(dl, 16, 64); dl += __shfl_xor(dl, 32, 64);
-        const float lg2 = s_gs[4 * gq];
-        float bias = 0.f;
-        if (glo) { if (p.g2g) bias = p.g2g[((int64_t)h * p.G + gq) * p.G + min(lj, p.G - 1)] * LOG2E; }
-        else bias = s_gs[4 * gq + 1];
-        // kv_gspare: the (global query, global key) pair is counted by chunk 0's unit alone, with the g2g bias
-        const bool gpair = gcol && ch == 0;
-        // (staged so that few values are live at once: this kernel has no registers to spare)
-        float pr[KT], ds[KT], bsum = 0.f;
+        const f32x4 d4 = *(const f32x4*)(s_gd + (gq * 64 + 48 + lj) * 4);          // row 31 - gq: written by lane group 3
+        float ds[KT], bsum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-          float sc = 0.f, dp = 0.f;
-#pragma unroll
-          for (int ks = 0; ks < MK; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              sc = __builtin_fmaf((float)qf[ks][e], (float)kfb[ks][kt][e], sc);
-              dp = __builtin_fmaf((float)df[ks][e], (float)vfb[ks][kt][e], dp);
-            }
-          sc += __shfl_xor(sc, 16, 64); sc += __shfl_xor(sc, 32, 64);
-          dp += __shfl_xor(dp, 16, 64); dp += __shfl_xor(dp, 32, 64);
           const bool gk_ = kt == 0 && gpair;
-          pr[kt] = (kreal[kt] || gk_) ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc, c1, (gk_ ? s_gs[4 * gq + 2] : bias) - lg2)) : 0.f;
-          ds[kt] = pr[kt] * (dp - dl);
+          ds[kt] = (kreal[kt] || gk_) ? d4[kt] : 0.f;      // (junk key columns hold finite garbage: never summed)
           if (!glo && !gk_) bsum += ds[kt];
         }
         if (glo && kreal[0] && lg == 0 && p.dg2g) atomicAdd(&p.dg2g[((int64_t)h * p.G + gq) * p.G + lj], ds[0]);
@@ -1147,25 +1060,6 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
             }
           }
           if (lg == 0) rec[gq * (M + 4) + M] = bsum;
-        }
-        // dK/dV of the unit's keys: on the MFMA like every other query (the accumulators never leave
-        // their registers): the global query is query 0 of an otherwise empty 32-query step
-        X8 pb0[KT], dsb0[KT];
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-          X8 z = {};
-          pb0[kt] = z; dsb0[kt] = z;
-          if (lg == 0) { pb0[kt][0] = (T)pr[kt]; dsb0[kt][0] = (T)ds[kt]; }
-        }
-#pragma unroll
-        for (int dt = 0; dt < MD; ++dt) {
-          X8 qt0 = {}, dt0 = {};
-          if (lg == 0) { qt0[0] = qg[dt * 16 + lj]; dt0[0] = dg[dt * 16 + lj]; }
-#pragma unroll
-          for (int kt = 0; kt < KT; ++kt) {
-            dv[dt][kt] = mfma16(dt0, pb0[kt], dv[dt][kt]);
-            dk[dt][kt] = mfma16(qt0, dsb0[kt], dk[dt][kt]);
-          }
         }
       }
     }
@@ -1358,6 +1252,18 @@ __global__ void k_mfma_delta(VilParams p, unsigned* norm2) {
     if (tok < p.G && sub == 0) {        // the G global rows of v
       const T* vg = (const T*)p.v + b * p.v_sb + (int64_t)tok * p.v_st + h * p.v_sh;
       for (int d = 0; d < M; ++d) n_vg = __builtin_fmaf((float)vg[d], (float)vg[d], n_vg);
+      if (p.glo_rows) {                 // ... and {lse, rowsum(dO * O)} of global QUERY row `tok` (vil_attn_bwd_full)
+        const T* og = (const T*)p.o_g + b * p.o_sb + (int64_t)tok * p.o_st + h * p.o_sh;
+        const T* dg = (const T*)p.do_g + b * p.do_sb + (int64_t)tok * p.do_st + h * p.do_sh;
+        float sg = 0.f;
+        for (int d = 0; d < M; ++d) sg = __builtin_fmaf((float)og[d], (float)dg[d], sg);
+        float* xs = p.xstat + ((int64_t)bh * (p.G + 1) + tok) * 2;
+        xs[0] = p.lse_g[(int64_t)bh * p.G + tok]; xs[1] = sg;
+      }
+    }
+    if (tok == 0 && sub == 0) {         // what a padding slot of the dK/dV pass reads: lse = +big (P = 0), delta = 0
+      float* xs = p.xstat + ((int64_t)bh * (p.G + 1) + p.G) * 2;
+      xs[0] = LSE_PAD / LOG2E; xs[1] = 0.f;
     }
   }
 #pragma unroll
@@ -1432,12 +1338,20 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   bc.gq_nrec = bc.nch * bc.kv_NWP + (bc.kv_gspare ? 0 : 1);
   // streamed query slots: an own-key unit sees <= nact query chunks, a global-key unit its share of all chunks
   const int qch = (d->G > 0 && !bc.glo_from_dq && bc.nsplit > 0) ? (bc.nch + bc.nsplit - 1) / bc.nsplit : 0;
-  bc.nqs = ((qch > g.nact ? qch : g.nact) * g.W2 + 31) & ~31;
+  const int gq_rows = (d->G >= 1 && d->G <= 4) ? d->G : 0;      // vil_attn_bwd_full's global-query rows close the stream (G <= 4)
+  bc.nqs = ((qch > g.nact ? qch : g.nact) * g.W2 + gq_rows + 31) & ~31;
+  bc.kv_xsize = gq_rows ? (gq_rows + gq_rows * gq_rows) * c.gsz : 0;
+  bc.kv_span = (g.W - 1) * c.P + bc.kv_KT * bc.kv_HQ - 1;
   // slot tables + Q/dO tiles + the q / dO / out rows of the G global queries (vil_attn_bwd_full)
   const int kv_tiles = (VIL_KV_PIPE && d->M == 32 && bc.kv_KT == 2) ? 4 : 2;       // Q + dO tiles (pipelined kernel: two pairs)
-  bc.kv_wave_lds = ((bc.nqs * 16 + kv_tiles * 32 * d->M * 2 + d->G * 3 * d->M * 2 + d->G * 16 + (bc.kv_gspare ? bc.nqs * 4 : 0) + 15) / 16) * 16;
-  bc.kv_wpw = 4;
-  while (bc.kv_wpw > 1 && (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
+  // slot tables (token, address term, lse, delta) + Q / dO tiles + the dS rows of the global queries + (kv_gspare) the global key's address terms
+  const int nqsa = ((bc.nqs + 63) & ~63) > 7 * 64 ? ((bc.nqs + 63) & ~63) : 7 * 64;      // (k_mfma_bwd_dkdv: EPRE rounds filled without bounds)
+  bc.kv_wave_lds = ((nqsa * 16 + kv_tiles * 32 * d->M * 2 + (d->G > 1 ? 4 : 1) * 1024 + (bc.kv_gspare ? nqsa * 4 : 0) + 15) / 16) * 16;
+#ifndef VIL_KV_WPW
+#define VIL_KV_WPW 4
+#endif
+  bc.kv_wpw = VIL_KV_WPW;
+  while (bc.kv_wpw > 1 && (size_t)(c.tabsize + bc.kv_xsize) * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
   const int groups = (bc.units_kv_bh + bc.kv_wpw - 1) / bc.kv_wpw;
 #ifndef VIL_KV_WGS
 #define VIL_KV_WGS 8192
@@ -1488,7 +1402,7 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
 }
 
 static size_t dq_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.tabsize * 16 + (size_t)bc.dq_wpw * bc.dq_wave_lds; }   // table, 32-bit bins, 64-bit bins, waves
-static size_t kv_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)c.tabsize * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds; }
+static size_t kv_lds(const MfmaCfg& c, const BwdCfg& bc) { return (size_t)(c.tabsize + bc.kv_xsize) * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds; }
 
 int vil_mfma_bwd_supported(const VilAttnDesc* d) {
   if ((d->do_st | d->do_sb | d->do_sh) & 7) return VIL_E_ALIGN;
@@ -1508,7 +1422,7 @@ int vil_mfma_bwd_supported(const VilAttnDesc* d) {
 static void bwd_ws_layout(const VilAttnDesc* d, const MfmaCfg& c, const BwdCfg& bc, size_t off[9]) {
   const size_t rows = (size_t)d->B * d->H * d->nx * d->ny;
   off[0] = 0;
-  off[1] = ((rows + 3) & ~(size_t)3) + 32 * VIL_NORM_SLOTS;      // + norm-maxima slots and the histogram scale
+  off[1] = ((rows + 3) & ~(size_t)3) + (((size_t)d->B * d->H * (d->G + 1) * 2 + 3) & ~(size_t)3) + 32 * VIL_NORM_SLOTS;   // + xstat, norm-maxima slots and the histogram scale
   off[2] = off[1] + (size_t)d->H * c.tabsize;
   off[3] = off[2] + (size_t)bc.dq_nwg * c.tabsize * 2;                              // 64-bit histogram records
   off[4] = off[3] + (size_t)d->B * d->H * bc.glo_nrec * d->G * 2 * d->M;
@@ -1535,6 +1449,7 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     return VIL_E_ALIGN;
   if (((uintptr_t)p.dq | (uintptr_t)p.dk | (uintptr_t)p.dv) & 7) return VIL_E_ALIGN;
   p.delta = ws + off[0];
+  p.xstat = ws + (((size_t)d->B * d->H * d->nx * d->ny + 3) & ~(size_t)3);
   float* tabws = ws + off[1];
   c.tabws = tabws;
   bc.hist_parts = ws + off[2];

@@ -33,6 +33,8 @@ struct VilParams {
   const float* g2g;          // (H,G,G) or null
   float* dg2l0; float* dg2g;
   const int* mode_dev;       // device-side random-shift neighbour (1..8) or null
+  float* xstat;              // workspace (B*H, G+1, 2): {lse, rowsum(dO * O)} of the G global-query rows, then {+big, 0} for
+                             // padding slots -- what the dK/dV pass's streamed slots with a negative token read (k_mfma_delta)
 };
 
 static inline void vil_fill_params(VilParams& p, const VilAttnDesc* d) {

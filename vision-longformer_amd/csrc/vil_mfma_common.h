@@ -457,6 +457,11 @@ struct BwdCfg {
   int kv_gspare;      // dK/dV pass, G == 1: the global key rides in a spare key column of every chunk's last wave (no owner units)
   int kv_gjj;         // ... that column's (x, hq) pair index within the chunk (= W * kv_HQ, the first unused pair)
   int gq_nrec;        // records per (image, head) in gq_parts: nch * kv_NWP (+ 1: the owner unit's, without kv_gspare)
+  // vil_attn_bwd_full: the G global QUERY rows are the last G slots of every unit's query stream (round 5).  Their bias
+  // (g2l[0][h][g] against local keys, g2g[h][gq][gk] against global keys) comes out of constant regions the dK/dV
+  // workgroups append to their LDS copy of the bias image:  [c.tabsize | G x gsz: g2l0 | G*G x gsz: g2g]
+  int kv_xsize;       // floats appended (0 without global-query rows)
+  int kv_span;        // largest key address term (W-1)*P + KT*HQ - 1: a global-query slot's address term is region + span
 };
 
 struct PrepZero { unsigned* ptr[5]; int n[5]; int total; };
