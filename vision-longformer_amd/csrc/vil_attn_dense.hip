@@ -587,7 +587,7 @@ __global__ __launch_bounds__(QT == 1 ? 64 * DN_MAXW_Q : 64 * DN_MAXW_Q2, QT == 1
           const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qt][r], c1, -lse2[qt]));
           ds[r] = pr * dpacc[qt][r];
           if (HIST)
-            __hip_atomic_fetch_add(lds_i32(i0[qt][r] + hist_off), __float2int_rn(FOLD ? ds[r] : ds[r] * hscale),
+            __hip_atomic_fetch_add(lds_i32(i0[qt][r] + hist_off), f2i_rpi(FOLD ? ds[r] : ds[r] * hscale),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (HIST && qt == 0 && GLO) {

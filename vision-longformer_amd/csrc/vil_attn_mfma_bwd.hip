@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
               const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[hf][qt][r], c1, -lse2[qt]));
               ds[r] = pr * dpacc[hf][qt][r];
               if (bc.do_hist)
-                __hip_atomic_fetch_add(lds_i32(i0[hf][r] + hist_off) + qt, __float2int_rn(FOLD ? ds[r] : ds[r] * hscale),
+                __hip_atomic_fetch_add(lds_i32(i0[hf][r] + hist_off) + qt, f2i_rpi(FOLD ? ds[r] : ds[r] * hscale),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             dsw[qt][hf * 2] = pack2<T>((f32x2){ds[0], ds[1]});
