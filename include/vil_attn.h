@@ -135,6 +135,18 @@ int vil_glo_attn_bwd(const VilAttnDesc* d, const void* q_g, const void* k, const
                      const float* g2g, const float* g2l0, void* dq_g, void* dk, void* dv,
                      float* dg2g, float* dg2l0, void* stream);
 
+/* ---- whole-layer forward (round 5): local rows AND the global token's query row from ONE pass over K / V.  The global
+ * query rides in the forward kernel as a spare query column of every chunk, live against the chunk's own keys; a small
+ * merge launch combines the chunks' partials with the global key's term into out_all[:, 0] and lse_g -- what
+ * vil_attn_fwd followed by vil_glo_attn_fwd computes (reference longformer2d.py:134-227), without streaming K / V a
+ * second time.  q_all / out_all point at TOKEN 0 of (B, G+Nloc, H*M) views with the descriptor's strides; g2l is the
+ * reference's (2,H,G) g2l_relative_position_bias, g2g (H,G,G); lse (B,H,Nloc), lse_g (B,H,G).  G == 1, 16-bit I/O, MFMA
+ * family, a free query slot in the chunk's last wave (every W but 8 at head_dim <= 32): VIL_E_BACKEND otherwise -- call
+ * vil_attn_fwd + vil_glo_attn_fwd instead.  Workspace: vil_attn_workspace_bytes(d, 0). */
+int vil_attn_fwd_full(const VilAttnDesc* d, const void* q_all, const void* k, const void* v,
+                      const float* bias_table, const float* g2l, const float* g2g,
+                      void* out_all, float* lse, float* lse_g, void* workspace, void* stream);
+
 /* ---- whole-layer backward: local rows AND the G global-token query rows in ONE call (MFMA family;
  * VIL_E_BACKEND otherwise -- call vil_attn_bwd + vil_glo_attn_bwd instead).  q_all / out_all /
  * dout_all / dq_all point at TOKEN 0 (the global rows) of (B, G+Nloc, H*M) views with the descriptor's

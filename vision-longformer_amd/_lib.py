@@ -33,7 +33,7 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_attn_profile_begin", "vil_attn_profile_end", "vil_attn_profile_end2", "vil_attn_kernel_name",
            "vil_layernorm_workspace_bytes", "vil_layernorm_fwd", "vil_layernorm_bwd",
            "vil_layernorm_fwd_tokens", "vil_layernorm_bwd_tokens", "vil_patchify_fwd", "vil_patchify_bwd",
-           "vil_glo_attn_fwd", "vil_glo_attn_bwd", "vil_attn_bwd_full",
+           "vil_glo_attn_fwd", "vil_glo_attn_bwd", "vil_attn_bwd_full", "vil_attn_fwd_full",
            "vil_dense_attn_supported", "vil_dense_attn_workspace_bytes", "vil_dense_attn_fwd", "vil_dense_attn_bwd", "vil_dense_attn_set_fwd_shape",
            "vil_colsum_workspace_bytes", "vil_colsum_bf16", "vil_colsum_f32",
            "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad", "vil_linear_wgrad_tune", "vil_linear_wgrad_set_plan", "vil_linear_wgrad_get_plan",
@@ -110,6 +110,9 @@ def lib():
         L.vil_glo_attn_bwd.argtypes = [dp] + [vp] * 14
         L.vil_attn_bwd_full.restype = ctypes.c_int
         L.vil_attn_bwd_full.argtypes = [dp] + [vp] * 18
+        if hasattr(L, "vil_attn_fwd_full"):          # (absent from an older A/B library: tools/)
+            L.vil_attn_fwd_full.restype = ctypes.c_int
+            L.vil_attn_fwd_full.argtypes = [dp] + [vp] * 11
         L.vil_gemm_dgelu_bf16.restype = ctypes.c_int
         L.vil_gemm_dgelu_bf16.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                           ctypes.c_int64, ctypes.c_int64, vp]

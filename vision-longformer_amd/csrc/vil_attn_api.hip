@@ -90,6 +90,33 @@ extern "C" int vil_attn_fwd(const VilAttnDesc* d, const void* q, const void* k, 
                                 : vil_scalar_fwd(d, p, (hipStream_t)stream);
 }
 
+// Whole-layer forward: local rows AND the global token's row in the forward pass's own launch (round 5).  Returns
+// VIL_E_BACKEND where the row cannot ride (G != 1, only_glo, fp32 / scalar family, W = 8 at head_dim 32): the caller then
+// runs vil_attn_fwd + vil_glo_attn_fwd.
+extern "C" int vil_attn_fwd_full(const VilAttnDesc* d, const void* q_all, const void* k, const void* v,
+                                 const float* bias_table, const float* g2l, const float* g2g,
+                                 void* out_all, float* lse, float* lse_g, void* workspace, void* stream) {
+  int e = check_common(d);
+  if (e) return e;
+  vil_prof_tag_desc(d);
+  if (!q_all || !k || !v || !out_all || !lse || !lse_g) return VIL_E_NULL;
+  if (d->G != 1 || d->only_glo) return VIL_E_BACKEND;
+  if (d->backend == VIL_BACKEND_SCALAR || d->dtype == VIL_DTYPE_F32 || vil_mfma_supported(d, 0) != VIL_OK) return VIL_E_BACKEND;
+  if (!workspace) return VIL_E_WORKSPACE;
+  const int64_t es = 2;                                   // the MFMA family: bf16 or fp16
+  VilParams p; memset(&p, 0, sizeof(p));
+  vil_fill_params(p, d);
+  const int64_t HG = (int64_t)d->H * d->G;
+  p.q = (const char*)q_all + d->G * d->q_st * es; p.o = (char*)out_all + d->G * d->o_st * es;
+  p.k = k; p.v = v; p.lse = lse;
+  p.table = bias_table; p.g2l = g2l ? g2l + HG : nullptr;          // (2, H, G): [1] local query -> global key
+  p.has_bias = bias_table != nullptr; p.has_g2l = g2l != nullptr;
+  p.glo_rows = 1;
+  p.q_g = q_all; p.o_g = out_all; p.lse_g = lse_g; p.g2l0 = g2l; p.g2g = g2g;
+  p.delta = (float*)workspace;
+  return vil_mfma_fwd(d, p, (hipStream_t)stream);
+}
+
 extern "C" int vil_attn_bwd(const VilAttnDesc* d, const void* q, const void* k, const void* v,
                             const void* out, const void* dout, const float* lse,
                             const float* bias_table, const float* g2l,

@@ -35,7 +35,22 @@ __global__ __launch_bounds__(256) void k_mfma_prep(VilParams p, MfmaCfg c, int r
   const int blk = blockIdx.x, ntab = ntx * p.H;
   if (blk < ntab) {
     const int h = blk / ntx, bx = blk - h * ntx;
-    table_element(p, c, (float*)c.tabws, h, bx * 256 + threadIdx.x, 1.0f / p.scale);
+    const int e = bx * 256 + threadIdx.x;
+    table_element(p, c, (float*)c.tabws, h, e, 1.0f / p.scale);
+    if (c.gq_on && e >= c.tabsize && e < c.tabsize + c.gq_ext) {
+      // image of the global query's column (vil_attn_fwd_full): entry i stands for the key address term
+      // Ak = Amax - i; it carries g2l[0][h][0] / scale where Ak = x * P + y with 0 <= x, y < W -- a key of the chunk's own
+      // chunk (neighbour offset (0, 0)) -- and the mask everywhere else: other neighbours, padding and global key slots
+      const int W = p.g.W;
+      const int amax = (2 * W - 1) * c.P + 2 * W - 1, amin = -W * c.P - W;
+      const int t = amax - (e - c.tabsize) - amin;             // Ak - Amin
+      float v = VIL_MASK_VAL;
+      if (t >= 0) {
+        const int xt = t / c.P - W, yt = t % c.P - W;
+        if (xt >= 0 && xt < W && yt >= 0 && yt < W) v = p.g2l0 ? p.g2l0[h * p.G] / p.scale : 0.f;
+      }
+      ((float*)c.tabws)[(int64_t)h * c.tabstride + e] = v;
+    }
   } else if (threadIdx.x < 64) {
     key_slots_block(p, c, blk - ntab, threadIdx.x, row_stride_b, smem);
   }
@@ -86,16 +101,17 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   const int bh = b * p.H + h;
 
   float* tab = (float*)smem;
+  const int tabx = c.tabsize + (c.gq_on ? c.gq_ext : 0);      // bias image (+ the global query column's image)
 #if !VIL_FWD_FASTPRO
   {
-    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
-    for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
+    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabstride);
+    for (int i = tid; i < (tabx >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
   }
   __syncthreads();
 #endif
   const unsigned tab_lds = lds_addr(smem);
 
-  char* wbase = smem + (size_t)c.tabsize * 4 + (size_t)wave * c.wave_lds;
+  char* wbase = smem + (size_t)tabx * 4 + (size_t)wave * c.wave_lds;
   int* s_koff = (int*)wbase;                       // [NSP] byte offset of each key slot's K/V row
   int* s_akey = s_koff + c.NSP;                    // [NSP] bias-table address term (bytes)
   char* s_v = (char*)(s_akey + c.NSP);             // [32][M] bf16 V tile of the current step
@@ -151,7 +167,10 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
     // ---- query slots of this lane: column j of q-tile qt is query (x, y = 4*hq + qt)
     const int jj = wp * 16 + lj;
     const int qx = fdiv(jj, c.m_HQ), qhq = jj - qx * c.HQ;
-    const unsigned aq0b = tab_lds + (min(qx, W - 1) * c.P + 4 * qhq) * 4;   // LDS byte address; + 4*qt per q-tile
+    // vil_attn_fwd_full: q-tile 0 of the chunk's first unused (x, hq) pair is the GLOBAL query; its bias comes from the
+    // column image behind the table (own-chunk keys: g2l[0], everything else masked)
+    const bool gqcol = c.gq_on && jj == c.gq_jj;
+    const unsigned aq0b = tab_lds + (gqcol ? c.tabsize + c.gq_a0 : min(qx, W - 1) * c.P + 4 * qhq) * 4;   // LDS byte address; + 4*qt per q-tile
     int qtok[4];
     bool qreal[4];
 #pragma unroll
@@ -168,7 +187,8 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
       for (int ks = 0; ks < MK; ++ks) {
         const int d0 = ks * 32 + lg * 8;
         X8 z = {};
-        qf[ks][qt] = d0 < M ? *(const X8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
+        const T* qrow = (gqcol && qt == 0) ? (const T*)p.q_g + b * p.q_sb + h * p.q_sh : qb + (int64_t)qtok[qt] * p.q_st;
+        qf[ks][qt] = d0 < M ? *(const X8*)(qrow + d0) : z;
       }
 #if VIL_FWD_FASTPRO
     // Unit prologue in two memory round trips (round 5; it was four: bias image -> barrier -> slot count -> slot table ->
@@ -184,8 +204,8 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
     for (int u = 0; u < EPRE; ++u) e[u] = ksrc[min(u * 64 + ln, c.NSP - 1)];
     const int nslots = __builtin_amdgcn_readfirstlane(c.key_nslots[ch]);
     if (gi == 0) {
-      const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabsize);
-      for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
+      const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabstride);
+      for (int i = tid; i < (tabx >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
     }
     if (!valid) break;
 #pragma unroll
@@ -371,9 +391,11 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
     }
 
     // ---- epilogue: normalise, store O (4 dims x 8 bytes per d-tile) and LSE
+    float l_q0 = 0.f;
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       const float l = __shfl(lacc[qt][0], lj, 64);      // row 0 lives in lane group 0
+      if (qt == 0) l_q0 = l;
       const float inv = 1.0f / l;
       if (qreal[qt]) {
 #pragma unroll
@@ -387,8 +409,55 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
           p.lse[(int64_t)bh * Nloc + qtok[qt]] = mrow[qt] * p.scale + __logf(l);
       }
     }
+    if (gqcol) {      // the global query's partial over this chunk's own keys: O (unnormalised), l, m -> k_gq_merge
+      float* part = c.gq_parts + ((int64_t)bh * (g.mx * g.my) + ch) * (M + 4);      // (16-byte records)
+#pragma unroll
+      for (int dt = 0; dt < MD; ++dt)
+        *(f32x4*)(part + dt * 16 + lg * 4) = o[dt][0];
+      if (lg == 0) { part[M] = l_q0; part[M + 1] = mrow[0]; }
+    }
     wave_lds_fence();
   }
+}
+
+// The global token's output row from the chunks' partials (vil_attn_fwd_full, G == 1): one workgroup of 64 threads per
+// (image, head).  Partial u: O_u = sum_k 2^((s_k - m_u) c1) v_k over the keys of chunk u, l_u the same sum without v, m_u
+// the running maximum (score domain: s = q.k + bias / scale, c1 = scale * log2 e); the global key itself is one more
+// partial (m = q_g.k_g + g2g / scale, l = 1, O = v_g).  out_g = sum_u w_u O_u / sum_u w_u l_u with w_u = 2^((m_u - m*) c1),
+// lse_g = m* scale + ln(sum_u w_u l_u) -- the definition k_glo_fwd uses (reference longformer2d.py:210-227).
+template <typename T>
+__global__ __launch_bounds__(64) void k_gq_merge(VilParams p, MfmaCfg c) {
+  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int M = p.M, nch = p.g.mx * p.g.my, t = threadIdx.x;
+  const float c1 = p.scale * LOG2E;
+  const float* parts = c.gq_parts + (int64_t)bh * nch * (M + 4);
+  const T* qg = (const T*)p.q_g + b * p.q_sb + h * p.q_sh;
+  const T* kg = (const T*)p.k + b * p.k_sb + h * p.k_sh;
+  const T* vg = (const T*)p.v + b * p.v_sb + h * p.v_sh;
+  // the global key's score
+  float sg = t < M ? (float)qg[t] * (float)kg[t] : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sg += __shfl_xor(sg, o, 64);
+  sg += p.g2g ? p.g2g[(int64_t)h * p.G * p.G] / p.scale : 0.f;
+  float mx = sg;
+  for (int u = t; u < nch; u += 64) mx = fmaxf(mx, parts[(int64_t)u * (M + 4) + M + 1]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  // thread t owns head dim t (M <= 64): walks all partials in a fixed order
+  float acc = 0.f, L = 0.f;
+  for (int u = 0; u < nch; ++u) {
+    const float* pu = parts + (int64_t)u * (M + 4);
+    const float w = __builtin_amdgcn_exp2f((pu[M + 1] - mx) * c1);
+    L = __builtin_fmaf(w, pu[M], L);
+    if (t < M) acc = __builtin_fmaf(w, pu[t], acc);
+  }
+  const float wg = __builtin_amdgcn_exp2f((sg - mx) * c1);
+  L += wg;
+  if (t < M) {
+    acc = __builtin_fmaf(wg, (float)vg[t], acc);
+    ((T*)p.o_g + b * p.o_sb + h * p.o_sh)[t] = (T)(acc / L);
+  }
+  if (t == 0) ((float*)p.lse_g)[bh] = mx * p.scale + __logf(L);
 }
 
 // ===================================================================== host side
@@ -408,6 +477,7 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   c.guard0 = ((c.trows * P + 3) / 4) * 4;
   c.glo0 = c.guard0 + c.gsz;
   c.tabsize = ((c.glo0 + d->G * c.gsz + 4 + 3) / 4) * 4;
+  c.tabstride = c.tabsize;
   c.aconst = c.tcen * (P + 1) + VIL_CPAD;
   c.magicW = vil_magic((unsigned)W);
   c.magicW2 = vil_magic((unsigned)(W * W));
@@ -436,13 +506,32 @@ bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   return true;
 }
 
-static size_t mfma_lds_bytes(const MfmaCfg& c) { return (size_t)c.tabsize * 4 + (size_t)c.wpw * c.wave_lds; }
+static size_t mfma_lds_bytes(const MfmaCfg& c) { return (size_t)(c.tabsize + (c.gq_on ? c.gq_ext : 0)) * 4 + (size_t)c.wpw * c.wave_lds; }
+
+// vil_attn_fwd_full: can the global token's query row ride in the forward pass?  One global token (every published
+// model), local keys attended, and an unused (x, hq) pair in the chunk's last wave (W = 8: all 16 pairs are queries).
+static bool gq_fusable(const VilAttnDesc* d, const MfmaCfg& c) {
+  return d->G == 1 && !d->only_glo && d->dtype != VIL_DTYPE_F32 && d->W * c.HQ < 16 * c.NWP;
+}
+static void gq_cfg(const VilAttnDesc* d, MfmaCfg& c) {
+  const int W = d->W;
+  const int amax = (2 * W - 1) * c.P + 2 * W - 1, amin = -W * c.P - W;
+  c.gq_jj = W * c.HQ;
+  c.gq_a0 = amax - c.aconst;
+  // entry i <-> key address term Amax - i; padding / global key slots (terms below -guard0) land behind the window,
+  // inside the extension, on masked entries
+  int ext = amax - amin + 4;
+  if (amax - c.aconst + c.tabsize + 4 > ext) ext = amax - c.aconst + c.tabsize + 4;
+  c.gq_ext = (ext + 3) & ~3;
+  c.tabstride = c.tabsize + c.gq_ext;
+  c.gq_on = 1;
+}
 
 int vil_mfma_bwd_supported(const VilAttnDesc* d);
 size_t vil_mfma_bwd_workspace(const VilAttnDesc* d);
 
 int vil_mfma_launch_prep(const VilParams& p, const MfmaCfg& c, int row_stride_b, hipStream_t s) {
-  const int ntx = (c.tabsize + 255) / 256, nch = p.g.mx * p.g.my;
+  const int ntx = (c.tabsize + (c.gq_on ? c.gq_ext : 0) + 255) / 256, nch = p.g.mx * p.g.my;
   if (int he = vil_ensure_dyn_lds((const void*)k_mfma_prep, (size_t)c.NSP * 8)) return he;
   k_mfma_prep<<<dim3((unsigned)(ntx * p.H + nch)), dim3(256), (size_t)c.NSP * 8, s>>>(p, c, row_stride_b, ntx);
   return (int)hipGetLastError();
@@ -473,7 +562,12 @@ size_t vil_mfma_workspace(const VilAttnDesc* d, int pass) {
   if (pass != 0) return vil_mfma_bwd_workspace(d);
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
-  return ((size_t)d->H * c.tabsize + vil_key_slots_floats(c, g.mx * g.my)) * sizeof(float);
+  size_t fl = (size_t)d->H * c.tabsize + vil_key_slots_floats(c, g.mx * g.my);
+  if (gq_fusable(d, c)) {       // vil_attn_fwd_full: wider images + one partial per (image, head, chunk)
+    gq_cfg(d, c);
+    fl = (size_t)d->H * c.tabstride + vil_key_slots_floats(c, g.mx * g.my) + (size_t)d->B * d->H * g.mx * g.my * (d->M + 4) + 4;
+  }
+  return fl * sizeof(float);
 }
 
 int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
@@ -481,15 +575,21 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   float* tabws = (float*)p.delta;          // workspace base
   c.tabws = tabws;
+  if (p.glo_rows) {                        // vil_attn_fwd_full
+    if (!gq_fusable(d, c)) return VIL_E_BACKEND;
+    gq_cfg(d, c);
+    if (mfma_lds_bytes(c) > 160 * 1024) return VIL_E_BACKEND;
+  }
   if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)tabws) & 15) return VIL_E_ALIGN;
   if ((uintptr_t)p.o & 7) return VIL_E_ALIGN;
   const VilWork w(d);
   const int nch = p.g.mx * p.g.my;
-  c.key_slots = (int2*)(tabws + (size_t)p.H * c.tabsize);           // (tabsize is a multiple of 4 floats)
+  c.key_slots = (int2*)(tabws + (size_t)p.H * c.tabstride);         // (tabsize / tabstride are multiples of 4 floats)
   c.key_nslots = (int*)(c.key_slots + (size_t)nch * c.NSP);
+  if (c.gq_on) c.gq_parts = tabws + (((size_t)p.H * c.tabstride + vil_key_slots_floats(c, nch) + 3) & ~(size_t)3);
   vil_prof_begin(VIL_K_TABLE, s, 0, 0);
   {
-    const int ntx = (c.tabsize + 255) / 256;
+    const int ntx = (c.tabsize + (c.gq_on ? c.gq_ext : 0) + 255) / 256;
     if (int he = vil_ensure_dyn_lds((const void*)k_mfma_prep, (size_t)c.NSP * 8)) return he;
     k_mfma_prep<<<dim3((unsigned)(ntx * p.H + nch)), dim3(256), (size_t)c.NSP * 8, s>>>(p, c, (int)p.k_st * 2, ntx);
   }
@@ -517,5 +617,12 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     default: return VIL_E_HEAD_DIM;
   }
   vil_prof_end(s);
+  if ((e = (int)hipGetLastError())) return e;
+  if (c.gq_on) {
+    vil_prof_begin(VIL_K_GLO_FWD, s, 0, 0);
+    if (d->dtype == VIL_DTYPE_F16) k_gq_merge<_Float16><<<dim3((unsigned)(p.B * p.H)), dim3(64), 0, s>>>(p, c);
+    else k_gq_merge<__bf16><<<dim3((unsigned)(p.B * p.H)), dim3(64), 0, s>>>(p, c);
+    vil_prof_end(s);
+  }
   return (int)hipGetLastError();
 }

@@ -91,6 +91,16 @@ struct MfmaCfg {
   int2* key_slots;     // (mx*my, NSP): key-slot table of every query chunk (key_slots_block), .x = K/V row byte offset, .y = bias term
   int* key_nslots;     // (mx*my): padded slot count of each
   UnitQueue uq;        // forward pass units (query chunks x NWP)
+  // vil_attn_fwd_full (G == 1): the global token's QUERY row rides in the forward pass as the first unused query column
+  // of every chunk's last wave, live against the chunk's OWN keys only (every key has exactly one own chunk); the unit
+  // leaves a partial (m, l, O) that k_gq_merge combines with the global key's term.  Its bias comes from a constant
+  // image behind the head's table: g2l[0][h][0] / scale where the key address term belongs to the own chunk, masked elsewhere.
+  int tabstride;       // floats between two heads' images in tabws (tabsize, or tabsize + gq_ext)
+  int gq_on;           // the forward launch carries the global query column
+  int gq_jj;           // its (x, hq) pair index within the chunk (= W * HQ)
+  int gq_a0;           // the column's address term: table index tabsize + gq_a0 - (Ak - aconst)
+  int gq_ext;          // floats of the image extension (multiple of 4)
+  float* gq_parts;     // (B*H, chunks, M + 4): O (unnormalised), l, m, pad per chunk
 };
 
 // n / d for a run-time divisor without the ~25-instruction integer division sequence: magic = floor(2^32 / d) + 1
@@ -407,7 +417,7 @@ __device__ __forceinline__ void table_element(const VilParams& p, const MfmaCfg&
     const int g = (e - c.glo0) / c.gsz;
     if (g < p.G && p.has_g2l) v = p.g2l[h * p.G + g] * inv;
   }
-  out[(int64_t)h * c.tabsize + e] = v;
+  out[(int64_t)h * c.tabstride + e] = v;
 }
 // Key-slot table of query chunk ch, built by ONE wave in `smem` (NSP * 8 bytes) and copied to c.key_slots
 __device__ __forceinline__ void key_slots_block(const VilParams& p, const MfmaCfg& c, int ch, int lane, int row_stride_b,

@@ -177,6 +177,14 @@ def _full_fwd(q_all, k, v, tab, g2l_f, g2g_f, cfg, backend):
     ws = _workspace(d, 0, q_all.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(q_all.device).cuda_stream)
     with torch.cuda.device(q_all.device):
+        if G == 1 and backend != "scalar" and hasattr(L, "vil_attn_fwd_full"):
+            # one pass over K / V: the global token's row rides in the forward kernel (round 5)
+            rc = L.vil_attn_fwd_full(ctypes.byref(d), _ptr(q_all), _ptr(k), _ptr(v), _ptr(tab), _ptr(g2l_f), _ptr(g2g_f),
+                                     _ptr(out_all), _ptr(lse), _ptr(lse_g), _ptr(ws), stream)
+            if rc == 0:
+                return out_all, lse, lse_g
+            if rc != _lib.VIL_E_BACKEND:
+                _lib.check(rc)
         _lib.check(L.vil_attn_fwd(ctypes.byref(d), _ptr(q_loc), _ptr(k), _ptr(v), _ptr(tab),
                                   _ptr(g2l_f[1]) if g2l_f is not None else None,
                                   _ptr(out_loc), _ptr(lse), _ptr(ws), stream))
