@@ -1,18 +1,17 @@
 #!/bin/bash
 # copies the summaries of a tools/final_session.sh run from gpurun_out/<tag>/ (scratch) into profiles/ (tracked)
-# usage: tools/collect_profiles.sh <tag> <round prefix, e.g. r04>
+# usage: tools/collect_profiles.sh <tag> <round prefix, e.g. r05>
 set -u
 T=gpurun_out/$1; R=$2
-cp $T/bench.json profiles/${R}_bench.json
+tail -1 $T/bench.json > profiles/${R}_bench_line.json
+cp $T/bench_detail.json profiles/${R}_bench.json
 cp $T/steady_vil_small_224.txt profiles/${R}_bench_small224_steady_state.txt
 cp $T/steady_vil_medium_deep_384.txt profiles/${R}_bench_meddeep384_steady_state.txt
 cp $T/kernel_stats_vil_small_224.csv profiles/${R}_bench_small224_kernel_stats.csv
 cp $T/kernel_stats_vil_medium_deep_384.csv profiles/${R}_bench_meddeep384_kernel_stats.csv
 cp $T/pmcstep/pmc_traffic.json profiles/${R}_pmc_traffic.json
 cp $T/parity_report.txt profiles/${R}_parity_report.txt
-cp $T/op_benchmark.jsonl profiles/${R}_op_benchmark_reference_protocol.jsonl
+cp $T/ab_summary.txt profiles/${R}_attn_ab_vs_round4.txt
 cp $T/dense_bench.txt profiles/${R}_dense_bench.txt 2>/dev/null
-cp $T/pmc/pipe_utilisation.txt profiles/${R}_pipe_utilisation.txt
-rm -f profiles/${R}_pmc_k_*.json
-python tools/pmc_all_summary.py $T/pmc profiles/${R}_pmc_ > /dev/null
+cp $T/valu_rate.txt profiles/${R}_valu_rate_ubench.txt 2>/dev/null
 ls profiles | grep "^${R}_" | wc -l

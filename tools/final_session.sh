@@ -1,17 +1,15 @@
-# end-of-round measurement call: full GPU suite, in-step PMC traffic, rocprofv3 traces of both configurations, the bench
-# line, counters of every hot kernel, the reference's operator protocol.  Results -> gpurun_out/r04_final/ (copy what is
-# to be judged into profiles/ afterwards: tools/collect_profiles.sh r04_final r04)
+# end-of-round measurement call (round 5): full GPU suite, in-step PMC traffic of the four bench configurations, rocprofv3
+# kernel traces of both headline configurations, the bench line, per-kernel A/B against the round-4 library.
+# Results -> gpurun_out/<tag>/ ; tools/collect_profiles.sh <tag> r05 copies what is to be judged into profiles/.
 set -u
 cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r04_final}
+TAG=${1:-r05_final}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-bash tools/gpu_session.sh $TAG testall pmcstep profile > $OUT/session.log 2>&1
-timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-tail -2 $OUT/bench.err
-python -c "
-import json; d=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['hot_path_ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['secondary']['value'], d['secondary']['ms_per_step'], [t['value'] for t in d['tertiary']], {k: v['images_per_s'] for k, v in d['eval'].items()}, d['cpu_baseline']['value'], d['cpu_baseline']['cores'])"
-bash tools/pmc_all.sh $OUT/pmc > $OUT/pmc.txt 2>&1; tail -45 $OUT/pmc.txt
-timeout 300 python tools/op_benchmark.py > $OUT/op_benchmark.jsonl 2> $OUT/op_benchmark.err; cut -c1-200 $OUT/op_benchmark.jsonl
-timeout 120 python tools/dense_bench.py --dense-only > $OUT/dense_bench.txt 2>&1
+bash tools/r5_session.sh $TAG testall pmcstep profile smoke > $OUT/session.log 2>&1
+timeout 900 python bench.py --detail $OUT/bench_detail.json > $OUT/bench.json 2> $OUT/bench.err
+tail -2 $OUT/bench.err; echo "bench line bytes: $(tail -1 $OUT/bench.json | wc -c)"; tail -1 $OUT/bench.json
+AB_SHAPES=small_s1,small_s2,meddeep_s1_f7,meddeep_s2_f7,meddeep_s1_f8,meddeep_s2_f12,basedeep_s1_f6_rs,basedeep_s2_f8_rs bash tools/attn_ab.sh $OUT/ab.txt "small_s1,small_s2,meddeep_s1_f7,meddeep_s2_f7,meddeep_s1_f8,meddeep_s2_f12,basedeep_s1_f6_rs,basedeep_s2_f8_rs" 1 > $OUT/ab_summary.txt 2>&1
+cat $OUT/ab_summary.txt
+timeout 200 python tools/dense_bench.py --dense-only > $OUT/dense_bench.txt 2>&1
 grep -E "passed|failed" $OUT/pytest_gpu.log | tail -2
-tail -6 $OUT/session.log
+tail -12 $OUT/session.log

@@ -1,4 +1,4 @@
-"""Builds the PMC traffic file bench.py attaches to its roofline objects (profiles/r03_pmc_traffic.json) from the
+"""Builds the PMC traffic file bench.py attaches to its roofline objects (profiles/r05_pmc_traffic.json) from the
 rocprofv3 --pmc passes of tools/pmc_step.sh.  Dispatches are matched to problem shapes by launch order: every eager
 step launches the library kernels in the same order, which bench.py dumped (VIL_BENCH_DUMP_TAGS) together with each
 launch's algorithmic bytes.  FETCH_SIZE (KB) is doubled (gfx950: the counter reports half of a wide coalesced stream --
@@ -17,7 +17,7 @@ from vision_longformer_amd import _lib  # noqa: E402
 
 SINK = {"k_mfma_prep": "k_mfma_table", "k_mfma_prep_bwd": "k_mfma_table", "k_mfma_fwd": "k_mfma_fwd", "k_mfma_delta": "k_delta", "k_mfma_bwd_dq": "k_mfma_bwd_dq",
         "k_mfma_bwd_dkdv": "k_mfma_bwd_dkdv", "k_mfma_post_bwd": "k_reduce_glo",
-        "k_glo_fwd": "k_glo_fwd", "k_glo_bwd": "k_glo_bwd", "k_dense_fwd": "k_dense_fwd", "k_dense_bwd_dq": "k_dense_bwd_dq",
+        "k_glo_fwd": "k_glo_fwd", "k_gq_merge": "k_glo_fwd", "k_glo_bwd": "k_glo_bwd", "k_dense_fwd": "k_dense_fwd", "k_dense_bwd_dq": "k_dense_bwd_dq",
         "k_dense_bwd_dkdv": "k_dense_bwd_dkdv", "k_dense_reduce": "k_dense_reduce", "k_wgrad": "k_wgrad", "k_wgrad_reduce": "k_wgrad_reduce",
         "k_wgrad2": "k_wgrad", "k_wgrad2_reduce": "k_wgrad_reduce"}
 

@@ -426,31 +426,58 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
 // partial (m = q_g.k_g + g2g / scale, l = 1, O = v_g).  out_g = sum_u w_u O_u / sum_u w_u l_u with w_u = 2^((m_u - m*) c1),
 // lse_g = m* scale + ln(sum_u w_u l_u) -- the definition k_glo_fwd uses (reference longformer2d.py:210-227).
 template <typename T>
-__global__ __launch_bounds__(64) void k_gq_merge(VilParams p, MfmaCfg c) {
+__global__ __launch_bounds__(1024) void k_gq_merge(VilParams p, MfmaCfg c) {
+  // 16 waves: wave w walks partials w, w + 16, ... (four records in flight per lane), lane = head dim; the waves' sums
+  // are added in wave order -- a fixed order, the result is bit-reproducible.  (A 64-thread version walked the 64 .. 196
+  // records of an (image, head) one dependent round trip after the other: 21 - 43 us.)
+  __shared__ float s_o[16][64], s_l[16], s_mx[16];
   const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
-  const int M = p.M, nch = p.g.mx * p.g.my, t = threadIdx.x;
+  const int M = p.M, nch = p.g.mx * p.g.my, t = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int RS = M + 4;
   const float c1 = p.scale * LOG2E;
-  const float* parts = c.gq_parts + (int64_t)bh * nch * (M + 4);
+  const float* parts = c.gq_parts + (int64_t)bh * nch * RS;
   const T* qg = (const T*)p.q_g + b * p.q_sb + h * p.q_sh;
   const T* kg = (const T*)p.k + b * p.k_sb + h * p.k_sh;
   const T* vg = (const T*)p.v + b * p.v_sb + h * p.v_sh;
-  // the global key's score
+  // the global key's score (every wave computes it: no broadcast needed)
   float sg = t < M ? (float)qg[t] * (float)kg[t] : 0.f;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sg += __shfl_xor(sg, o, 64);
   sg += p.g2g ? p.g2g[(int64_t)h * p.G * p.G] / p.scale : 0.f;
+  // maximum over all partials: lane t of wave w reads m of partials w * 64 + t, ...
   float mx = sg;
-  for (int u = t; u < nch; u += 64) mx = fmaxf(mx, parts[(int64_t)u * (M + 4) + M + 1]);
+  for (int u = threadIdx.x; u < nch; u += 1024) mx = fmaxf(mx, parts[(int64_t)u * RS + M + 1]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  // thread t owns head dim t (M <= 64): walks all partials in a fixed order
+  if (t == 0) s_mx[w] = mx;
+  __syncthreads();
+  mx = s_mx[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s_mx[i]);
   float acc = 0.f, L = 0.f;
-  for (int u = 0; u < nch; ++u) {
-    const float* pu = parts + (int64_t)u * (M + 4);
-    const float w = __builtin_amdgcn_exp2f((pu[M + 1] - mx) * c1);
-    L = __builtin_fmaf(w, pu[M], L);
-    if (t < M) acc = __builtin_fmaf(w, pu[t], acc);
+  for (int u0 = w; u0 < nch; u0 += 64) {
+    float mu[4], lu[4], ou[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int u = min(u0 + 16 * k, nch - 1);
+      const float* pu = parts + (int64_t)u * RS;
+      mu[k] = pu[M + 1]; lu[k] = pu[M]; ou[k] = t < M ? pu[t] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (u0 + 16 * k < nch) {
+        const float wt = __builtin_amdgcn_exp2f((mu[k] - mx) * c1);
+        L = __builtin_fmaf(wt, lu[k], L);
+        acc = __builtin_fmaf(wt, ou[k], acc);
+      }
   }
+  s_o[w][t] = acc;
+  if (t == 0) s_l[w] = L;
+  __syncthreads();
+  if (w != 0) return;
+  acc = 0.f; L = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc += s_o[i][t]; L += s_l[i]; }
   const float wg = __builtin_amdgcn_exp2f((sg - mx) * c1);
   L += wg;
   if (t < M) {
@@ -521,7 +548,7 @@ static void gq_cfg(const VilAttnDesc* d, MfmaCfg& c) {
   // entry i <-> key address term Amax - i; padding / global key slots (terms below -guard0) land behind the window,
   // inside the extension, on masked entries
   int ext = amax - amin + 4;
-  if (amax - c.aconst + c.tabsize + 4 > ext) ext = amax - c.aconst + c.tabsize + 4;
+  if (amax - c.aconst + c.glo0 + d->G * c.gsz + 4 > ext) ext = amax - c.aconst + c.glo0 + d->G * c.gsz + 4;
   c.gq_ext = (ext + 3) & ~3;
   c.tabstride = c.tabsize + c.gq_ext;
   c.gq_on = 1;
@@ -620,8 +647,8 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   if ((e = (int)hipGetLastError())) return e;
   if (c.gq_on) {
     vil_prof_begin(VIL_K_GLO_FWD, s, 0, 0);
-    if (d->dtype == VIL_DTYPE_F16) k_gq_merge<_Float16><<<dim3((unsigned)(p.B * p.H)), dim3(64), 0, s>>>(p, c);
-    else k_gq_merge<__bf16><<<dim3((unsigned)(p.B * p.H)), dim3(64), 0, s>>>(p, c);
+    if (d->dtype == VIL_DTYPE_F16) k_gq_merge<_Float16><<<dim3((unsigned)(p.B * p.H)), dim3(1024), 0, s>>>(p, c);
+    else k_gq_merge<__bf16><<<dim3((unsigned)(p.B * p.H)), dim3(1024), 0, s>>>(p, c);
     vil_prof_end(s);
   }
   return (int)hipGetLastError();
