@@ -1347,8 +1347,12 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   // slot tables (token, address term, lse, delta) + Q / dO tiles + the dS rows of the global queries + (kv_gspare) the global key's address terms
   const int nqsa = ((bc.nqs + 63) & ~63) > 7 * 64 ? ((bc.nqs + 63) & ~63) : 7 * 64;      // (k_mfma_bwd_dkdv: EPRE rounds filled without bounds)
   bc.kv_wave_lds = ((nqsa * 16 + kv_tiles * 32 * d->M * 2 + (d->G > 1 ? 4 : 1) * 1024 + (bc.kv_gspare ? nqsa * 4 : 0) + 15) / 16) * 16;
+  // waves per workgroup: 2 at head_dim <= 32, 4 above.  A workgroup's slot on the CU is held until its longest unit ends
+  // (interior chunks walk 14 steps, corner chunks 7): same-box A/B (tools/attn_ab.sh, round 5) 354 -> 350 us at 56x56 and
+  // 271 -> 262 us at 96x96 for two-wave workgroups at head_dim 32, 160 -> 181 us at 28x28 / head_dim 64 (two waves per
+  // chunk there: splitting them over workgroups costs the shared L1 lines).
 #ifndef VIL_KV_WPW
-#define VIL_KV_WPW 4
+#define VIL_KV_WPW (d->M <= 32 ? 2 : 4)
 #endif
   bc.kv_wpw = VIL_KV_WPW;
   while (bc.kv_wpw > 1 && (size_t)(c.tabsize + bc.kv_xsize) * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
