@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void k_mfma_prep_bwd(VilParams p, MfmaCfg c, B
 }
 
 constexpr int kv_waves(int MD) { return MD == 2 ? VIL_KV_WAVES : 2; }
-template <typename T, int MD, int KT>
+template <typename T, int MD, int KT, int EPRE>
 __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p, MfmaCfg c, BwdCfg bc) {
   typedef typename V16<T>::x8 X8;
   typedef typename V16<T>::x4 X4;
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
 
   float* tab = (float*)smem;
   char* wbase = smem + (size_t)tabx * 4 + (size_t)wave * bc.kv_wave_lds;
-  const int nqsa = max((bc.nqs + 63) & ~63, 7 * 64);   // (arrays hold whole rounds of 64 slots, at least the EPRE rounds the prologue fills without bounds)
+  const int nqsa = max((bc.nqs + 63) & ~63, EPRE * 64);   // (arrays hold whole rounds of 64 slots, at least the EPRE rounds the prologue fills without bounds)
   int* s_tok = (int*)wbase;                       // [nqsa] row index of each streamed query slot in the Q / dO descriptors
   int* s_aq = s_tok + nqsa;                       // [nqsa] bias-table address term (bytes)
   float* s_lse = (float*)(s_aq + nqsa);           // [nqsa] lse * log2(e)   (+big for padding slots)
@@ -768,8 +768,9 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     // scalars, and LAST the bias image, whose copy loop waits for its own loads and therefore (loads return in order) for
     // all of the above -- then everything that depends on the slot entries: lse / delta gathers and the first Q / dO rows.
     // Same-box A/B at ViL-Small stage 1: 372 -> 358 us.
-    constexpr int EPRE = 7;                          // 448 slots: W <= 7 (+ global rows) in one straight-line pass -- no branch, so
-                                                     // that the compiler's counter waits stay where the data is first used
+    // EPRE rounds of 64 slots in one straight-line pass (no branch, so that the compiler's counter waits stay where the
+    // data is first used): 7 (448 slots: W <= 7 with the global rows) or 10 (W = 8: 577 slots); longer tables (W = 12)
+    // finish in the three-phase loop below
     const int tix = glo ? bc.nch + split : ch;
     const int2* slots = bc.kv_slots + (int64_t)tix * bc.nqs;
     // (a laundered copy of the lane id for the unit's one-off addresses: derived from `lane` they are invariants of the
@@ -1345,14 +1346,14 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
   // slot tables + Q/dO tiles + the q / dO / out rows of the G global queries (vil_attn_bwd_full)
   const int kv_tiles = (VIL_KV_PIPE && d->M == 32 && bc.kv_KT == 2) ? 4 : 2;       // Q + dO tiles (pipelined kernel: two pairs)
   // slot tables (token, address term, lse, delta) + Q / dO tiles + the dS rows of the global queries + (kv_gspare) the global key's address terms
-  const int nqsa = ((bc.nqs + 63) & ~63) > 7 * 64 ? ((bc.nqs + 63) & ~63) : 7 * 64;      // (k_mfma_bwd_dkdv: EPRE rounds filled without bounds)
+  bc.kv_epre = bc.nqs > 7 * 64 ? 10 : 7;                   // straight-line rounds of the dK/dV prologue (template parameter)
+  const int nqsa = ((bc.nqs + 63) & ~63) > bc.kv_epre * 64 ? ((bc.nqs + 63) & ~63) : bc.kv_epre * 64;
   bc.kv_wave_lds = ((nqsa * 16 + kv_tiles * 32 * d->M * 2 + (d->G > 1 ? 4 : 1) * 1024 + (bc.kv_gspare ? nqsa * 4 : 0) + 15) / 16) * 16;
-  // waves per workgroup: 2 at head_dim <= 32, 4 above.  A workgroup's slot on the CU is held until its longest unit ends
-  // (interior chunks walk 14 steps, corner chunks 7): same-box A/B (tools/attn_ab.sh, round 5) 354 -> 350 us at 56x56 and
-  // 271 -> 262 us at 96x96 for two-wave workgroups at head_dim 32, 160 -> 181 us at 28x28 / head_dim 64 (two waves per
-  // chunk there: splitting them over workgroups costs the shared L1 lines).
+  // waves per workgroup.  Two-wave workgroups (a workgroup's slot is held until its longest unit ends) measured 354 -> 350 us
+  // at 56x56 and 271 -> 262 us at 96x96 alone (head_dim 32; 160 -> 181 us at head_dim 64) but LOST inside the training step
+  // (313 -> 322 us at 56x56: twice the workgroups, twice the bias-image copies next to the other kernels' traffic): four.
 #ifndef VIL_KV_WPW
-#define VIL_KV_WPW (d->M <= 32 ? 2 : 4)
+#define VIL_KV_WPW 4
 #endif
   bc.kv_wpw = VIL_KV_WPW;
   while (bc.kv_wpw > 1 && (size_t)(c.tabsize + bc.kv_xsize) * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
@@ -1521,8 +1522,14 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     const unsigned grid = (unsigned)(p.B * p.H * bc.kv_wg_per_bh);
     vil_prof_begin(VIL_K_MFMA_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
     BWD_SWITCH({
-      if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dkdv<TT_, MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))>, lds)) return he;
-      k_mfma_bwd_dkdv<TT_, MD_, (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4))><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
+      constexpr int KT_ = (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4));
+      if (bc.kv_epre == 7) {
+        if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dkdv<TT_, MD_, KT_, 7>, lds)) return he;
+        k_mfma_bwd_dkdv<TT_, MD_, KT_, 7><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
+      } else {
+        if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dkdv<TT_, MD_, KT_, 10>, lds)) return he;
+        k_mfma_bwd_dkdv<TT_, MD_, KT_, 10><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
+      }
     });
     vil_prof_end(s);
     if ((e = (int)hipGetLastError())) return e;
