@@ -73,9 +73,6 @@ __global__ __launch_bounds__(256) void k_mfma_prep(VilParams p, MfmaCfg c, int r
 #ifndef VIL_FWD_WAVES
 #define VIL_FWD_WAVES 3    // waves per SIMD the register allocation is held to (2: 256, 3: 168, 4: 128 VGPRs)
 #endif
-#ifndef VIL_FWD_FASTPRO
-#define VIL_FWD_FASTPRO 1  // unit prologue as two memory round trips (0: round 4's four, for A/B builds)
-#endif
 constexpr int fwd_waves(int MD) { return MD <= 2 ? VIL_FWD_WAVES : 2; }
 template <typename T, int MD>
 __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, MfmaCfg c) {
@@ -102,13 +99,11 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
 
   float* tab = (float*)smem;
   const int tabx = c.tabsize + (c.gq_on ? c.gq_ext : 0);      // bias image (+ the global query column's image)
-#if !VIL_FWD_FASTPRO
   {
     const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabstride);
     for (int i = tid; i < (tabx >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
   }
   __syncthreads();
-#endif
   const unsigned tab_lds = lds_addr(smem);
 
   char* wbase = smem + (size_t)tabx * 4 + (size_t)wave * c.wave_lds;
@@ -151,16 +146,8 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
   const int lgo = lg * 16;
 
   for (int gi = 0; gi < c.gpw; ++gi) {
-#if VIL_FWD_FASTPRO
-    // (a wave whose first unit lies beyond the range still copies its share of the bias image before it leaves)
-    const int unit_ = (wgi * c.gpw + gi) * c.wpw + wave;
-    const bool valid = unit_ < c.units_bh;
-    if (!valid && gi > 0) break;
-    const int unit = valid ? unit_ : 0;
-#else
     const int unit = (wgi * c.gpw + gi) * c.wpw + wave;
     if (unit >= c.units_bh) break;
-#endif
     const int ch = fdiv(unit, c.m_NWP), wp = unit - ch * c.NWP;
     const int cm = fdiv(ch, c.m_my), cn = ch - cm * g.my;
 
@@ -190,45 +177,11 @@ __global__ __launch_bounds__(256, fwd_waves(MD)) void k_mfma_fwd(VilParams p, Mf
         const T* qrow = (gqcol && qt == 0) ? (const T*)p.q_g + b * p.q_sb + h * p.q_sh : qb + (int64_t)qtok[qt] * p.q_st;
         qf[ks][qt] = d0 < M ? *(const X8*)(qrow + d0) : z;
       }
-#if VIL_FWD_FASTPRO
-    // Unit prologue in two memory round trips (round 5; it was four: bias image -> barrier -> slot count -> slot table ->
-    // first K / V): the Q fragments above, the chunk's slot count and EPRE rounds of its slot table are requested with
-    // nothing between them, then the workgroup's bias image, whose copy loop waits for all of them (loads return in
-    // order); the first K / V rows follow.  Table entries beyond the chunk's slot count are never walked.
-    constexpr int EPRE = 7;                          // 448 slots: W <= 7 with one global token in one pass
-    int ln = lane;
-    asm volatile("" : "+v"(ln));                     // (keeps the one-off addresses below out of the unit loop's invariants)
-    const int2* ksrc = c.key_slots + (int64_t)ch * c.NSP;
-    int2 e[EPRE];
-#pragma unroll
-    for (int u = 0; u < EPRE; ++u) e[u] = ksrc[min(u * 64 + ln, c.NSP - 1)];
-    const int nslots = __builtin_amdgcn_readfirstlane(c.key_nslots[ch]);
-    if (gi == 0) {
-      const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabstride);
-      for (int i = tid; i < (tabx >> 2); i += blockDim.x) ((f32x4*)tab)[i] = src[i];
-    }
-    if (!valid) break;
-#pragma unroll
-    for (int u = 0; u < EPRE; ++u) {
-      const int sl = u * 64 + ln;
-      if (sl < c.NSP) { s_koff[sl] = e[u].x; s_akey[sl] = e[u].y; }
-    }
-    for (int s0 = EPRE * 64; s0 < nslots; s0 += 512) {      // (W > 7)
-      int2 e8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) e8[u] = ksrc[min(s0 + u * 64 + ln, nslots - 1)];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int sl = s0 + u * 64 + ln;
-        if (sl < nslots) { s_koff[sl] = e8[u].x; s_akey[sl] = e8[u].y; }
-      }
-    }
-    if (gi == 0) __syncthreads(); else wave_lds_fence();
-#else
     // (the Q fragments above are requested BEFORE the chunk's key-slot table is fetched: a unit's prologue used to be
     //  table -> Q -> first K/V, three dependent round trips; the table's and Q's now overlap)
     const int nslots = load_key_slots(c, ch, lane, s_koff, s_akey);
-#endif
+    // (round 5 measured the slot count, the slot table and the workgroup's bias image in ONE round trip here: 212 vs 213 us
+    //  at 56x56 -- three resident waves per SIMD already hide it -- and a loss on the 2 W^2-slot tables of random-shift training)
 
     f32x4 o[MD][4], lacc[4];
     float mrow[4];
@@ -604,8 +557,15 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   c.tabws = tabws;
   if (p.glo_rows) {                        // vil_attn_fwd_full
     if (!gq_fusable(d, c)) return VIL_E_BACKEND;
+    // ... and only where the column's image does not cost resident waves: at W = 12 / head_dim 64 it is 14 KB on top of
+    // 79 KB per workgroup -- one workgroup per CU instead of two (forward 140 -> 190 us at 48x48, same-box A/B)
+    const int cap = fwd_waves(d->M / 16) * 4;
+    const size_t lds0 = mfma_lds_bytes(c);
+    const int res0 = (int)((160 * 1024) / lds0) * c.wpw < cap ? (int)((160 * 1024) / lds0) * c.wpw : cap;
     gq_cfg(d, c);
-    if (mfma_lds_bytes(c) > 160 * 1024) return VIL_E_BACKEND;
+    const size_t lds1 = mfma_lds_bytes(c);
+    const int res1 = lds1 > 160 * 1024 ? 0 : ((int)((160 * 1024) / lds1) * c.wpw < cap ? (int)((160 * 1024) / lds1) * c.wpw : cap);
+    if (res1 < res0) return VIL_E_BACKEND;
   }
   if (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)tabws) & 15) return VIL_E_ALIGN;
   if ((uintptr_t)p.o & 7) return VIL_E_ALIGN;

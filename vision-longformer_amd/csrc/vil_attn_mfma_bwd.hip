@@ -198,11 +198,8 @@ __global__ __launch_bounds__(256, dq_waves(MD)) void k_mfma_bwd_dq(VilParams p, 
           qf[ks][qt] = d0 < M ? *(const X8*)(qb + (int64_t)qtok[qt] * p.q_st + d0) : z;
           dof[ks][qt] = d0 < M ? *(const X8*)(dob + (int64_t)qtok[qt] * p.do_st + d0) : z;
         }
-      // (requested after this wave's own rows, so that the table's round trip overlaps theirs: see k_mfma_fwd; round 5: the
-      //  slot count and the table entries in ONE round trip)
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      const int nslots = load_key_slots_once<7>(c, ch, ln, s_koff, s_akey);
+      // (requested after this wave's own rows, so that the table's round trip overlaps theirs: see k_mfma_fwd)
+      const int nslots = load_key_slots(c, ch, lane, s_koff, s_akey);
       if (bc.glo_from_dq) {
         // dK / dV of the G global keys as a by-product of this pass: the wave holds the Q / dO rows, lse and delta of its
         // queries; its share of dK_g = scale * sum_q dS[q,g] Q[q] and dV_g = sum_q P[q,g] dO[q] is ~250 VALU instructions
@@ -1333,30 +1330,44 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
 #define VIL_KV_GSPARE 1
 #endif
   bc.kv_gjj = g.W * bc.kv_HQ;
-  bc.kv_gspare = VIL_KV_GSPARE && d->G == 1 && !d->only_glo && !bc.glo_from_dq && bc.kv_gjj < 16 * bc.kv_NWP;
-  bc.nsplit = d->G > 0 ? (bc.kv_gspare ? 0 : (bc.glo_from_dq ? 1 : (bc.nch + 8) / 9)) : 0;
-  bc.units_kv_bh = bc.nch * bc.kv_NWP + bc.nsplit;
-  bc.gq_nrec = bc.nch * bc.kv_NWP + (bc.kv_gspare ? 0 : 1);
-  // streamed query slots: an own-key unit sees <= nact query chunks, a global-key unit its share of all chunks
-  const int qch = (d->G > 0 && !bc.glo_from_dq && bc.nsplit > 0) ? (bc.nch + bc.nsplit - 1) / bc.nsplit : 0;
+  const bool gspare_ok = VIL_KV_GSPARE && d->G == 1 && !d->only_glo && !bc.glo_from_dq && bc.kv_gjj < 16 * bc.kv_NWP;
   const int gq_rows = (d->G >= 1 && d->G <= 4) ? d->G : 0;      // vil_attn_bwd_full's global-query rows close the stream (G <= 4)
-  bc.nqs = ((qch > g.nact ? qch : g.nact) * g.W2 + gq_rows + 31) & ~31;
   bc.kv_xsize = gq_rows ? (gq_rows + gq_rows * gq_rows) * c.gsz : 0;
   bc.kv_span = (g.W - 1) * c.P + bc.kv_KT * bc.kv_HQ - 1;
-  // slot tables + Q/dO tiles + the q / dO / out rows of the G global queries (vil_attn_bwd_full)
   const int kv_tiles = (VIL_KV_PIPE && d->M == 32 && bc.kv_KT == 2) ? 4 : 2;       // Q + dO tiles (pipelined kernel: two pairs)
-  // slot tables (token, address term, lse, delta) + Q / dO tiles + the dS rows of the global queries + (kv_gspare) the global key's address terms
-  bc.kv_epre = bc.nqs > 7 * 64 ? 10 : 7;                   // straight-line rounds of the dK/dV prologue (template parameter)
-  const int nqsa = ((bc.nqs + 63) & ~63) > bc.kv_epre * 64 ? ((bc.nqs + 63) & ~63) : bc.kv_epre * 64;
-  bc.kv_wave_lds = ((nqsa * 16 + kv_tiles * 32 * d->M * 2 + (d->G > 1 ? 4 : 1) * 1024 + (bc.kv_gspare ? nqsa * 4 : 0) + 15) / 16) * 16;
   // waves per workgroup.  Two-wave workgroups (a workgroup's slot is held until its longest unit ends) measured 354 -> 350 us
   // at 56x56 and 271 -> 262 us at 96x96 alone (head_dim 32; 160 -> 181 us at head_dim 64) but LOST inside the training step
   // (313 -> 322 us at 56x56: twice the workgroups, twice the bias-image copies next to the other kernels' traffic): four.
 #ifndef VIL_KV_WPW
 #define VIL_KV_WPW 4
 #endif
-  bc.kv_wpw = VIL_KV_WPW;
-  while (bc.kv_wpw > 1 && (size_t)(c.tabsize + bc.kv_xsize) * 4 + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
+  // everything that depends on whether the global key rides in a spare column; returns the waves resident on a CU
+  auto layout = [&](bool gspare) {
+    bc.kv_gspare = gspare;
+    bc.nsplit = d->G > 0 ? (gspare ? 0 : (bc.glo_from_dq ? 1 : (bc.nch + 8) / 9)) : 0;
+    bc.units_kv_bh = bc.nch * bc.kv_NWP + bc.nsplit;
+    bc.gq_nrec = bc.nch * bc.kv_NWP + (gspare ? 0 : 1);
+    // streamed query slots: an own-key unit sees <= nact query chunks, a global-key unit its share of all chunks
+    const int qch = (d->G > 0 && !bc.glo_from_dq && bc.nsplit > 0) ? (bc.nch + bc.nsplit - 1) / bc.nsplit : 0;
+    bc.nqs = ((qch > g.nact ? qch : g.nact) * g.W2 + gq_rows + 31) & ~31;
+    // straight-line rounds of 64 slots in the dK/dV prologue (the kernel's template parameter): the whole table where it
+    // is short (random-shift training: 2 W^2 slots), 7 rounds at W = 7, 10 at W = 8; W = 12 finishes in a loop
+    bc.kv_epre = bc.nqs <= 3 * 64 ? 3 : (bc.nqs <= 7 * 64 ? 7 : 10);
+    const int nqsa = ((bc.nqs + 63) & ~63) > bc.kv_epre * 64 ? ((bc.nqs + 63) & ~63) : bc.kv_epre * 64;
+    // slot tables (token, address term, lse, delta) + Q / dO tiles + the dS rows of the global queries + (kv_gspare) the global key's address terms
+    bc.kv_wave_lds = ((nqsa * 16 + kv_tiles * 32 * d->M * 2 + (d->G > 1 ? 4 : 1) * 1024 + (gspare ? nqsa * 4 : 0) + 15) / 16) * 16;
+    bc.kv_wpw = VIL_KV_WPW;
+    const size_t tabb = (size_t)(c.tabsize + bc.kv_xsize) * 4;
+    while (bc.kv_wpw > 1 && tabb + (size_t)bc.kv_wpw * bc.kv_wave_lds > 160 * 1024) bc.kv_wpw >>= 1;
+    const size_t lds = tabb + (size_t)bc.kv_wpw * bc.kv_wave_lds;
+    const int wgs = lds > 160 * 1024 ? 0 : (int)((160 * 1024) / lds);
+    return wgs * bc.kv_wpw < 8 ? wgs * bc.kv_wpw : 8;           // (two waves per SIMD: the register budget)
+  };
+  // The spare-column scheme costs nqs * 4 bytes of LDS per wave (the global key's address terms): it is taken only where
+  // that does not cost resident waves (W = 12 at head_dim 64: 144 KB -> 164 KB per four-wave workgroup, i.e. two-wave
+  // workgroups and half a wave per SIMD -- 340 -> 518 us at 48x48, same-box A/B)
+  const int res0 = layout(false);
+  if (gspare_ok && layout(true) < res0) layout(false);
   const int groups = (bc.units_kv_bh + bc.kv_wpw - 1) / bc.kv_wpw;
 #ifndef VIL_KV_WGS
 #define VIL_KV_WGS 8192
@@ -1523,7 +1534,10 @@ int vil_mfma_bwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
     vil_prof_begin(VIL_K_MFMA_DKDV, s, w.dkdv_bytes(), w.dkdv_flops());
     BWD_SWITCH({
       constexpr int KT_ = (MD_ >= 3 ? 2 : (MD_ == 2 ? VIL_KV_KT32 : 4));
-      if (bc.kv_epre == 7) {
+      if (bc.kv_epre == 3) {
+        if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dkdv<TT_, MD_, KT_, 3>, lds)) return he;
+        k_mfma_bwd_dkdv<TT_, MD_, KT_, 3><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
+      } else if (bc.kv_epre == 7) {
         if (int he = vil_ensure_dyn_lds((const void*)k_mfma_bwd_dkdv<TT_, MD_, KT_, 7>, lds)) return he;
         k_mfma_bwd_dkdv<TT_, MD_, KT_, 7><<<dim3(grid), dim3(64 * bc.kv_wpw), lds, s>>>(p, c, bc);
       } else {

@@ -368,34 +368,6 @@ __device__ __forceinline__ int load_key_slots(const MfmaCfg& c, int ch, int lane
   wave_lds_fence();
   return nslots;
 }
-// The same without the dependent round trip (round 5): the slot count and the first EPRE x 64 table entries are requested
-// together (entries beyond the chunk's count exist in the workspace and are never walked); `ln` is a laundered lane id,
-// so that the one-off addresses do not become invariants of the caller's unit loop.
-template <int EPRE>
-__device__ __forceinline__ int load_key_slots_once(const MfmaCfg& c, int ch, int ln, int* s_koff, int* s_akey) {
-  const int2* src = c.key_slots + (int64_t)ch * c.NSP;
-  int2 e[EPRE];
-#pragma unroll
-  for (int u = 0; u < EPRE; ++u) e[u] = src[min(u * 64 + ln, c.NSP - 1)];
-  const int nslots = __builtin_amdgcn_readfirstlane(c.key_nslots[ch]);
-#pragma unroll
-  for (int u = 0; u < EPRE; ++u) {
-    const int sl = u * 64 + ln;
-    if (sl < c.NSP) { s_koff[sl] = e[u].x; s_akey[sl] = e[u].y; }
-  }
-  for (int s0 = EPRE * 64; s0 < nslots; s0 += 512) {
-    int2 e8[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) e8[u] = src[min(s0 + u * 64 + ln, nslots - 1)];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int sl = s0 + u * 64 + ln;
-      if (sl < nslots) { s_koff[sl] = e8[u].x; s_akey[sl] = e8[u].y; }
-    }
-  }
-  wave_lds_fence();
-  return nslots;
-}
 // One element e of head h's LDS-image bias table: bias * inv (backward passes: inv = 1 / scale, so that one multiply by
 // scale*log2e serves scores and bias alike; forward: inv = log2(e), the scores of its pre-scaled Q are log2-domain; masks and the exact window as VIL_MASK_VAL; one constant region per global token)
 __device__ __forceinline__ void table_element(const VilParams& p, const MfmaCfg& c, float* out, int h, int e, float inv) {
