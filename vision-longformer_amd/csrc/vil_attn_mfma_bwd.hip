@@ -827,18 +827,19 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
     float l8[EPRE], d8[EPRE];
 #pragma unroll
     for (int u = 0; u < EPRE; ++u) put_slot(u * 64 + ln, e[u], l8[u], d8[u]);
-    // slots beyond the first EPRE rounds (W > 8): three phases per four rounds
-    for (int s0 = EPRE * 64; s0 < bc.nqs; s0 += 256) {
+    // slots beyond the first EPRE rounds (W = 12; global-key owner units): three phases per four rounds
+    const int nq_u = glo ? bc.nqs : bc.nqs_own;
+    for (int s0 = EPRE * 64; s0 < nq_u; s0 += 256) {
       int2 e4[4];
       float l4[4], d4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) e4[u] = slots[min(s0 + u * 64 + ln, bc.nqs - 1)];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (s0 + u * 64 < bc.nqs) put_slot(s0 + u * 64 + ln, e4[u], l4[u], d4[u]);
+        if (s0 + u * 64 < nq_u) put_slot(s0 + u * 64 + ln, e4[u], l4[u], d4[u]);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (s0 + u * 64 < bc.nqs) { s_lse[s0 + u * 64 + ln] = l4[u] * LOG2E; s_dlt[s0 + u * 64 + ln] = d4[u]; }
+        if (s0 + u * 64 < nq_u) { s_lse[s0 + u * 64 + ln] = l4[u] * LOG2E; s_dlt[s0 + u * 64 + ln] = d4[u]; }
     }
     if (gi == 0) __syncthreads(); else wave_lds_fence();      // bias image (whole workgroup) and this wave's s_tok visible
     const int nsteps = (nchunks * W2 + Gu + 31) >> 5;
@@ -1352,7 +1353,11 @@ static void bwd_cfg(const VilAttnDesc* d, const MfmaCfg& c, BwdCfg& bc) {
     bc.nqs = ((qch > g.nact ? qch : g.nact) * g.W2 + gq_rows + 31) & ~31;
     // straight-line rounds of 64 slots in the dK/dV prologue (the kernel's template parameter): the whole table where it
     // is short (random-shift training: 2 W^2 slots), 7 rounds at W = 7, 10 at W = 8; W = 12 finishes in a loop
-    bc.kv_epre = bc.nqs <= 3 * 64 ? 3 : (bc.nqs <= 7 * 64 ? 7 : 10);
+    // ... sized for the chunks' own units (nact * W^2 slots); a global-key owner unit, whose table is a ninth of ALL
+    // chunks, finishes in the loop.  (Sized for the longest table, the 2-chunk units of random-shift training at W = 8
+    // filled ten rounds for 129 slots: dK/dV 90 -> 117 us at 48x48.)
+    bc.nqs_own = (g.nact * g.W2 + gq_rows + 31) & ~31;
+    bc.kv_epre = bc.nqs_own <= 3 * 64 ? 3 : (bc.nqs_own <= 7 * 64 ? 7 : 10);
     const int nqsa = ((bc.nqs + 63) & ~63) > bc.kv_epre * 64 ? ((bc.nqs + 63) & ~63) : bc.kv_epre * 64;
     // slot tables (token, address term, lse, delta) + Q / dO tiles + the dS rows of the global queries + (kv_gspare) the global key's address terms
     bc.kv_wave_lds = ((nqsa * 16 + kv_tiles * 32 * d->M * 2 + (d->G > 1 ? 4 : 1) * 1024 + (gspare ? nqsa * 4 : 0) + 15) / 16) * 16;

@@ -454,6 +454,7 @@ struct BwdCfg {
   // (g2l[0][h][g] against local keys, g2g[h][gq][gk] against global keys) comes out of constant regions the dK/dV
   // workgroups append to their LDS copy of the bias image:  [c.tabsize | G x gsz: g2l0 | G*G x gsz: g2g]
   int kv_xsize;       // floats appended (0 without global-query rows)
+  int nqs_own;        // slots of a chunk's own unit (nact * W^2 + global rows, padded to 32) <= nqs
   int kv_epre;        // straight-line slot rounds of the dK/dV prologue (7 or 10: the kernel's template parameter)
   int kv_span;        // largest key address term (W-1)*P + KT*HQ - 1: a global-query slot's address term is region + span
 };
