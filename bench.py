@@ -66,25 +66,29 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md "Chip-level parameters": 8.0 TB/s spec (6.29 TB/s measured copy rate)
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # same table: ~2.5 PF dense bf16 (2495 TF measured)
 F32_VALU_PEAK_TFLOPS = 157.3       # same table: peak FP32 (vector)
-# VALU roof of the attention kernels, stated from MI355X_MICROARCH.md:
-#   "Wave scheduling": a CU has 4 SIMD-32 units and a wave issues each VALU instruction over 2 cycles (32 lanes / cycle),
-#       so the vector pipes retire 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-slots / s (= F32 peak / 2 flops per
-#       FMA).  None of the per-score instructions below is a packed-f32 op (the guide's constants table prices
-#       v_pk_*_f32 beside MFMAs as an anti-lever), so no packing factor is applied.
-#   "Two waves per SIMD", item 3: a transcendental costs ~5/3 of a plain VALU issue, everything else 1.
-# Per-score instruction counts are the ones the compiled loops contain (tools/isa_mix.py --per-score over the
-# -save-temps listing of each kernel, 2048 scores per wave step; profiles/r05_isa_mix.txt), restricted to the
-# instructions no formulation of the step can drop:
-#   forward  v_exp 5/3 + fma (scale, -max) 1 + v_cvt_pk 1/2 + v_max3 1/3                          -> 3.5
-#   dQ       v_exp 5/3 + fma 1 + mul (P * (dP - delta)) 1 + v_cvt_pk 1/2 + v_cvt_i32 (histogram) 1  -> 5.17
-#   dK/dV    v_exp 5/3 + fma 1 + mul 1 + 2 x v_cvt_pk 1/2                                          -> 4.67
-VALU_LANE_SLOTS_PER_S = F32_VALU_PEAK_TFLOPS * 1e12 / 2
-TRANSCENDENTAL_SLOTS = 5.0 / 3.0
-VALU_SLOTS_PER_SCORE = {"k_mfma_fwd": round(TRANSCENDENTAL_SLOTS + 1 + 0.5 + 1 / 3, 2),
-                        "k_mfma_bwd_dq": round(TRANSCENDENTAL_SLOTS + 1 + 1 + 0.5 + 1, 2),
-                        "k_mfma_bwd_dkdv": round(TRANSCENDENTAL_SLOTS + 1 + 1 + 1, 2)}
+# VALU roof of the attention kernels: MEASURED issue rates of the instructions a score costs, not assumed ones.
+# tools/ubench/valu_rate.hip (profiles/r05_valu_rate_ubench.txt; 16 independent chains per wave, 1-8 waves per SIMD,
+# chip-level instructions / clock / SIMD from hipEvents) gives, in cycles of one SIMD's vector pipe per wave instruction:
+#   v_fma_f32 / v_mul_f32 2.75 (8 waves; the guide's "Wave scheduling": 2 cycles per VALU instruction on a SIMD-32),
+#   v_exp_f32 8.5 at any occupancy (3.1 x a plain instruction -- the guide's "~5/3" is its issue cost beside MFMAs, the
+#   pipe time is what bounds a loop that is 1/4 exponentials), v_cvt_pk_bf16_f32 5.1, v_max3_f32 4.6, v_pk_fma_f32 4.65
+#   (no gain over two v_fma_f32); for scale: v_mfma_f32_16x16x32_bf16 16.7, ds_read_b32 2.1 per CU.
+# Per score (one lane of one wave instruction), counting only what no formulation of the step can drop -- the compiled
+# loops' actual mixes are in profiles/r05_isa_mix.txt (tools/isa_mix.py --per-score) --:
+#   forward  v_exp 8.5 + fma (scale, -max) 2.75 + v_cvt_pk 5.1 / 2 + v_max3 4.6 / 3                       = 15.3 cycles / 64 scores
+#   dQ       v_exp 8.5 + fma 2.75 + mul (P * (dP - delta)) 2.75 + v_cvt_pk 5.1 / 2 + v_cvt_i32 (histogram) 2.75 = 19.3
+#   dK/dV    v_exp 8.5 + fma 2.75 + mul 2.75 + 2 x v_cvt_pk 5.1 / 2                                        = 19.1
+# roof = 1024 SIMDs x 2.4 GHz x 64 lanes / cycles.
+VALU_CYCLES = {"fma": 2.75, "exp": 8.5, "cvt_pk": 5.1, "max3": 4.6, "cvt_i32": 2.75}
+SIMD_LANE_RATE = 256 * 4 * 2.4e9 * 64            # scores per second if a score cost one pipe cycle per wave instruction
+VALU_CYCLES_PER_SCORE = {
+    "k_mfma_fwd": VALU_CYCLES["exp"] + VALU_CYCLES["fma"] + VALU_CYCLES["cvt_pk"] / 2 + VALU_CYCLES["max3"] / 3,
+    "k_mfma_bwd_dq": VALU_CYCLES["exp"] + 2 * VALU_CYCLES["fma"] + VALU_CYCLES["cvt_pk"] / 2 + VALU_CYCLES["cvt_i32"],
+    "k_mfma_bwd_dkdv": VALU_CYCLES["exp"] + 2 * VALU_CYCLES["fma"] + VALU_CYCLES["cvt_pk"]}
 for _k in ("fwd", "bwd_dq", "bwd_dkdv"):
-    VALU_SLOTS_PER_SCORE["k_dense_" + _k] = VALU_SLOTS_PER_SCORE["k_mfma_" + _k]
+    VALU_CYCLES_PER_SCORE["k_dense_" + _k] = VALU_CYCLES_PER_SCORE["k_mfma_" + _k]
+VALU_SLOTS_PER_SCORE = VALU_CYCLES_PER_SCORE      # (name kept for the per-shape table)
+VALU_LANE_SLOTS_PER_S = SIMD_LANE_RATE
 FLOPS_PER_SCORE = {"k_mfma_fwd": 4, "k_dense_fwd": 4, "k_mfma_bwd_dq": 6, "k_dense_bwd_dq": 6, "k_mfma_bwd_dkdv": 8,
                    "k_dense_bwd_dkdv": 8}       # x head_dim: the library's algorithmic flops are 4 / 6 / 8 * scores * M
 # the reference's published evaluation costs (README.md:211-221; unstated GPU, fp16 AMP): seconds per image
@@ -374,8 +378,8 @@ def roofline_of(config, B, shapes, tags, kernel="k_mfma_bwd_dkdv"):
             "mfma": {"achieved": k["TFLOPs"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": k["frac_mfma"]},
             "valu": {"achieved": k.get("Gscores_per_s"), "unit": "Gscores/s", "frac": k.get("frac_valu"),
                      "peak": round(VALU_LANE_SLOTS_PER_S / VALU_SLOTS_PER_SCORE[kernel] / 1e9, 1),
-                     "model": f"{VALU_SLOTS_PER_SCORE[kernel]} vector issue slots per score (transcendental = 5/3, MI355X_MICROARCH.md), "
-                              f"{VALU_LANE_SLOTS_PER_S / 1e12:.1f} T lane-slots/s"},
+                     "model": f"{VALU_CYCLES_PER_SCORE[kernel]:.1f} vector-pipe cycles per 64 scores, measured instruction rates "
+                              f"(profiles/r05_valu_rate_ubench.txt)"},
             "algorithmic_bytes_per_launch": k["bytes_per_launch"], "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
             "achieved_tflops": k["TFLOPs"], "frac_of_bf16_mfma_peak": k["frac_mfma"],
             "backward_unit_frac": shapes[lab].get("backward_unit", {}).get("frac_hbm")}
