@@ -227,6 +227,66 @@ def test_full_attention_fuzz_vs_oracle(c, dev):
     compare("fuzz full mfma/bf16 " + cid(c), got, ref, tol)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 32, 7, 21, 20, 0), (2, 2, 64, 7, 14, 14, 0), (1, 3, 32, 6, 18, 18, 3), (2, 2, 16, 4, 9, 10, 0),
+                                   (1, 2, 64, 12, 24, 24, 0)],
+                         ids=lambda s: "B%d_H%dM%d_W%d_%dx%d_m%d" % s)
+def test_forward_full_equals_two_call_path(shape, dev):
+    """vil_attn_fwd_full (round 5: the global token's query row as a spare query column of the forward pass + k_gq_merge)
+    against the two calls it replaces, vil_attn_fwd + vil_glo_attn_fwd (reference longformer2d.py:134-227), through the
+    C ABI on the same inputs: local rows within one bf16 step and their log-sum-exps to 1e-4 (the deferred-maximum
+    rescale is a wave-wide decision, so the extra column can move WHEN a local column rescales, not what it sums), the
+    global row and its lse within bf16 output tolerance (another summation order).  And VIL_E_BACKEND exactly where
+    the row cannot ride: two global tokens, W = 8 at head_dim 32 (no free query slot)."""
+    import ctypes
+    from vision_longformer_amd import _lib, ops
+    B, H, M, W, nx, ny, mode = shape
+    G, C, Nloc = 1, H * M, nx * ny
+    g = torch.Generator().manual_seed(GC.SEED + 9)
+    q = torch.randn(B, G + Nloc, C, generator=g).to(dev, torch.bfloat16)
+    kv = torch.randn(B, G + Nloc, 2 * C, generator=g).to(dev, torch.bfloat16)
+    tab = (torch.randn((4 * W - 1) ** 2, H, generator=g) * 0.5).to(dev)
+    g2l = (torch.randn(2, H, G, generator=g) * 0.5).to(dev)
+    g2g = (torch.randn(H, G, G, generator=g) * 0.5).to(dev)
+    cfg = ops._cfg(C, nx, ny, W, G, H, mode, 0, None)
+    k, v = kv[..., :C], kv[..., C:]
+    L = _lib.lib()
+    res = {}
+    for which in ("full", "two"):
+        out = torch.zeros(B, G + Nloc, C, dtype=torch.bfloat16, device=dev)
+        lse = torch.zeros(B, H, Nloc, device=dev)
+        lse_g = torch.zeros(B, H, G, device=dev)
+        d = ops._make_desc(q[:, G:], k, v, out[:, G:], cfg, "mfma")
+        ws = ops._workspace(d, 0, dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        P = ops._ptr
+        if which == "full":
+            _lib.check(L.vil_attn_fwd_full(ctypes.byref(d), P(q), P(k), P(v), P(tab), P(g2l), P(g2g), P(out), P(lse), P(lse_g), P(ws), st))
+        else:
+            _lib.check(L.vil_attn_fwd(ctypes.byref(d), P(q[:, G:]), P(k), P(v), P(tab), P(g2l[1]), P(out[:, G:]), P(lse), P(ws), st))
+            _lib.check(L.vil_glo_attn_fwd(ctypes.byref(d), P(q), P(k), P(v), P(g2g), P(g2l[0]), P(out), P(lse_g), st))
+        torch.cuda.synchronize()
+        res[which] = (out.float().cpu(), lse.cpu(), lse_g.cpu())
+    (of, lf, lgf), (ot, lt, lgt) = res["full"], res["two"]
+    dloc, dlse = float((of[:, G:] - ot[:, G:]).abs().max()), float((lf - lt).abs().max())
+    assert dloc <= 1.6e-2 and dlse <= 1e-4, f"local rows changed: {dloc:.2e} {dlse:.2e}"
+    eg = float((of[:, :G] - ot[:, :G]).abs().max())
+    el = float((lgf - lgt).abs().max())
+    report(f"     fwd_full vs fwd + glo_fwd {shape}: global row max|d| {eg:.2e}, lse_g max|d| {el:.2e}")
+    assert eg < 2e-2 and el < 2e-3
+    # where the row cannot ride
+    for (G2, W2_, M2) in ((2, 7, 32), (1, 8, 32)):
+        cfg2 = ops._cfg(H * M2, 16, 16, W2_, G2, H, 0, 0, None)
+        q2 = torch.zeros(1, G2 + 256, H * M2, dtype=torch.bfloat16, device=dev)
+        kv2 = torch.zeros(1, G2 + 256, 2 * H * M2, dtype=torch.bfloat16, device=dev)
+        o2 = torch.zeros_like(q2)
+        d2 = ops._make_desc(q2[:, G2:], kv2[..., :H * M2], kv2[..., H * M2:], o2[:, G2:], cfg2, "mfma")
+        ws2 = ops._workspace(d2, 0, dev)
+        rc = L.vil_attn_fwd_full(ctypes.byref(d2), ops._ptr(q2), ops._ptr(kv2[..., :H * M2]), ops._ptr(kv2[..., H * M2:]), None, None, None,
+                                 ops._ptr(o2), ops._ptr(torch.zeros(1, H, 256, device=dev)), ops._ptr(torch.zeros(1, H, G2, device=dev)),
+                                 ops._ptr(ws2), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        assert rc == _lib.VIL_E_BACKEND, (G2, W2_, M2, rc)
+
+
 # ---------------------------------------------------------------- module level vs golden
 def _load_module(c, dev, dtype):
     from vision_longformer_amd.longformer2d import Long2DSCSelfAttention
