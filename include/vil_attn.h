@@ -413,6 +413,16 @@ int vil_optim_plan_build(const VilOptimTensor* tensors, int ntensors, void* host
 int vil_optim_adamw_step(const void* plan_dev, int nblocks, float beta1, float beta2, float eps, int correct_bias,
                          int32_t* step_words, void* stream);
 int vil_optim_qhm_step(const void* plan_dev, int nblocks, float momentum, float nu, int32_t* step_words, void* stream);
+/* The same steps under torch.amp.GradScaler (fp16 training: reference src/engine.py:84-100, src/run_experiment.py:206;
+ * what scaler.step(optimizer) does with _amp_foreach_non_finite_check_and_unscale_ + a host-side `if found_inf`):
+ * `inv_scale` and `found_inf` are DEVICE floats (either may be NULL).  Gradients are multiplied by *inv_scale as they are
+ * loaded (16-bit gradients are unscaled in fp32, never in place); *found_inf != 0 skips the whole step -- parameters,
+ * state, working copies and the step count keep their values -- without a host synchronisation, so a captured step
+ * (hipGraph) carries the scaler. */
+int vil_optim_adamw_step_amp(const void* plan_dev, int nblocks, float beta1, float beta2, float eps, int correct_bias,
+                             int32_t* step_words, const float* inv_scale, const float* found_inf, void* stream);
+int vil_optim_qhm_step_amp(const void* plan_dev, int nblocks, float momentum, float nu, int32_t* step_words,
+                           const float* inv_scale, const float* found_inf, void* stream);
 
 #ifdef __cplusplus
 }

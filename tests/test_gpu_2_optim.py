@@ -316,3 +316,88 @@ def test_second_capture_with_other_addresses_raises(dev):
         with torch.cuda.graph(torch.cuda.CUDAGraph()):
             opt.step()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("name", ["adamw_recipe", "qhm_recipe"])
+def test_loss_scaled_step_matches_the_reference_fixtures_and_skips_on_inf(name, dev):
+    """fp16 training under torch.amp.GradScaler (reference src/engine.py:84-100): the optimizer declares
+    _step_supports_amp_scaling, so scaler.step() hands it `grad_scale` / `found_inf` device tensors and the HIP launch
+    unscales on load and skips on the device.  Gradients multiplied by 1024 and fed with grad_scale = 1024 reproduce the
+    reference fixtures bit for bit (a power of two: the unscaling is exact); a step with found_inf = 1 in between changes
+    nothing -- parameters, moments, step count -- so the trajectory afterwards is still the fixtures'."""
+    gold = np.load(GOLD)
+    kind, hyper, wds = OC.CASES[name]
+    params, grads = OC.make_inputs()
+    ps = [torch.nn.Parameter(p.clone().to(dev)) for p in params]
+    opt = _hip_opt(kind, [{"params": ps[0::2], "weight_decay": wds[0]}, {"params": ps[1::2], "weight_decay": wds[1]}], hyper)
+    assert getattr(opt, "_step_supports_amp_scaling", False)
+    scale = torch.tensor(1024.0, device=dev)
+    for k in range(OC.NSTEPS):
+        if k == 2:                                   # an overflowed step in the middle: skipped entirely
+            before = [p.detach().clone() for p in ps]
+            for p in ps:
+                p.grad = torch.full_like(p, float("inf"))
+            opt.grad_scale, opt.found_inf = scale, torch.ones(1, device=dev)
+            opt.step()
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, p.detach()) for a, p in zip(before, ps)), "a skipped step moved a parameter"
+        for p, g in zip(ps, grads[k]):
+            p.grad = (g * 1024.0).to(dev)
+        opt.grad_scale, opt.found_inf = scale, torch.zeros(1, device=dev)
+        opt.step()
+        del opt.grad_scale, opt.found_inf
+        for i, p in enumerate(ps):
+            _close(p.detach().float().cpu(), torch.from_numpy(gold[f"{name}/step{k + 1}/p{i}"]), f"{name} step {k + 1} tensor {i}")
+
+
+def test_grad_scaler_drives_the_master_weight_optimizer(dev):
+    """torch.amp.GradScaler.step(MasterWeightOptimizer): fp16 working copies, fp16 gradients living on them.  The
+    optimizer's own non-finite check must see those gradients (GradScaler's walk over param_groups would not), the scale
+    must back off after an overflow, and a clean step must equal the unscaled step."""
+    from vision_longformer_amd.engine import MasterWeightOptimizer
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = torch.nn.Linear(64, 64)
+            self.norm = torch.nn.LayerNorm(64)
+
+        def no_weight_decay(self):
+            return set()
+
+    def build():
+        torch.manual_seed(0)
+        m = Net().to(dev)
+        return m, MasterWeightOptimizer(m, kind="adamw", low_dtype=torch.float16, lr=1e-2)
+
+    g = torch.Generator().manual_seed(3)
+    gw = (torch.randn(64, 64, generator=g) * 1e-3).to(dev)
+    gb = (torch.randn(64, generator=g) * 1e-3).to(dev)
+    # reference run: unscaled gradients, plain step
+    m0, o0 = build()
+    m0.fc.weight.grad, m0.fc.bias.grad = gw.half(), gb.half()
+    m0.norm.weight.grad, m0.norm.bias.grad = gb.clone(), gb.clone()
+    o0.step()
+    # scaled run through GradScaler.step
+    m1, o1 = build()
+    scaler = torch.amp.GradScaler("cuda", init_scale=256.0, growth_interval=1000)
+    scaler.scale(torch.zeros((), device=dev))                 # (creates the scaler's state, as scale(loss) does in a loop)
+    m1.fc.weight.grad, m1.fc.bias.grad = (gw * 256).half(), (gb * 256).half()
+    m1.norm.weight.grad, m1.norm.bias.grad = gb * 256, gb * 256
+    scaler.step(o1)
+    scaler.update()
+    torch.cuda.synchronize()
+    for a, b in zip(o0.master, o1.master):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+    assert float(scaler.get_scale()) == 256.0
+    # overflow in a 16-bit gradient only: step skipped, scale halved
+    before = [mm.clone() for mm in o1.master]
+    m1.fc.weight.grad = torch.full_like(m1.fc.weight, float("inf"))
+    m1.fc.bias.grad = (gb * 256).half()
+    m1.norm.weight.grad, m1.norm.bias.grad = gb * 256, gb * 256
+    scaler.step(o1)
+    scaler.update()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(before, o1.master)), "the overflowed step was not skipped"
+    assert float(scaler.get_scale()) == 128.0, "the scale did not back off"

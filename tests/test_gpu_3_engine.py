@@ -376,3 +376,51 @@ def test_graphed_step_makes_differently_seeded_replicas_identical(dev, tmp_path)
     assert got["seeded_per_rank"] and got["differed_before"], "the ranks did not start from different weights"
     assert got["same"], "ranks diverged although the engine synchronised them"
     report(f"     differently seeded replicas after GraphedTrainStep(world=2) + 3 steps: identical = {got['same']}")
+
+
+def test_fp16_grad_scaler_step_graphed_equals_eager(dev):
+    """The reference's AMP recipe (src/engine.py:84-100, src/run_experiment.py:206: fp16 autocast + GradScaler) in the
+    build's own loop: engine.train_step(scaler=...) eagerly and GraphedTrainStep(scaler=...) as ONE hipGraph -- loss
+    scaling, the non-finite check over the fp16 gradients of the working copies, the device-side skip inside the HIP
+    optimizer launch and the scale update are all captured.  Same trajectory both ways; an overflowing loss scale (2^24:
+    fp16 gradients overflow) must skip steps and back the scale off, under replay, without a host decision."""
+    from vision_longformer_amd.engine import MasterWeightOptimizer, train_step, GraphedTrainStep
+    from vision_longformer_amd.msvit import MsViT
+    arch = "l1,h1,d32,n1,s1,g1,p4,f4,a0_l2,h2,d64,n1,s1,g1,p2,f4,a0_l3,h2,d64,n1,s0,g1,p2,f7,a0"
+    g = torch.Generator().manual_seed(13)
+    xs = [torch.randn(8, 3, 64, 64, generator=g).to(dev) for _ in range(4)]
+    ts = [torch.softmax(torch.randn(8, 10, generator=g), -1).to(dev) for _ in range(4)]
+
+    def run(graphed, init_scale):
+        torch.manual_seed(0)
+        m = MsViT(arch, img_size=64, num_classes=10, drop_path_rate=0.0, norm_embed=True, sharew=True).to(dev).train()
+        opt = MasterWeightOptimizer(m, kind="adamw", low_dtype=torch.float16, lr=1e-3, capturable=graphed)
+        scaler = torch.amp.GradScaler("cuda", init_scale=init_scale, growth_interval=1000)
+        if graphed:
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+            msd = [mm.clone() for mm in opt.master]
+            gs = GraphedTrainStep(m, opt, xs[0], ts[0], warmup=1, amp_dtype=torch.float16, scaler=scaler)
+            with torch.no_grad():
+                for k, v in m.state_dict().items():
+                    v.copy_(sd[k])
+                for mm, v in zip(opt.master, msd):
+                    mm.copy_(v)
+            opt.reset_state()
+            scaler._scale.fill_(init_scale)
+            scaler._growth_tracker.zero_()
+        losses = [float(gs(x, t) if graphed else train_step(m, opt, x, t, amp_dtype=torch.float16, scaler=scaler))
+                  for x, t in zip(xs, ts)]
+        torch.cuda.synchronize()
+        return losses, torch.cat([mm.detach().float().reshape(-1) for mm in opt.master]).cpu(), float(scaler.get_scale())
+
+    le, pe, se = run(False, 1024.0)
+    lg, pg, sg = run(True, 1024.0)
+    dl = max(abs(a - b) for a, b in zip(le, lg))
+    dp = float((pe - pg).abs().max())
+    report(f"     fp16 + GradScaler: graphed vs eager max|dloss| {dl:.3e} max|dmaster| {dp:.3e}; scale {se} / {sg}")
+    assert all(v == v and 0.0 < v < 30.0 for v in le + lg)
+    assert dl < 2e-2 and dp < 2e-2 and se == sg == 1024.0
+    # a loss scale that overflows fp16 gradients: steps are skipped on the device and the scale backs off, replay after replay
+    lo, po, so = run(True, 2.0 ** 24)
+    assert so < 2.0 ** 24, "the scale never backed off under graph replay"
+    assert all(v == v for v in lo)

@@ -39,7 +39,8 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_linear_wgrad_workspace_bytes", "vil_linear_wgrad", "vil_linear_wgrad_tune", "vil_linear_wgrad_set_plan", "vil_linear_wgrad_get_plan",
            "vil_resln_fwd", "vil_resln_bwd", "vil_gemm_workspace_bytes", "vil_gemm_bf16", "vil_gemm_tune", "vil_gemm_dgelu_bf16", "vil_gemm_gelu_bf16", "vil_gemm_tile_bf16", "vil_gemm_skinny_bf16", "vil_gemm_skinny_gelu_bf16",
            "vil_sc2d_qk", "vil_sc2d_av", "vil_sc2d_agrad", "vil_sc2d_mask",
-           "vil_optim_plan_bytes", "vil_optim_plan_build", "vil_optim_adamw_step", "vil_optim_qhm_step")
+           "vil_optim_plan_bytes", "vil_optim_plan_build", "vil_optim_adamw_step", "vil_optim_qhm_step",
+           "vil_optim_adamw_step_amp", "vil_optim_qhm_step_amp")
 
 
 class VilAttnDesc(ctypes.Structure):
@@ -187,6 +188,11 @@ def lib():
             L.vil_optim_adamw_step.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp, vp]
             L.vil_optim_qhm_step.restype = ci
             L.vil_optim_qhm_step.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, vp, vp]
+            if hasattr(L, "vil_optim_adamw_step_amp"):
+                L.vil_optim_adamw_step_amp.restype = ci
+                L.vil_optim_adamw_step_amp.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp, vp, vp, vp]
+                L.vil_optim_qhm_step_amp.restype = ci
+                L.vil_optim_qhm_step_amp.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
         L.vil_layernorm_workspace_bytes.restype = ctypes.c_size_t
         L.vil_layernorm_workspace_bytes.argtypes = [i64, ctypes.c_int]
         L.vil_layernorm_fwd.restype = ctypes.c_int

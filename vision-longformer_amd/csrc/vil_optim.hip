@@ -27,6 +27,9 @@ struct OptHyper {
   float b1, b2, eps; int correct_bias;     // AdamW
   float momentum, nu;                      // QHM
   int32_t* step_words;                     // [0] completed steps t, [1] arrival ticket of the running launch
+  // loss scaling (fp16 training with torch.amp.GradScaler, reference src/engine.py:84-100): device scalars, or null
+  const float* inv_scale;                  // gradients are multiplied by *inv_scale (1 / loss scale) on load
+  const float* found_inf;                  // != 0: a gradient was non-finite -- the step is skipped, the step count kept
 };
 
 typedef float of32x4 __attribute__((ext_vector_type(4)));
@@ -70,6 +73,11 @@ __global__ __launch_bounds__(OPT_THREADS) void k_optim(const char* plan, OptHype
   const OptBlock blk = blocks[blockIdx.x];
   const VilOptimTensor t = tens[blk.tensor];
   const float lr = t.lr_dev ? *t.lr_dev : t.lr;
+  // GradScaler semantics on the device (no host synchronisation, so the step stays capturable): a non-finite gradient
+  // anywhere skips the whole step -- parameters, moments, working copies and the step counter keep their values
+  const bool skip = hp.found_inf != nullptr && *hp.found_inf != 0.f;
+  const bool unscale = hp.inv_scale != nullptr;
+  const float gscale = unscale ? *hp.inv_scale : 1.f;
   // scalars of this step, in double like the reference's Python arithmetic, rounded once to fp32 (what
   // addcdiv_(value=...) / add_(alpha=...) do with a Python float)
   float neg_step = 0.f, neg_lrwd = 0.f;
@@ -101,6 +109,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_optim(const char* plan, OptHype
   float* S1 = (float*)t.state1;
   float* S2 = (float*)t.state2;
   auto update = [&](float p, float g, float& s1, float& s2) -> float {
+    if (unscale) g = g * gscale;               // (no multiply without a scaler: the fixtures of the unscaled step stay bit-exact)
     if (ALGO == 0) {
       s1 = s1 * b1 + g * omb1;
       s2 = s2 * hp.b2 + (g * g) * omb2;          // addcmul_(grad, grad, value): value * (t1 * t2)
@@ -123,7 +132,9 @@ __global__ __launch_bounds__(OPT_THREADS) void k_optim(const char* plan, OptHype
   const bool vec_ok = ((uintptr_t)t.param | (uintptr_t)t.state1 | (uintptr_t)(ALGO == 0 ? t.state2 : t.state1)) % 16 == 0 &&
                       (uintptr_t)t.grad % (t.grad_dtype == VIL_DTYPE_F32 ? 16 : 8) == 0 &&
                       (!t.low || (uintptr_t)t.low % 8 == 0);
-  if (vec_ok && base + OPT_BLOCK_ELEMS <= t.n) {
+  if (skip) {
+    // nothing to update
+  } else if (vec_ok && base + OPT_BLOCK_ELEMS <= t.n) {
     // full block: all 16-byte loads of the 4 iterations in flight before the first update (the kernel is a stream of
     // ~30 bytes per element; issued one iteration at a time it ran at 3.3 TB/s)
     of32x4 p[OPT_ITERS], s1[OPT_ITERS], s2[OPT_ITERS], g[OPT_ITERS];
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_optim(const char* plan, OptHype
     const int prev = __hip_atomic_fetch_add(&hp.step_words[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == (int)gridDim.x - 1) {
       __hip_atomic_store(&hp.step_words[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&hp.step_words[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!skip) __hip_atomic_fetch_add(&hp.step_words[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -224,18 +235,28 @@ static int optim_launch(int algo, const void* plan_dev, int nblocks, const OptHy
   return (int)hipGetLastError();
 }
 
-extern "C" int vil_optim_adamw_step(const void* plan_dev, int nblocks, float beta1, float beta2, float eps, int correct_bias,
-                                    int32_t* step_words, void* stream) {
+extern "C" int vil_optim_adamw_step_amp(const void* plan_dev, int nblocks, float beta1, float beta2, float eps, int correct_bias,
+                                        int32_t* step_words, const float* inv_scale, const float* found_inf, void* stream) {
   if (!(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f)) return VIL_E_SHAPE;
   OptHyper hp = {};
   hp.b1 = beta1; hp.b2 = beta2; hp.eps = eps; hp.correct_bias = correct_bias;
-  hp.step_words = step_words;
+  hp.step_words = step_words; hp.inv_scale = inv_scale; hp.found_inf = found_inf;
   return optim_launch(0, plan_dev, nblocks, hp, stream);
 }
 
-extern "C" int vil_optim_qhm_step(const void* plan_dev, int nblocks, float momentum, float nu, int32_t* step_words, void* stream) {
+extern "C" int vil_optim_adamw_step(const void* plan_dev, int nblocks, float beta1, float beta2, float eps, int correct_bias,
+                                    int32_t* step_words, void* stream) {
+  return vil_optim_adamw_step_amp(plan_dev, nblocks, beta1, beta2, eps, correct_bias, step_words, nullptr, nullptr, stream);
+}
+
+extern "C" int vil_optim_qhm_step_amp(const void* plan_dev, int nblocks, float momentum, float nu, int32_t* step_words,
+                                      const float* inv_scale, const float* found_inf, void* stream) {
   if (!(momentum >= 0.f && momentum <= 1.f)) return VIL_E_SHAPE;
   OptHyper hp = {};
-  hp.momentum = momentum; hp.nu = nu; hp.step_words = step_words;
+  hp.momentum = momentum; hp.nu = nu; hp.step_words = step_words; hp.inv_scale = inv_scale; hp.found_inf = found_inf;
   return optim_launch(1, plan_dev, nblocks, hp, stream);
+}
+
+extern "C" int vil_optim_qhm_step(const void* plan_dev, int nblocks, float momentum, float nu, int32_t* step_words, void* stream) {
+  return vil_optim_qhm_step_amp(plan_dev, nblocks, momentum, nu, step_words, nullptr, nullptr, stream);
 }

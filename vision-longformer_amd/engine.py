@@ -148,6 +148,12 @@ class MasterWeightOptimizer:
     over xGMI).  On the GPU the whole step is ONE kernel launch (csrc/vil_optim.hip): it reads the 16-bit gradients
     autograd produced, updates master + state, and writes the working copy in the same pass."""
 
+    # fp16 training under torch.amp.GradScaler (the reference's loop: src/engine.py:84-100): scaler.step(this) hands the
+    # scaler to step(), which checks EVERY gradient it consumes for non-finite values (the 16-bit gradients live on the
+    # working copies, where GradScaler's own walk over param_groups would not look), and the HIP launch unscales in fp32
+    # and skips on the device
+    _step_supports_amp_scaling = True
+
     def __init__(self, model, kind="adamw", low_dtype=torch.bfloat16, capturable=False, optimizer_module=None, **overrides):
         skip = model.no_weight_decay()
         names = {id(p): n for n, p in model.named_parameters()}
@@ -245,11 +251,37 @@ class MasterWeightOptimizer:
             self.opt.allocate()
             self.opt.after_capture()
 
+    def _amp_found_inf(self):
+        """device float: non-zero iff a gradient this optimizer is about to consume is inf / NaN (no host synchronisation)"""
+        grads = [p.grad for p in self.low + self.direct if p.grad is not None]
+        dev = grads[0].device
+        found = torch.zeros(1, dtype=torch.float32, device=dev)
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        by_dtype = {}
+        for g in grads:
+            by_dtype.setdefault(g.dtype, []).append(g)
+        for gl in by_dtype.values():
+            torch._amp_foreach_non_finite_check_and_unscale_(gl, found, one)      # scale 1: a pure check, gradients untouched
+        return found
+
     @torch.no_grad()
-    def step(self):
+    def step(self, grad_scaler=None):
         if self._fused:
+            if grad_scaler is not None:
+                # GradScaler.step() passed itself (its contract with optimizers that declare _step_supports_amp_scaling):
+                # record the verdict where scaler.update() reads it, hand scale and verdict to the launch
+                found = self._amp_found_inf()
+                grad_scaler._per_optimizer_states[id(self)]["found_inf_per_device"] = {found.device: found}
+                self.opt.grad_scale, self.opt.found_inf = grad_scaler._get_scale_async(), found
+                try:
+                    self.opt.step()
+                finally:
+                    del self.opt.grad_scale, self.opt.found_inf
+                return
             self.opt.step()                         # one launch: bf16 grads in, master + state + working copy out
             return
+        if grad_scaler is not None:
+            raise RuntimeError("loss scaling is part of the HIP optimizer step (no CPU path)")
         # CPU host-logic tests (oracle optimizer): gradients up-cast, step, working copies refreshed
         for p, m in zip(self.low, self.master):
             m.grad = None if p.grad is None else p.grad.float()
@@ -337,15 +369,21 @@ def soft_target_cross_entropy(logits, target):
     return torch.sum(-target * F.log_softmax(logits.float(), dim=-1), dim=-1).mean()
 
 
-def train_step(model, optimizer, images, targets, amp_dtype=torch.bfloat16):
+def train_step(model, optimizer, images, targets, amp_dtype=torch.bfloat16, scaler=None):
     """forward + backward (DDP all-reduce overlaps) + optimizer step; returns the
-    loss tensor without synchronising."""
+    loss tensor without synchronising.  `scaler`: a torch.amp.GradScaler for fp16 autocast -- the reference's loop
+    (src/engine.py:84-100: scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update())."""
     dev_type = images.device.type
     with torch.autocast(dev_type, dtype=amp_dtype, enabled=amp_dtype is not None):
         loss = soft_target_cross_entropy(model(images), targets)
     optimizer.zero_grad(set_to_none=True)
-    loss.backward()
-    optimizer.step()
+    if scaler is not None:
+        scaler.scale(loss).backward()
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        loss.backward()
+        optimizer.step()
     return loss.detach()
 
 
@@ -429,8 +467,14 @@ class GraphedTrainStep:
     kernels (VilAttnDesc.mode_dev), refreshed from the host before every replay."""
 
     def __init__(self, model, optimizer, images, targets, world=1, amp_dtype=torch.bfloat16, warmup=3, segments=3,
-                 force_segments=False, sync=True):
+                 force_segments=False, sync=True, scaler=None):
         self.model, self.opt, self.world, self.amp = model, optimizer, world, amp_dtype
+        # fp16 + torch.amp.GradScaler (the reference's AMP recipe): loss scaling, the non-finite check, the skipped step
+        # and the scale update are all device-side, so they are captured with the step (a skipped step costs a replay,
+        # not a host round trip).  The scaler's tensors must exist before capture: at least one warm-up step.
+        self.scaler = scaler
+        if scaler is not None and warmup < 1:
+            raise ValueError("GraphedTrainStep(scaler=...) needs warmup >= 1 (the scaler creates its state lazily)")
         # Replica consistency is the step's own job (DistributedDataParallel's constructor does it for the reference,
         # src/run_experiment.py:146-153): rank 0's parameters, buffers, masters and optimizer state before the warm-up
         # steps; rank 0's tuned plans after them; and a checksum over ranks before anything is captured.
@@ -521,7 +565,7 @@ class GraphedTrainStep:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode=mode):
                 self._segment(0, None)
-                self.opt.step()
+                self._opt_step()
             self.graphs.append(g)
         else:
             state, pool = None, None
@@ -534,7 +578,7 @@ class GraphedTrainStep:
             del state
             self.opt_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.opt_graph, pool=pool, capture_error_mode=mode):
-                self.opt.step()
+                self._opt_step()
         self.graph = self.graphs[0]
         if settle:
             settle()                                  # the optimizer's plan of the captured addresses is on the device
@@ -569,6 +613,8 @@ class GraphedTrainStep:
             self.loss = loss.detach()
             cuts = self.model._seg_points
             self.model._seg_points = None
+            if self.scaler is not None:
+                loss = self.scaler.scale(loss)
             if nseg == 1:
                 loss.backward()
                 return None
@@ -631,6 +677,13 @@ class GraphedTrainStep:
             out.append(round(t0.elapsed_time(t1) / reps, 4))
         return out
 
+    def _opt_step(self):
+        if self.scaler is not None:
+            self.scaler.step(self.opt)
+            self.scaler.update()
+        else:
+            self.opt.step()
+
     def _body(self, eager):
         """the same step launched op by op (warm-up, and the per-kernel profile of bench.py)"""
         self._draw_modes()
@@ -639,7 +692,7 @@ class GraphedTrainStep:
             state = self._segment(k, state)
             if self.segmented:
                 self._allreduce(self.seg_flats[k])
-        self.opt.step()
+        self._opt_step()
 
     def _sync_lr(self):
         """A scheduler that assigns param_group["lr"] = float between replays (the reference's pattern,

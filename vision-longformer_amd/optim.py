@@ -66,6 +66,10 @@ class _Bucket:
 class _VilOptimizer(Optimizer):
     _ALGO = None
     _HAS_STEP = False          # the reference class keeps a per-parameter `step` in its state (AdamW: yes, QHM: no)
+    # torch.amp.GradScaler (the reference trains with fp16 autocast + GradScaler: src/engine.py:84-100): scaler.step()
+    # sets `grad_scale` / `found_inf` (device tensors) on an optimizer that declares this, and leaves unscaling and the
+    # skip-on-inf decision to its step() -- here they happen inside the HIP launch, without a host synchronisation
+    _step_supports_amp_scaling = True
 
     def __init__(self, params, defaults):
         super().__init__(params, defaults)
@@ -88,11 +92,25 @@ class _VilOptimizer(Optimizer):
     def _state_for(self, p, group):
         raise NotImplementedError
 
-    def _launch(self, plan, group, stream):
+    def _launch(self, plan, group, stream, inv_scale, found_inf):
         raise NotImplementedError
 
     def _bucket_key(self, group):
         raise NotImplementedError
+
+    def _amp_scalars(self, device):
+        """(1 / loss scale, found_inf) as device float pointers, or (None, None) outside a GradScaler step"""
+        gs, fi = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+        vp = ctypes.c_void_p
+        inv = None
+        if gs is not None:
+            inv = gs.to(device=device, dtype=torch.float64).reciprocal().to(torch.float32).reshape(1)
+        if fi is not None and torch.is_tensor(fi):
+            fi = fi.to(device=device, dtype=torch.float32).reshape(-1)[:1].contiguous()
+        else:
+            fi = None
+        self._amp_keep = (inv, fi)                   # alive until the launch has been enqueued (and for a captured graph's pool)
+        return (vp(inv.data_ptr()) if inv is not None else None), (vp(fi.data_ptr()) if fi is not None else None)
 
     def _buckets(self):
         """param groups that share the kernel-wide hyper-parameters (one launch each; lr and weight decay are per
@@ -195,7 +213,8 @@ class _VilOptimizer(Optimizer):
             plan.steps = bucket.steps
             self._refresh(plan, entries)
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(self._launch(plan, groups[0], stream))
+            inv_scale, found_inf = self._amp_scalars(dev)
+            _lib.check(self._launch(plan, groups[0], stream, inv_scale, found_inf))
         return loss
 
     def _refresh(self, plan, entries):
@@ -367,11 +386,11 @@ class AdamW(_VilOptimizer):
             st["exp_avg_sq"] = self._new_state(p)
         return st["exp_avg"], st["exp_avg_sq"]
 
-    def _launch(self, plan, group, stream):
+    def _launch(self, plan, group, stream, inv_scale=None, found_inf=None):
         b1, b2 = group["betas"]
-        return _lib.lib().vil_optim_adamw_step(ctypes.c_void_p(plan.dev.data_ptr()), plan.nblocks, b1, b2, group["eps"],
-                                                int(bool(group["correct_bias"])),
-                                                ctypes.c_void_p(plan.steps.data_ptr()), stream)
+        return _lib.lib().vil_optim_adamw_step_amp(ctypes.c_void_p(plan.dev.data_ptr()), plan.nblocks, b1, b2, group["eps"],
+                                                    int(bool(group["correct_bias"])),
+                                                    ctypes.c_void_p(plan.steps.data_ptr()), inv_scale, found_inf, stream)
 
 
 class QHM(_VilOptimizer):
@@ -399,6 +418,6 @@ class QHM(_VilOptimizer):
             st["momentum_buffer"] = self._new_state(p)
         return st["momentum_buffer"], None
 
-    def _launch(self, plan, group, stream):
-        return _lib.lib().vil_optim_qhm_step(ctypes.c_void_p(plan.dev.data_ptr()), plan.nblocks, group["momentum"],
-                                              group["qhm_nu"], ctypes.c_void_p(plan.steps.data_ptr()), stream)
+    def _launch(self, plan, group, stream, inv_scale=None, found_inf=None):
+        return _lib.lib().vil_optim_qhm_step_amp(ctypes.c_void_p(plan.dev.data_ptr()), plan.nblocks, group["momentum"],
+                                                  group["qhm_nu"], ctypes.c_void_p(plan.steps.data_ptr()), inv_scale, found_inf, stream)
