@@ -233,8 +233,9 @@ def test_full_attention_fuzz_vs_oracle(c, dev):
 def test_forward_full_equals_two_call_path(shape, dev):
     """vil_attn_fwd_full (round 5: the global token's query row as a spare query column of the forward pass + k_gq_merge)
     against the two calls it replaces, vil_attn_fwd + vil_glo_attn_fwd (reference longformer2d.py:134-227), through the
-    C ABI on the same inputs: local rows within one bf16 step and their log-sum-exps to 1e-4 (the deferred-maximum
-    rescale is a wave-wide decision, so the extra column can move WHEN a local column rescales, not what it sums), the
+    C ABI on the same inputs: local rows within one bf16 step and their log-sum-exps to 5e-3 (the deferred-maximum
+    rescale is a wave-wide decision, so the extra column can move WHEN a local column rescales -- the probabilities are
+    rounded to bf16 against another maximum, not another set of keys), the
     global row and its lse within bf16 output tolerance (another summation order).  And VIL_E_BACKEND exactly where
     the row cannot ride: two global tokens, W = 8 at head_dim 32 (no free query slot)."""
     import ctypes
@@ -260,7 +261,11 @@ def test_forward_full_equals_two_call_path(shape, dev):
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         P = ops._ptr
         if which == "full":
-            _lib.check(L.vil_attn_fwd_full(ctypes.byref(d), P(q), P(k), P(v), P(tab), P(g2l), P(g2g), P(out), P(lse), P(lse_g), P(ws), st))
+            rc = L.vil_attn_fwd_full(ctypes.byref(d), P(q), P(k), P(v), P(tab), P(g2l), P(g2g), P(out), P(lse), P(lse_g), P(ws), st)
+            if W == 12 and M == 64:       # the column's image would cost resident waves there: declined, the caller makes two calls
+                assert rc == _lib.VIL_E_BACKEND
+                return
+            _lib.check(rc)
         else:
             _lib.check(L.vil_attn_fwd(ctypes.byref(d), P(q[:, G:]), P(k), P(v), P(tab), P(g2l[1]), P(out[:, G:]), P(lse), P(ws), st))
             _lib.check(L.vil_glo_attn_fwd(ctypes.byref(d), P(q), P(k), P(v), P(g2g), P(g2l[0]), P(out), P(lse_g), st))
@@ -268,7 +273,7 @@ def test_forward_full_equals_two_call_path(shape, dev):
         res[which] = (out.float().cpu(), lse.cpu(), lse_g.cpu())
     (of, lf, lgf), (ot, lt, lgt) = res["full"], res["two"]
     dloc, dlse = float((of[:, G:] - ot[:, G:]).abs().max()), float((lf - lt).abs().max())
-    assert dloc <= 1.6e-2 and dlse <= 1e-4, f"local rows changed: {dloc:.2e} {dlse:.2e}"
+    assert dloc <= 1.6e-2 and dlse <= 5e-3, f"local rows changed: {dloc:.2e} {dlse:.2e}"
     eg = float((of[:, :G] - ot[:, :G]).abs().max())
     el = float((lgf - lgt).abs().max())
     report(f"     fwd_full vs fwd + glo_fwd {shape}: global row max|d| {eg:.2e}, lse_g max|d| {el:.2e}")
