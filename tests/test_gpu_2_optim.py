@@ -346,8 +346,9 @@ def test_loss_scaled_step_matches_the_reference_fixtures_and_skips_on_inf(name, 
         opt.grad_scale, opt.found_inf = scale, torch.zeros(1, device=dev)
         opt.step()
         del opt.grad_scale, opt.found_inf
-        for i, p in enumerate(ps):
-            _close(p.detach().float().cpu(), torch.from_numpy(gold[f"{name}/step{k + 1}/p{i}"]), f"{name} step {k + 1} tensor {i}")
+        if f"{name}/step{k + 1}/p0" in gold.files:          # (the fixtures hold steps 1 and NSTEPS)
+            for i, p in enumerate(ps):
+                _close(p.detach().float().cpu(), torch.from_numpy(gold[f"{name}/step{k + 1}/p{i}"]), f"{name} step {k + 1} tensor {i}")
 
 
 def test_grad_scaler_drives_the_master_weight_optimizer(dev):
