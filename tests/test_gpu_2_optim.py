@@ -373,8 +373,9 @@ def test_grad_scaler_drives_the_master_weight_optimizer(dev):
         return m, MasterWeightOptimizer(m, kind="adamw", low_dtype=torch.float16, lr=1e-2)
 
     g = torch.Generator().manual_seed(3)
-    gw = (torch.randn(64, 64, generator=g) * 1e-3).to(dev)
-    gb = (torch.randn(64, generator=g) * 1e-3).to(dev)
+    # fp16-representable gradients: scaling by 256 and back is then exact, so the two runs must agree to rounding
+    gw = (torch.randn(64, 64, generator=g) * 0.05).half().float().to(dev)
+    gb = (torch.randn(64, generator=g) * 0.05).half().float().to(dev)
     # reference run: unscaled gradients, plain step
     m0, o0 = build()
     m0.fc.weight.grad, m0.fc.bias.grad = gw.half(), gb.half()
