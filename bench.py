@@ -143,7 +143,7 @@ def compact_line(full, detail_path=None):
         out["wgrad"] = {k: wg.get(k) for k in ("ms_per_step", "reduce_ms_per_step", "frac_hbm", "frac_mfma")}
     cm = full.get("comm")
     if cm:
-        out["comm"] = {k: cm.get(k) for k in ("ranks_in_communicator", "exposed_bytes_per_step", "bytes_per_step",
+        out["comm"] = {k: cm.get(k) for k in ("ranks_in_communicator", "total_bytes", "exposed_bytes", "segments_bytes",
                                                "allreduce_alone_ms_per_segment") if k in cm}
     out["final_loss"] = full.get("final_loss")
     out["detail"] = detail_path

@@ -59,7 +59,7 @@ def test_line_stays_under_the_limit_with_hostile_strings(canned):
     big["config"]["precision"] = "p" * 5000
     big["cpu_baseline"]["sample"] = "s" * 5000
     big["tertiary"] = big["tertiary"] * 20
-    big["comm"] = {"ranks_in_communicator": 8, "exposed_bytes_per_step": 1, "bytes_per_step": 2,
+    big["comm"] = {"ranks_in_communicator": 8, "exposed_bytes": 1, "total_bytes": 2, "segments_bytes": [1, 2, 3],
                    "allreduce_alone_ms_per_segment": [0.1] * 200}
     line = bench.compact_line(big, None)
     assert len(json.dumps(line)) <= bench.LINE_LIMIT
