@@ -14,4 +14,7 @@ cp $T/parity_report.txt profiles/${R}_parity_report.txt
 cp $T/ab_summary.txt profiles/${R}_attn_ab_vs_round4.txt
 cp $T/dense_bench.txt profiles/${R}_dense_bench.txt 2>/dev/null
 cp $T/valu_rate.txt profiles/${R}_valu_rate_ubench.txt 2>/dev/null
+cp $T/pmc/pipe_utilisation.txt profiles/${R}_pipe_utilisation.txt 2>/dev/null
+rm -f profiles/${R}_pmc_k_*.json
+python tools/pmc_all_summary.py $T/pmc profiles/${R}_pmc_ > /dev/null 2>&1
 ls profiles | grep "^${R}_" | wc -l

@@ -11,5 +11,6 @@ tail -2 $OUT/bench.err; echo "bench line bytes: $(tail -1 $OUT/bench.json | wc -
 AB_SHAPES=small_s1,small_s2,meddeep_s1_f7,meddeep_s2_f7,meddeep_s1_f8,meddeep_s2_f12,basedeep_s1_f6_rs,basedeep_s2_f8_rs bash tools/attn_ab.sh $OUT/ab.txt "small_s1,small_s2,meddeep_s1_f7,meddeep_s2_f7,meddeep_s1_f8,meddeep_s2_f12,basedeep_s1_f6_rs,basedeep_s2_f8_rs" 1 > $OUT/ab_summary.txt 2>&1
 cat $OUT/ab_summary.txt
 timeout 200 python tools/dense_bench.py --dense-only > $OUT/dense_bench.txt 2>&1
+bash tools/pmc_all.sh $OUT/pmc --only sc_56x56_m32,sc_28x28_m64,sc_96x96_m32,sc_48x48_m64,sc_48x48_w12_m64,sc_96x96_w6_m32_rs,dense_14x14,dense_24x24 > $OUT/pmc.txt 2>&1; tail -40 $OUT/pmc.txt
 grep -E "passed|failed" $OUT/pytest_gpu.log | tail -2
 tail -12 $OUT/session.log

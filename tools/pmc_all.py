@@ -18,7 +18,7 @@ import torch  # noqa: E402
 from vision_longformer_amd import _lib  # noqa: E402
 if os.environ.get("VIL_ATTN_LIB"):
     _lib.use_library_for_ab(os.environ["VIL_ATTN_LIB"])
-from vision_longformer_amd.ops import vil_local_attention, vil_dense_attention  # noqa: E402
+from vision_longformer_amd.ops import vil_full_attention, vil_dense_attention  # noqa: E402
 
 MARK_UNIT = 1 << 20
 
@@ -26,6 +26,9 @@ ATTN = {  # H, M, W, nx, ny, G, mode, B
     "sc_56x56_m32": (3, 32, 7, 56, 56, 1, 0, 128),
     "sc_28x28_m64": (3, 64, 7, 28, 28, 1, 0, 128),
     "sc_48x48_m64": (3, 64, 7, 48, 48, 1, 0, 32),
+    "sc_96x96_m32": (3, 32, 7, 96, 96, 1, 0, 32),
+    "sc_48x48_w12_m64": (3, 64, 12, 48, 48, 1, 0, 32),          # the one MFMA-bound shape (AI 648): Medium-Deep f8 / f12 stage 2
+    "sc_96x96_w6_m32_rs": (3, 32, 6, 96, 96, 1, 3, 32),         # Base-Deep stage 1, random shift
     "dense_14x14": (6, 64, 14, 14, 14, 1, -1, 128),
     "dense_24x24": (6, 64, 24, 24, 24, 1, -1, 32),
 }
@@ -63,14 +66,16 @@ def attn_case(name, dev, fwd_only=False):
             if not fwd_only:
                 out.backward(dout)
         return step
-    q = torch.randn(B, nx * ny, C, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
+    # the whole layer as the model runs it (round 5): local AND global rows, vil_attn_fwd_full / vil_attn_bwd_full
+    q = torch.randn(B, G + nx * ny, C, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
     kv = torch.randn(B, G + nx * ny, 2 * C, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
     table = (torch.randn((4 * W - 1) ** 2, H, generator=g) * 0.02).to(dev).requires_grad_(True)
-    g2l = (torch.randn(H, G, generator=g) * 0.02).to(dev).requires_grad_(True)
-    dout = torch.randn(B, nx * ny, C, generator=g).to(dev, torch.bfloat16)
+    g2l = (torch.randn(2, H, G, generator=g) * 0.02).to(dev).requires_grad_(True)
+    g2g = (torch.randn(H, G, G, generator=g) * 0.02).to(dev).requires_grad_(True)
+    dout = torch.randn(B, G + nx * ny, C, generator=g).to(dev, torch.bfloat16)
 
     def step():
-        out = vil_local_attention(q, kv, table, g2l, nx=nx, ny=ny, w=W, nglo=G, num_heads=H, mode=mode)
+        out = vil_full_attention(q, kv, table, g2l, g2g, nx=nx, ny=ny, w=W, nglo=G, num_heads=H, mode=mode)
         if not fwd_only:
             out.backward(dout)
     return step
