@@ -53,10 +53,10 @@ def main():
     meta = {}
     for pd in sorted(glob.glob(os.path.join(out, "p[0-9]"))):
         disp = load_pass(pd)
-        marks = sorted({d["grid"] for d in disp if "sign" in d["name"]})
+        marks = sorted({d["grid"] for d in disp if "sign_kernel" in d["name"]})
         cur = None
         for d in disp:
-            if "sign" in d["name"]:
+            if "sign_kernel" in d["name"]:
                 cur = marks.index(d["grid"])
                 continue
             k = kname(d["name"])
