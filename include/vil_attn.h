@@ -65,7 +65,9 @@ enum {
 };
 
 /* kernel family selection (desc.backend) */
-enum { VIL_BACKEND_AUTO = 0, VIL_BACKEND_SCALAR = 1, VIL_BACKEND_MFMA = 2 };
+enum { VIL_BACKEND_AUTO = 0, VIL_BACKEND_SCALAR = 1, VIL_BACKEND_MFMA = 2,
+       VIL_BACKEND_MFMA_WAVE = 3 /* the matrix-core family's wave-per-chunk kernels only (rounds 1-5; the chunk-workgroup
+                                    kernels of round 6 are skipped): the ablation row of tools/attn_ab.py */ };
 
 typedef struct VilAttnDesc {
   int32_t B, H, M;          /* images, heads, head_dim                                   */
@@ -134,6 +136,10 @@ int vil_glo_attn_bwd(const VilAttnDesc* d, const void* q_g, const void* k, const
                      const void* out_g, const void* dout_g, const float* lse_g,
                      const float* g2g, const float* g2l0, void* dq_g, void* dk, void* dv,
                      float* dg2g, float* dg2l0, void* stream);
+
+/* ---- tuning hook of the chunk-workgroup kernels (round 6; tools/ only): K / V ring depth (2..4) and chunks per workgroup
+ * of the following launches, 0 = the library's own choice. */
+int vil_attn_cw_set_shape(int ring_depth, int chunks_per_wg);
 
 /* ---- whole-layer forward (round 5): local rows AND the global token's query row from ONE pass over K / V.  The global
  * query rides in the forward kernel as a spare query column of every chunk, live against the chunk's own keys; a small

@@ -262,9 +262,8 @@ def test_forward_full_equals_two_call_path(shape, dev):
         P = ops._ptr
         if which == "full":
             rc = L.vil_attn_fwd_full(ctypes.byref(d), P(q), P(k), P(v), P(tab), P(g2l), P(g2g), P(out), P(lse), P(lse_g), P(ws), st)
-            if W == 12 and M == 64:       # the column's image would cost resident waves there: declined, the caller makes two calls
-                assert rc == _lib.VIL_E_BACKEND
-                return
+            # (W = 12 at head_dim 64: the wave-per-chunk kernels declined the ride -- the column's image cost resident waves --;
+            #  the chunk-workgroup kernels of round 6 carry it in a spare column like everywhere else)
             _lib.check(rc)
         else:
             _lib.check(L.vil_attn_fwd(ctypes.byref(d), P(q[:, G:]), P(k), P(v), P(tab), P(g2l[1]), P(out[:, G:]), P(lse), P(ws), st))

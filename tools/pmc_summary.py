@@ -10,7 +10,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
         if m:
             rest = name[m.end() + int(m.group(1)):]
             name = name[m.end():m.end() + int(m.group(1))] + "<" + rest.split("Ev")[0].lstrip("I") + ">"
-        if not ("k_mfma" in name or "k_scalar" in name or "k_delta" in name):
+        if not ("k_mfma" in name or "k_scalar" in name or "k_delta" in name or "k_cw" in name):
             continue
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}

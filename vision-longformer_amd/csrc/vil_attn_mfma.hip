@@ -508,6 +508,7 @@ static void gq_cfg(const VilAttnDesc* d, MfmaCfg& c) {
 }
 
 int vil_mfma_bwd_supported(const VilAttnDesc* d);
+int vil_mfma_launch_gq_merge(const VilAttnDesc* d, const VilParams& p, const MfmaCfg& c, hipStream_t s);
 size_t vil_mfma_bwd_workspace(const VilAttnDesc* d);
 
 int vil_mfma_launch_prep(const VilParams& p, const MfmaCfg& c, int row_stride_b, hipStream_t s) {
@@ -547,11 +548,19 @@ size_t vil_mfma_workspace(const VilAttnDesc* d, int pass) {
     gq_cfg(d, c);
     fl = (size_t)d->H * c.tabstride + vil_key_slots_floats(c, g.mx * g.my) + (size_t)d->B * d->H * g.mx * g.my * (d->M + 4) + 4;
   }
-  return fl * sizeof(float);
+  size_t bytes = fl * sizeof(float);
+  if (vil_cw_supported(d, 0) == VIL_OK) { const size_t b2 = vil_cw_workspace(d, 0); if (b2 > bytes) bytes = b2; }
+  return bytes;
 }
 
 int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   if (d->dtype == VIL_DTYPE_F32) return vil_f32_fwd(d, p, s);
+  // round 6: the chunk-workgroup kernels (vil_attn_cw.hip) wherever they apply; VIL_BACKEND_MFMA_WAVE keeps the
+  // wave-per-chunk kernels below selectable (A/B, and every shape the new family declines)
+  if (d->backend != VIL_BACKEND_MFMA_WAVE && vil_cw_supported(d, 0) == VIL_OK) {
+    const int r = vil_cw_fwd(d, p, s);
+    if (r != VIL_E_BACKEND) return r;
+  }
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   float* tabws = (float*)p.delta;          // workspace base
   c.tabws = tabws;
@@ -605,11 +614,14 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   }
   vil_prof_end(s);
   if ((e = (int)hipGetLastError())) return e;
-  if (c.gq_on) {
-    vil_prof_begin(VIL_K_GLO_FWD, s, 0, 0);
-    if (d->dtype == VIL_DTYPE_F16) k_gq_merge<_Float16><<<dim3((unsigned)(p.B * p.H)), dim3(1024), 0, s>>>(p, c);
-    else k_gq_merge<__bf16><<<dim3((unsigned)(p.B * p.H)), dim3(1024), 0, s>>>(p, c);
-    vil_prof_end(s);
-  }
+  if (c.gq_on) return vil_mfma_launch_gq_merge(d, p, c, s);
+  return (int)hipGetLastError();
+}
+
+int vil_mfma_launch_gq_merge(const VilAttnDesc* d, const VilParams& p, const MfmaCfg& c, hipStream_t s) {
+  vil_prof_begin(VIL_K_GLO_FWD, s, 0, 0);
+  if (d->dtype == VIL_DTYPE_F16) k_gq_merge<_Float16><<<dim3((unsigned)(p.B * p.H)), dim3(1024), 0, s>>>(p, c);
+  else k_gq_merge<__bf16><<<dim3((unsigned)(p.B * p.H)), dim3(1024), 0, s>>>(p, c);
+  vil_prof_end(s);
   return (int)hipGetLastError();
 }

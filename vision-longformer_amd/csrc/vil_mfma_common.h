@@ -278,7 +278,8 @@ __device__ __forceinline__ void shift_neighbour(const VilParams& p, int& adr1, i
 // grid see 4-6 of 9 neighbours).  Rows of the neighbourhood are distributed over lanes (one validity
 // test per row); a wave prefix sum places each row's keys.  Returns the padded slot count.
 __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg& c, int cm, int cn, int lane,
-                                               int row_stride_b, int* s_koff, int* s_akey, int adr1, int adc1) {
+                                               int row_stride_b, int* s_koff, int* s_akey, int adr1, int adc1,
+                                               bool own_first = false) {
   const VilGeom& g = p.g;
   const int W = g.W;
   const bool cyc = g.exact == -1;
@@ -294,7 +295,10 @@ __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg
     int na = 0, nb = 0, off = 0, ak = 0;
     bool real = true;
     if (rid < nrows) {
-      const int a = fdiv(rid, c.magicW), xt = rid - a * W;
+      const int a_ = fdiv(rid, c.magicW), xt = rid - a_ * W;
+      // own_first (chunk-workgroup family): the query chunk's own keys lead the list (neighbour 4 of the 3x3 order), so
+      // that the global query column riding in the pass is live in the first steps only
+      const int a = (own_first && g.nact == 9) ? (a_ == 0 ? 4 : (a_ <= 4 ? a_ - 1 : a_)) : a_;
       const int a3 = (a * 11) >> 5;                           // a / 3 for a in [0, 9)
       const int dr = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : adr1);
       const int dc = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : adc1);
@@ -416,6 +420,35 @@ static inline size_t vil_key_slots_floats(const MfmaCfg& c, int nch) {
 // LDS footprint), a multiple of 8 * H so that every (XCD, head) queue is served by the same number of workgroups, and no
 // more than the units can feed
 int vil_persistent_grid(int waves_per_simd, int waves_per_wg, size_t lds, int H, int64_t units_total);
+
+// ---- chunk-workgroup family (vil_attn_cw.hip): a chunk is NWP waves of 16 * QT query slots; a workgroup is one COLUMN --
+// a head and NCH chunks in lockstep -- bound to an XCD, streaming over that XCD's images
+struct CwCfg {
+  int QT;              // 16-column query tiles per wave (2 or 4)
+  int HQ;              // query groups (y = QT yq .. QT yq + QT - 1) per chunk row = ceil(W / QT)
+  int NWP;             // waves per chunk = ceil(W * HQ / 16)
+  int NCH;             // chunks per workgroup
+  int nch, ngrp;       // chunks / chunk groups per (image, head)
+  int lpt;             // chunks taken in order of decreasing work (chunk_of_rank): groups of equal step counts
+  int NSP;
+  int by_image;        // B >= 8: XCD x walks images x, x + 8, ...; else (image, head) pairs are dealt to the XCDs, one image per workgroup
+  int ncolx;           // columns of one XCD's list: H * ngrp (by_image) or ceil(B H / 8) * ngrp
+  int NS;              // image streams per column (stream s of XCD x: images x + 8 s, x + 8 (s + NS), ...)
+  int chunk_lds, koff_lds, ak_lds;   // LDS bytes per chunk: ring + tables; the two tables (whole 1 KB DMA pieces)
+  int abl;             // timing-ablation bits (VIL_CW_ABLATE builds only)
+  void* dbg;           // cycle-stamp records (VIL_CW_ABLATE builds only)
+  int akb;             // bias of the packed 16-bit address terms (bytes, multiple of 4)
+  int gq_on, gq_wp, gq_lj;     // vil_attn_fwd_full: the global query's column (wave part, lane column)
+  unsigned m_HQ, m_NWP, m_ncolx, m_ngrp;
+  int* koff;           // (nch, NSP) K / V row byte offset of every key slot (own chunk's keys first)
+  int* akey;           // (nch, NSP) halfwords: bias address term + akb of every key slot, in per-lane order (k_cw_prep)
+  int* nslots;         // (nch) padded slot count
+  int* nown;           // (nch) key slots of the chunk's own keys (slots [G, G + nown))
+  unsigned* redo;      // (workgroups) images the fast kernel's workgroup hands to the exact kernel (bit j: its j-th image)
+};
+int vil_cw_supported(const VilAttnDesc* d, int pass);
+size_t vil_cw_workspace(const VilAttnDesc* d, int pass);
+int vil_cw_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s);
 
 // host: fills the launch configuration for a descriptor
 bool vil_mfma_make_cfg(const VilAttnDesc* d, MfmaCfg& c);
