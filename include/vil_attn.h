@@ -66,8 +66,10 @@ enum {
 
 /* kernel family selection (desc.backend) */
 enum { VIL_BACKEND_AUTO = 0, VIL_BACKEND_SCALAR = 1, VIL_BACKEND_MFMA = 2,
-       VIL_BACKEND_MFMA_WAVE = 3 /* the matrix-core family's wave-per-chunk kernels only (rounds 1-5; the chunk-workgroup
-                                    kernels of round 6 are skipped): the ablation row of tools/attn_ab.py */ };
+       VIL_BACKEND_MFMA_WAVE = 3, /* the matrix-core family's wave-per-chunk kernels only (rounds 1-5; the chunk-workgroup
+                                    kernels of round 6 are skipped): the ablation row of tools/attn_ab.py */
+       VIL_BACKEND_MFMA_CW = 4   /* the matrix-core family with the chunk-workgroup forward kernels wherever they can run
+                                    (AUTO / MFMA take them only where they measured faster) */ };
 
 typedef struct VilAttnDesc {
   int32_t B, H, M;          /* images, heads, head_dim                                   */

@@ -91,7 +91,7 @@ def main():
                 _lib.check(_lib.lib().vil_attn_cw_set_shape(v[0], v[1] if len(v) > 1 else 0))
                 if len(v) > 2:          # timing ablation bits (a -DVIL_CW_ABLATE build loaded through VIL_ATTN_LIB)
                     _lib.lib().vil_attn_cw_set_ablation(v[2])
-            r_new, t_new = run(shape, "mfma", full, a.bwd, a.reps)
+            r_new, t_new = run(shape, "mfma_cw", full, a.bwd, a.reps)
             report(name, shape, full, cw, r_new, r_old, t_new, t_old)
 
 

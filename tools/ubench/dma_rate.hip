@@ -9,14 +9,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)0, 0x7fffffff, 0x00020000);
 }
 // MODE 0: LDS-DMA, rows scattered; 1: LDS-DMA contiguous KB; 2: global_load to VGPR, rows scattered; 3: VGPR contiguous;
-// 4: LDS-DMA, 8 whole 128-byte lines (2.67 token rows of 384 B: K | V of all three heads)
+// 4: LDS-DMA, 8 whole 128-byte lines (2.67 token rows of 384 B: K | V of all three heads);
+// 5: LDS-DMA, 16 half lines like 0, but the waves of a workgroup come in pairs that request the two halves of the SAME lines
+//    at the same time (two heads of one chunk in one workgroup: does the CU's L1 merge them?)
 template <int MODE, int INFLIGHT>
 __global__ __launch_bounds__(256) void k(const char* src, int iters, int region_rows, int stride, float* sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const __amdgpu_buffer_rsrc_t rs = mk(src);
   char* dst = smem + wave * (INFLIGHT * 1024);
-  unsigned seed = blockIdx.x * 977 + wave * 131;
+  unsigned seed = blockIdx.x * 977 + (MODE == 5 ? (wave >> 1) : wave) * 131;
   float acc = 0.f;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -25,18 +27,20 @@ __global__ __launch_bounds__(256) void k(const char* src, int iters, int region_
       const int base_row = (seed >> 8) % (region_rows - 64);
       int off;
       if (MODE == 0 || MODE == 2) off = (base_row + (lane >> 2) * 3) * stride + (lane & 3) * 16;      // 16 rows, 3 rows apart
+      else if (MODE == 5) off = (base_row + (lane >> 2) * 3) * 128 + (wave & 1) * 64 + (lane & 3) * 16;   // lines of 128 B, this wave's half
       else if (MODE == 4) off = (base_row + (lane / 24) * 5) * 384 + (lane % 24) * 16;              // 2.67 rows of 384 B, 5 rows apart
       else off = base_row * stride + lane * 16;
-      if (MODE < 2 || MODE == 4)
+      if (MODE < 2 || MODE >= 4)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, off, 0, 0, 0);
       else {
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
         acc += __builtin_bit_cast(float, v[0]);
       }
     }
-    if (MODE < 2 || MODE == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MODE < 2 || MODE >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MODE == 5) __syncthreads();
   }
-  if (MODE < 2 || MODE == 4) acc = ((float*)dst)[lane];
+  if (MODE < 2 || MODE >= 4) acc = ((float*)dst)[lane];
   if (acc == 123.456f) sink[0] = acc;
 }
 template <int MODE, int INFLIGHT> void run(const char* d, float* sink, int wgs, const char* name, int rows = 4096) {
@@ -66,6 +70,8 @@ int main() {
     run<4, 2>(d, sink, wgs, "LDS-DMA 8 whole lines");
     run<0, 2>(d, sink, wgs, "LDS-DMA 16 rows x 64 B, 200 MB", 1000000);
     run<4, 2>(d, sink, wgs, "LDS-DMA 8 whole lines, 200 MB", 500000);
+    run<5, 2>(d, sink, wgs, "LDS-DMA half lines, paired waves");
+    run<5, 2>(d, sink, wgs, "LDS-DMA half lines, paired, 200 MB", 1000000);
   }
   return 0;
 }

@@ -25,7 +25,7 @@ def use_library_for_ab(path):
     LIB_PATH, _AB_LIBRARY = path, True
 
 DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F64 = 0, 1, 2, 3
-BACKEND_AUTO, BACKEND_SCALAR, BACKEND_MFMA, BACKEND_MFMA_WAVE = 0, 1, 2, 3
+BACKEND_AUTO, BACKEND_SCALAR, BACKEND_MFMA, BACKEND_MFMA_WAVE, BACKEND_MFMA_CW = 0, 1, 2, 3, 4
 ABI_VERSION = 2
 
 EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_attn_workspace_bytes",

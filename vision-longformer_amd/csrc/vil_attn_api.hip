@@ -44,7 +44,7 @@ static int check_common(const VilAttnDesc* d) {
 static int pick_backend(const VilAttnDesc* d, int pass) {
   const int want = d->backend;
   if (want == VIL_BACKEND_SCALAR) return vil_scalar_supported(d) == VIL_OK ? VIL_BACKEND_SCALAR : 0;
-  if (want == VIL_BACKEND_MFMA || want == VIL_BACKEND_MFMA_WAVE) return vil_mfma_supported(d, pass) == VIL_OK ? VIL_BACKEND_MFMA : 0;
+  if (want == VIL_BACKEND_MFMA || want == VIL_BACKEND_MFMA_WAVE || want == VIL_BACKEND_MFMA_CW) return vil_mfma_supported(d, pass) == VIL_OK ? VIL_BACKEND_MFMA : 0;
   if (vil_mfma_supported(d, pass) == VIL_OK) return VIL_BACKEND_MFMA;
   if (vil_scalar_supported(d) == VIL_OK) return VIL_BACKEND_SCALAR;
   return 0;
@@ -54,7 +54,7 @@ extern "C" int vil_attn_check(const VilAttnDesc* d) {
   int e = check_common(d);
   if (e) return e;
   if (d->backend == VIL_BACKEND_SCALAR) return vil_scalar_supported(d);
-  if (d->backend == VIL_BACKEND_MFMA || d->backend == VIL_BACKEND_MFMA_WAVE) {
+  if (d->backend == VIL_BACKEND_MFMA || d->backend == VIL_BACKEND_MFMA_WAVE || d->backend == VIL_BACKEND_MFMA_CW) {
     e = vil_mfma_supported(d, 0);
     return e ? e : vil_mfma_supported(d, 1);
   }

@@ -159,23 +159,27 @@ __global__ __launch_bounds__(512, cw_occ(MD, QT)) void k_cw_fwd(VilParams p, Mfm
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lj = lane & 15, lg = lane >> 4;
   const int W = g.W;
-  // wave -> (chunk slot of the workgroup, query part of the chunk)
-  const int cslot = fdiv(wave, w.m_NWP), wp = wave - cslot * w.NWP;
+  // wave -> (slot of the workgroup = (chunk slot, head slot), query part of the chunk).  The HPW heads of a chunk sit in
+  // one workgroup where a K / V row is half a cache line (head_dim 32): their requests for the two halves of a line are
+  // issued in the same step and the CU's L1 merges them (tools/ubench/dma_rate.hip: 23 - 27 TB/s instead of 16.7).
+  const int slot_ = fdiv(wave, w.m_NWP), wp = wave - slot_ * w.NWP;
+  const int cslot = fdiv(slot_, w.m_HPW), hslot = slot_ - cslot * w.HPW;
 
   // ---- the column and its image stream
   const int xcd = blockIdx.x & 7, kblk = blockIdx.x >> 3;
   const int strm = fdiv(kblk, w.m_ncolx), col = kblk - strm * w.ncolx;
   int h, grp, b0, bstride, nimg;
   if (w.by_image) {
-    // chunk-group-major, head-minor: the H workgroups of a group are dispatched back to back (both halves of a K / V line)
-    grp = fdiv(col, c.m_H); h = col - grp * p.H;
+    // chunk-group-major, head-group-minor: the workgroups of a chunk group's heads are dispatched back to back
+    grp = fdiv(col, w.m_NHG); h = (col - grp * w.NHG) * w.HPW + hslot;
     b0 = xcd + 8 * strm; bstride = 8 * w.NS;
     nimg = b0 < p.B ? (p.B - b0 + bstride - 1) / bstride : 0;
   } else {
+    // (image, head group) pairs dealt to the XCDs
     const int pj = fdiv(col, w.m_ngrp); grp = col - pj * w.ngrp;
     const int pi = xcd + 8 * pj;
-    b0 = pi / p.H; h = pi - b0 * p.H; bstride = 0;
-    nimg = pi < p.B * p.H ? 1 : 0;
+    b0 = pi / w.NHG; h = (pi - b0 * w.NHG) * w.HPW + hslot; bstride = 0;
+    nimg = pi < p.B * w.NHG ? 1 : 0;
   }
   if (nimg == 0) return;
   unsigned redo_mask = 0u;
@@ -195,14 +199,15 @@ __global__ __launch_bounds__(512, cw_occ(MD, QT)) void k_cw_fwd(VilParams p, Mfm
   }
   const int nown = active ? __builtin_amdgcn_readfirstlane(w.nown[ch]) : 0;
 
-  // ---- LDS: [bias image of head h | NCH x (ring of D x (K tile, V tile) | row offsets | address terms) | flag]
-  float* tab = (float*)smem;
-  const unsigned tab_lds = lds_addr(smem);
-  const int ring_off = c.tabsize * 4 + cslot * w.chunk_lds;
+  // ---- LDS: [HPW bias images | NCH x HPW rings of D x (K tile, V tile) | NCH x (row offsets | address terms) | flag]
+  const unsigned lds0 = lds_addr(smem);
+  const int tab_off = hslot * c.tabsize * 4;
+  const unsigned tab_lds = lds0 + tab_off;
+  const int ring_off = w.HPW * c.tabsize * 4 + slot_ * (D * SLOTB);
   char* ring = smem + ring_off;
-  const int koff_lds = ring_off + D * SLOTB;               // [NSP] ints (whole 1 KB pieces)
+  const int koff_lds = w.HPW * c.tabsize * 4 + w.NCH * w.HPW * (D * SLOTB) + cslot * (w.koff_lds + w.ak_lds);   // [NSP] ints (whole 1 KB pieces)
   const int ak_lds = koff_lds + w.koff_lds;                // [NSP] halfwords, per-lane order (k_cw_prep)
-  unsigned* flag = (unsigned*)(smem + (size_t)c.tabsize * 4 + (size_t)w.NCH * w.chunk_lds);
+  unsigned* flag = (unsigned*)(smem + (size_t)w.HPW * c.tabsize * 4 + (size_t)w.NCH * (w.HPW * (D * SLOTB) + w.koff_lds + w.ak_lds));
 
   const int Nloc = g.nx * g.ny;
   const int kstride_b = (int)p.k_st * 2;
@@ -218,16 +223,16 @@ __global__ __launch_bounds__(512, cw_occ(MD, QT)) void k_cw_fwd(VilParams p, Mfm
   unsigned kaddr[MK];
 #pragma unroll
   for (int ks = 0; ks < MK; ++ks)
-    kaddr[ks] = tab_lds + ring_off + lj * ROWB + (((ks * 32 + lg * 8) * 2) ^ tile_swz<MD>(lj));
+    kaddr[ks] = lds0 + ring_off + lj * ROWB + (((ks * 32 + lg * 8) * 2) ^ tile_swz<MD>(lj));
   // V^T through the transposed read: row hf * 16 + lg * 4 + lj / 4, 8 bytes at (dt * 32 + (lj & 3) * 8) ^ swizzle
   unsigned vaddr[MD];
 #pragma unroll
   for (int dt = 0; dt < MD; ++dt) {
     const int row = lg * 4 + (lj >> 2);
-    vaddr[dt] = tab_lds + ring_off + TILE + row * ROWB + ((dt * 32 + (lj & 3) * 8) ^ tile_swz<MD>(row));
+    vaddr[dt] = lds0 + ring_off + TILE + row * ROWB + ((dt * 32 + (lj & 3) * 8) ^ tile_swz<MD>(row));
   }
-  const unsigned akaddr = tab_lds + ak_lds + lg * 16;            // + st * 64: this lane's eight address terms of step st
-  const unsigned kfaddr = tab_lds + koff_lds + drow * 4;         // + (st * 32 + sub * RPP) * 4: row offset of a DMA piece's row
+  const unsigned akaddr = lds0 + ak_lds + lg * 16;            // + st * 64: this lane's eight address terms of step st
+  const unsigned kfaddr = lds0 + koff_lds + drow * 4;         // + (st * 32 + sub * RPP) * 4: row offset of a DMA piece's row
   // constant A operand whose row 0 is all ones: D[0][j] = sum_k P^T[k][j]
   X8 ones;
 #pragma unroll
@@ -258,15 +263,20 @@ __global__ __launch_bounds__(512, cw_occ(MD, QT)) void k_cw_fwd(VilParams p, Mfm
     const __amdgpu_buffer_rsrc_t trs = make_rsrc_n(koff_ch, (unsigned)c.NSP * 4u);
     const __amdgpu_buffer_rsrc_t ars = make_rsrc_n((const unsigned short*)w.akey + (int64_t)ch * c.NSP, (unsigned)c.NSP * 2u);
     const int npk = w.koff_lds >> 10, npa = w.ak_lds >> 10;
-    for (int i = wp; i < npk + npa; i += w.NWP) {
+    for (int i = hslot * w.NWP + wp; i < npk + npa; i += w.NWP * w.HPW) {      // (one copy per chunk slot: its heads' waves share it)
       if (i < npk) cw_dma16(trs, smem + koff_lds + i * 1024, i * 1024 + lane * 16);
       else cw_dma16(ars, smem + ak_lds + (i - npk) * 1024, (i - npk) * 1024 + lane * 16);
     }
   }
   {
-    const f32x4* src = (const f32x4*)(c.tabws + (int64_t)h * c.tabstride);
-    // (the image is in log2 units; the exact kernel works in score units: one multiply by scale * log2 e serves scores and bias)
-    for (int i = tid; i < (c.tabsize >> 2); i += blockDim.x) ((f32x4*)tab)[i] = SAFE ? src[i] * (1.0f / c1) : src[i];
+    // the bias images of the workgroup's HPW heads (in log2 units; the exact kernel works in score units: one multiply by
+    // scale * log2 e serves scores and bias)
+    const int h0 = h - hslot;
+    for (int i = tid; i < w.HPW * (c.tabsize >> 2); i += blockDim.x) {
+      const int hh = fdiv(i, w.m_tab4), e4 = i - hh * (c.tabsize >> 2);
+      const f32x4 v = ((const f32x4*)(c.tabws + (int64_t)(h0 + hh) * c.tabstride))[e4];
+      ((f32x4*)smem)[i] = SAFE ? v * (1.0f / c1) : v;
+    }
     if (tid == 0) *flag = 0u;
   }
 
@@ -529,12 +539,12 @@ __global__ __launch_bounds__(512, cw_occ(MD, QT)) void k_cw_fwd(VilParams p, Mfm
 // ===================================================================== host side
 // launch-shape override (tools/cw_check.py: image streams per column of the next launches; 0 = the library's own choice).
 // Process-global like the other tuning hooks of the library; the product never calls it.
-static int g_cw_streams = 0, g_cw_qt = 0, g_cw_nch = 0, g_cw_abl = 0;
+static int g_cw_streams = 0, g_cw_qt = 0, g_cw_nch = 0, g_cw_hpw = 0, g_cw_abl = 0;
 extern "C" int vil_attn_cw_set_shape(int streams, int chunks_per_wg) {
-  // chunks_per_wg: chunks per workgroup + 10 * query tiles per wave (0: the library's choice of either)
-  const int nch = chunks_per_wg % 10, qt = chunks_per_wg / 10;
-  if (streams < 0 || chunks_per_wg < 0 || nch > 4 || (qt != 0 && qt != 1 && qt != 2)) return VIL_E_SHAPE;
-  g_cw_streams = streams; g_cw_nch = nch; g_cw_qt = qt;
+  // chunks_per_wg: chunks per workgroup + 10 * query tiles per wave + 100 * heads per workgroup (0: the library's choice)
+  const int nch = chunks_per_wg % 10, qt = (chunks_per_wg / 10) % 10, hpw = chunks_per_wg / 100;
+  if (streams < 0 || chunks_per_wg < 0 || nch > 4 || (qt != 0 && qt != 1 && qt != 2) || hpw > 8) return VIL_E_SHAPE;
+  g_cw_streams = streams; g_cw_nch = nch; g_cw_qt = qt; g_cw_hpw = hpw;
   return VIL_OK;
 }
 #ifdef VIL_CW_ABLATE
@@ -547,7 +557,7 @@ extern "C" int vil_attn_cw_set_debug(void* buf) { g_cw_dbg = buf; return VIL_OK;
 #define VIL_CW_QT 2
 #endif
 static size_t cw_lds_bytes(const VilAttnDesc* d, const MfmaCfg& c, const CwCfg& w) {
-  return (size_t)c.tabsize * 4 + (size_t)w.NCH * (CW_D * 2 * (32 * d->M * 2) + w.koff_lds + w.ak_lds) + 16;
+  return (size_t)w.HPW * c.tabsize * 4 + (size_t)w.NCH * (w.HPW * CW_D * 2 * (32 * d->M * 2) + w.koff_lds + w.ak_lds) + 16;
 }
 static bool cw_make_cfg(const VilAttnDesc* d, const MfmaCfg& c, CwCfg& w) {
   memset(&w, 0, sizeof(w));
@@ -557,10 +567,17 @@ static bool cw_make_cfg(const VilAttnDesc* d, const MfmaCfg& c, CwCfg& w) {
   w.HQ = (W + w.QT - 1) / w.QT;
   w.NWP = (W * w.HQ + 15) / 16;
   w.nch = g.mx * g.my;
-  // chunks per workgroup: two at head_dim 32 (one bias image per four waves: 20 resident waves per CU), one at head_dim 64
-  // (measured: 74 against 76 - 89 us at 28 x 28)
-  int nchw = g_cw_nch > 0 ? g_cw_nch : (d->M <= 32 ? VIL_CW_NCH : 1);
-  while (nchw > 1 && nchw * w.NWP > 8) nchw >>= 1;
+  // heads per workgroup: one.  (Putting the H heads of a chunk into one lockstep workgroup, so that their requests for the two
+  // halves of a K / V cache line meet in the CU's L1 -- the micro-benchmark's 23 - 27 TB/s instead of 16.7 -- LOSES in the
+  // kernel: 244 - 267 us against 204 us at ViL-Small stage 1, 195 - 221 against 158 us at 96 x 96: six waves per barrier and
+  // three bias images per workgroup cost more than the L2 path gives back.  Kept selectable: vil_attn_cw_set_shape.)
+  int hpw = 1;
+  if (g_cw_hpw > 0 && d->H % g_cw_hpw == 0) hpw = g_cw_hpw;
+  if (hpw * w.NWP > 8) hpw = 1;
+  w.HPW = hpw; w.NHG = d->H / hpw;
+  // chunks per workgroup: two at head_dim 32 with one head per workgroup (one bias image per four waves), else one
+  int nchw = g_cw_nch > 0 ? g_cw_nch : ((d->M <= 32 && hpw == 1) ? VIL_CW_NCH : 1);
+  while (nchw > 1 && nchw * hpw * w.NWP > 8) nchw >>= 1;
   if (nchw > w.nch) nchw = w.nch;
   w.NCH = nchw < 1 ? 1 : nchw;
   w.ngrp = (w.nch + w.NCH - 1) / w.NCH;
@@ -568,6 +585,7 @@ static bool cw_make_cfg(const VilAttnDesc* d, const MfmaCfg& c, CwCfg& w) {
   w.m_HQ = vil_magic((unsigned)w.HQ);
   w.m_NWP = vil_magic((unsigned)w.NWP);
   w.m_ngrp = vil_magic((unsigned)w.ngrp);
+  w.m_HPW = vil_magic((unsigned)w.HPW); w.m_NHG = vil_magic((unsigned)w.NHG); w.m_tab4 = vil_magic((unsigned)(c.tabsize >> 2));
   w.NSP = c.NSP;
   w.abl = g_cw_abl;
 #ifdef VIL_CW_ABLATE
@@ -575,16 +593,15 @@ static bool cw_make_cfg(const VilAttnDesc* d, const MfmaCfg& c, CwCfg& w) {
 #endif
   w.koff_lds = ((c.NSP * 4 + 1023) >> 10) << 10;
   w.ak_lds = ((c.NSP * 2 + 1023) >> 10) << 10;
-  w.chunk_lds = CW_D * 2 * (32 * d->M * 2) + w.koff_lds + w.ak_lds;
   w.akb = (c.glo0 + d->G * c.gsz) * 4;        // the smallest address term is -(glo0 + (G - 1) gsz + ...) * 4
   // columns of one XCD's list and image streams per column
   w.by_image = d->B >= 8;
   const int nimg_x = w.by_image ? (d->B + 7) / 8 : 1;
-  w.ncolx = w.by_image ? d->H * w.ngrp : ((d->B * d->H + 7) / 8) * w.ngrp;
+  w.ncolx = w.by_image ? w.NHG * w.ngrp : ((d->B * w.NHG + 7) / 8) * w.ngrp;
   w.m_ncolx = vil_magic((unsigned)w.ncolx);
   // workgroups an XCD holds at once: registers (cw_occ waves per SIMD) and LDS
   const size_t lds = cw_lds_bytes(d, c, w);
-  int per_cu = cw_occ(d->M / 16, w.QT) * 4 / (w.NWP * w.NCH);
+  int per_cu = cw_occ(d->M / 16, w.QT) * 4 / (w.NWP * w.NCH * w.HPW);
   if (per_cu > (int)((160 * 1024) / lds)) per_cu = (int)((160 * 1024) / lds);
   if (per_cu < 1) per_cu = 1;
   const int cap = per_cu * (vil_cu_count() / 8 > 0 ? vil_cu_count() / 8 : 32);
@@ -628,7 +645,7 @@ int vil_cw_supported(const VilAttnDesc* d, int pass) {
     return VIL_E_BACKEND;
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   CwCfg w; cw_make_cfg(d, c, w);
-  if (w.NWP * w.NCH > 8) return VIL_E_BACKEND;
+  if (w.NWP * w.NCH * w.HPW > 8) return VIL_E_BACKEND;
   if (cw_lds_bytes(d, c, w) > 160 * 1024) return VIL_E_BACKEND;
   if (w.akb + c.tabsize * 4 >= 65536) return VIL_E_BACKEND;                 // 16-bit address terms
   if ((uint64_t)w.ncolx * w.NS * 8 >= (1ull << 31) || (uint64_t)w.ncolx * w.NS * (uint64_t)w.ncolx >= (1ull << 32)) return VIL_E_BACKEND;
@@ -681,7 +698,7 @@ int vil_cw_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   vil_prof_begin(VIL_K_MFMA_FWD, s, wk.fwd_bytes(), wk.fwd_flops());
   const unsigned grid = 8u * (unsigned)(w.ncolx * w.NS);
   const size_t lds = cw_lds_bytes(d, c, w);
-  const unsigned nthr = 64u * (unsigned)(w.NWP * w.NCH);
+  const unsigned nthr = 64u * (unsigned)(w.NWP * w.NCH * w.HPW);
 #define LAUNCH_CW(T_, MD_, QT_, SAFE_, RO_)                                                        \
   {                                                                                                \
     if (int he = vil_ensure_dyn_lds((const void*)k_cw_fwd<T_, MD_, QT_, SAFE_>, lds)) return he;   \

@@ -557,7 +557,11 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   if (d->dtype == VIL_DTYPE_F32) return vil_f32_fwd(d, p, s);
   // round 6: the chunk-workgroup kernels (vil_attn_cw.hip) wherever they apply; VIL_BACKEND_MFMA_WAVE keeps the
   // wave-per-chunk kernels below selectable (A/B, and every shape the new family declines)
-  if (d->backend != VIL_BACKEND_MFMA_WAVE && vil_cw_supported(d, 0) == VIL_OK) {
+  // (measured, same-box, hipEvents: 3x3 neighbourhoods with W <= 8 run 3 - 10 % faster on them; the two-chunk lists of
+  //  random-shift training and W = 12 -- five waves per chunk -- slower: those stay on the kernels below unless the caller
+  //  asks for the new family by name)
+  const bool cw_wins = d->mode == 0 && d->W <= 8 && !d->only_glo;
+  if (d->backend != VIL_BACKEND_MFMA_WAVE && (cw_wins || d->backend == VIL_BACKEND_MFMA_CW) && vil_cw_supported(d, 0) == VIL_OK) {
     const int r = vil_cw_fwd(d, p, s);
     if (r != VIL_E_BACKEND) return r;
   }

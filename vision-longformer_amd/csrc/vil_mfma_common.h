@@ -428,18 +428,19 @@ struct CwCfg {
   int HQ;              // query groups (y = QT yq .. QT yq + QT - 1) per chunk row = ceil(W / QT)
   int NWP;             // waves per chunk = ceil(W * HQ / 16)
   int NCH;             // chunks per workgroup
+  int HPW, NHG;        // heads per workgroup (H at head_dim 32: the halves of a K / V line meet in the CU's L1), head groups = H / HPW
   int nch, ngrp;       // chunks / chunk groups per (image, head)
   int lpt;             // chunks taken in order of decreasing work (chunk_of_rank): groups of equal step counts
   int NSP;
   int by_image;        // B >= 8: XCD x walks images x, x + 8, ...; else (image, head) pairs are dealt to the XCDs, one image per workgroup
   int ncolx;           // columns of one XCD's list: H * ngrp (by_image) or ceil(B H / 8) * ngrp
   int NS;              // image streams per column (stream s of XCD x: images x + 8 s, x + 8 (s + NS), ...)
-  int chunk_lds, koff_lds, ak_lds;   // LDS bytes per chunk: ring + tables; the two tables (whole 1 KB DMA pieces)
+  int koff_lds, ak_lds;   // LDS bytes of a chunk's two slot tables (whole 1 KB DMA pieces)
   int abl;             // timing-ablation bits (VIL_CW_ABLATE builds only)
   void* dbg;           // cycle-stamp records (VIL_CW_ABLATE builds only)
   int akb;             // bias of the packed 16-bit address terms (bytes, multiple of 4)
   int gq_on, gq_wp, gq_lj;     // vil_attn_fwd_full: the global query's column (wave part, lane column)
-  unsigned m_HQ, m_NWP, m_ncolx, m_ngrp;
+  unsigned m_HQ, m_NWP, m_ncolx, m_ngrp, m_HPW, m_NHG, m_tab4;
   int* koff;           // (nch, NSP) K / V row byte offset of every key slot (own chunk's keys first)
   int* akey;           // (nch, NSP) halfwords: bias address term + akb of every key slot, in per-lane order (k_cw_prep)
   int* nslots;         // (nch) padded slot count

@@ -20,7 +20,8 @@ from . import _lib
 
 _DT = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
 _BACKENDS = {"auto": _lib.BACKEND_AUTO, "scalar": _lib.BACKEND_SCALAR, "mfma": _lib.BACKEND_MFMA,
-             "mfma_wave": _lib.BACKEND_MFMA_WAVE}     # the wave-per-chunk kernels only (rounds 1-5): A/B row
+             "mfma_wave": _lib.BACKEND_MFMA_WAVE,     # the wave-per-chunk kernels only (rounds 1-5): A/B row
+             "mfma_cw": _lib.BACKEND_MFMA_CW}         # the chunk-workgroup forward wherever it can run (round 6)
 
 # process-wide default kernel family ("auto" | "scalar" | "mfma"); tests override per call
 DEFAULT_BACKEND = "auto"
