@@ -16,8 +16,9 @@ torch.cuda.synchronize(); the elapsed time is the MAX over ranks; rank 0 prints 
 JSON line.  `value` = images of all ranks / that time (weak scaling: fixed per-GPU batch).
 
 Extra objects on the same line:
-  roofline      k_mfma_bwd_dkdv (the dominant kernel) AT THE STAGE-1 SLIDING-CHUNK SHAPE of the
-                workload -- the hot path proper -- not an average over different problems:
+  roofline      the hot kernel FURTHEST from its roof among k_mfma_fwd / k_mfma_bwd_dq / k_mfma_bwd_dkdv AT THE
+                STAGE-1 SLIDING-CHUNK SHAPE of the workload (`by_kernel` carries all three fractions) -- the
+                hot path proper -- not an average over different problems:
                 per-launch durations come from hipEvents the library records around each of
                 its launches on the launch stream (vil_attn_profile_begin/_end2, every record
                 tagged with its problem shape); achieved = ALGORITHMIC bytes of the launch /
@@ -98,8 +99,8 @@ REFERENCE_EVAL_S_PER_IMAGE = {"vil_tiny_224": 0.0022, "vil_small_224": 0.0029}
 LINE_LIMIT = 4000        # bytes of the final stdout line (the driver keeps an 8 KB tail; round 4's 29 KB line did not parse)
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                  "vs_baseline", "dtype", "data")
-ROOFLINE_KEYS = ("kernel", "shape", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
-                 "avg_launch_ms", "backward_unit_frac")
+ROOFLINE_KEYS = ("kernel", "shape", "bound", "achieved", "peak", "unit", "frac", "by_kernel", "traffic",
+                 "algorithmic_bytes_per_launch", "avg_launch_ms", "backward_unit_frac")
 
 
 def _short_roofline(r, full=True):
@@ -157,7 +158,27 @@ def compact_line(full, detail_path=None):
                             (out["config"], "workload")):
             if isinstance(holder.get(key), str):
                 holder[key] = holder[key][:160]
-    assert len(json.dumps(out)) <= LINE_LIMIT, "bench line over the limit"
+    if len(json.dumps(out)) > LINE_LIMIT:
+        # last resort: the measurement is done -- never raise here.  Contract keys + the detail path, every string cut.
+        def cut(v):
+            if isinstance(v, str):
+                return v[:120]
+            if isinstance(v, dict):
+                return {k: cut(x) for k, x in list(v.items())[:16]}
+            if isinstance(v, (list, tuple)):
+                return [cut(x) for x in list(v)[:8]]
+            return v
+        slim = {k: cut(out.get(k)) for k in CONTRACT_KEYS}
+        slim["config"] = cut(out.get("config"))
+        for k in ("roofline", "cpu_baseline", "secondary"):
+            if out.get(k) is not None:
+                slim[k] = cut(out[k])
+        slim["detail"] = cut(out.get("detail"))
+        for victim in ("secondary", "cpu_baseline", "roofline", "config"):
+            if len(json.dumps(slim)) <= LINE_LIMIT:
+                break
+            slim[victim] = None
+        out = slim
     return out
 
 
@@ -368,12 +389,25 @@ def pmc_traffic(config, B, kernel, label):
     return None
 
 
-def roofline_of(config, B, shapes, tags, kernel="k_mfma_bwd_dkdv"):
+HOT_KERNELS = ("k_mfma_fwd", "k_mfma_bwd_dq", "k_mfma_bwd_dkdv")
+
+
+def roofline_of(config, B, shapes, tags, kernel=None):
+    """The `roofline` object of the line: the hot kernel FURTHEST from its roof at the workload's stage-1 shape (kernel = None;
+    the judge's recomputation found dQ below the dK/dV kernel the line used to report), with `by_kernel` = frac of all three."""
     lab = hot_shape(tags)
-    if lab is None or kernel not in shapes.get(lab, {}):
+    if lab is None:
+        return None
+    have = [k for k in HOT_KERNELS if k in shapes.get(lab, {})]
+    if kernel is None:
+        if not have:
+            return None
+        kernel = min(have, key=lambda k: shapes[lab][k]["frac_hbm"])
+    if kernel not in shapes.get(lab, {}):
         return None
     k = shapes[lab][kernel]
     return {"kernel": kernel, "shape": lab, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "by_kernel": {n[2:]: shapes[lab][n]["frac_hbm"] for n in have},
             "frac": k["frac_hbm"], "traffic": pmc_traffic(config, B, kernel, lab),
             "mfma": {"achieved": k["TFLOPs"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": k["frac_mfma"]},
             "valu": {"achieved": k.get("Gscores_per_s"), "unit": "Gscores/s", "frac": k.get("frac_valu"),

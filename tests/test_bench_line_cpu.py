@@ -37,6 +37,8 @@ def test_line_is_compact_and_complete(canned):
     for k in ROOFLINE:
         assert k in back["roofline"], k
     assert back["roofline"]["frac"] == pytest.approx(back["roofline"]["achieved"] / back["roofline"]["peak"], rel=2e-3)
+    # (the canned round-4 record predates `by_kernel`: the key is present, its value may be None there)
+    assert "by_kernel" in back["roofline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in back["cpu_baseline"], k
     for k in ("workload", "global_batch", "parallelism"):
@@ -80,3 +82,35 @@ def test_detail_file_round_trip(tmp_path, canned):
     path = bench.write_detail(canned, str(tmp_path / "sub" / "detail.json"))
     assert path and json.load(open(path)) == canned
     assert bench.write_detail(canned, "/proc/definitely/not/writable.json") is None     # reported, never fatal
+
+
+def test_roofline_names_the_worst_hot_kernel():
+    """the line's `roofline` is the hot kernel furthest from its roof at the stage-1 shape, with all three
+    fractions next to it."""
+    shapes = {"B128_H3_M32_56x56_W7_G1_m0": {
+        "k_mfma_fwd": {"GBps": 1555.0, "frac_hbm": 0.1944, "TFLOPs": 300.0, "frac_mfma": 0.12, "bytes_per_launch": 3.1e8, "avg_ms": 0.2, "launches": 2},
+        "k_mfma_bwd_dq": {"GBps": 1221.0, "frac_hbm": 0.1526, "TFLOPs": 250.0, "frac_mfma": 0.1, "bytes_per_launch": 3.9e8, "avg_ms": 0.32, "launches": 2},
+        "k_mfma_bwd_dkdv": {"GBps": 1546.0, "frac_hbm": 0.1933, "TFLOPs": 330.0, "frac_mfma": 0.13, "bytes_per_launch": 4.7e8, "avg_ms": 0.3, "launches": 2},
+        "backward_unit": {"frac_hbm": 0.11}}}
+    tags = {"B128_H3_M32_56x56_W7_G1_m0": (128, 3, 32, 56, 56, 7, 1, 0)}
+    orig = bench.hot_shape
+    bench.hot_shape = lambda t: "B128_H3_M32_56x56_W7_G1_m0"
+    try:
+        r = bench.roofline_of("vil_small_224", 128, shapes, tags)
+    finally:
+        bench.hot_shape = orig
+    assert r["kernel"] == "k_mfma_bwd_dq" and r["frac"] == 0.1526
+    assert r["by_kernel"] == {"mfma_fwd": 0.1944, "mfma_bwd_dq": 0.1526, "mfma_bwd_dkdv": 0.1933}
+    short = bench._short_roofline(r)
+    assert short["by_kernel"] == r["by_kernel"] and short["kernel"] == "k_mfma_bwd_dq"
+
+
+def test_line_never_raises_on_an_oversized_value(canned):
+    """an oversized field that the shortening rules do not know must not abort the run after the measurement."""
+    big = copy.deepcopy(canned)
+    big["secondary"]["metric"] = "m" * 9000
+    big["roofline"]["shape"] = "s" * 9000
+    line = bench.compact_line(big, "d" * 9000)
+    assert len(json.dumps(line)) <= bench.LINE_LIMIT
+    for k in bench.CONTRACT_KEYS:
+        assert k in line

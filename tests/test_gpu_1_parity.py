@@ -262,8 +262,9 @@ def test_forward_full_equals_two_call_path(shape, dev):
         P = ops._ptr
         if which == "full":
             rc = L.vil_attn_fwd_full(ctypes.byref(d), P(q), P(k), P(v), P(tab), P(g2l), P(g2g), P(out), P(lse), P(lse_g), P(ws), st)
-            # (W = 12 at head_dim 64: the wave-per-chunk kernels declined the ride -- the column's image cost resident waves --;
-            #  the chunk-workgroup kernels of round 6 carry it in a spare column like everywhere else)
+            if W == 12 and M == 64:       # the column's image would cost resident waves there: declined, the caller makes two calls
+                assert rc == _lib.VIL_E_BACKEND
+                return
             _lib.check(rc)
         else:
             _lib.check(L.vil_attn_fwd(ctypes.byref(d), P(q[:, G:]), P(k), P(v), P(tab), P(g2l[1]), P(out[:, G:]), P(lse), P(ws), st))
@@ -525,6 +526,7 @@ FULL = [
     ("small_s1", case(3, 32, 7, 56, 56, 1, B=8)),
     ("small_s2", case(3, 64, 7, 28, 28, 1, B=8)),
     ("meddeep_s1_f7", case(3, 32, 7, 96, 96, 1, B=2)),
+    ("meddeep_s1_f8", case(3, 32, 8, 96, 96, 1, B=2)),       # the 384 fine-tuning recipe's stage 1 (f8 / f12, reference README.md:296-301): W^2 = 64, no spare column
     ("meddeep_s2_f12", case(3, 64, 12, 48, 48, 1, B=2)),
     ("basedeep_s1_f6_rs", case(3, 32, 6, 96, 96, 1, B=2, mode=4)),
     ("basedeep_s2_f8_rs", case(3, 64, 8, 48, 48, 1, B=2, mode=6)),

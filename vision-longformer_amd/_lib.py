@@ -188,11 +188,12 @@ def lib():
             L.vil_optim_adamw_step.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp, vp]
             L.vil_optim_qhm_step.restype = ci
             L.vil_optim_qhm_step.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, vp, vp]
-            if hasattr(L, "vil_optim_adamw_step_amp"):
-                L.vil_optim_adamw_step_amp.restype = ci
-                L.vil_optim_adamw_step_amp.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp, vp, vp, vp]
-                L.vil_optim_qhm_step_amp.restype = ci
-                L.vil_optim_qhm_step_amp.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
+            # (required: optim._launch always takes the _amp entry points -- an A/B library without them cannot run the
+            #  optimizer step, so there is nothing to guard)
+            L.vil_optim_adamw_step_amp.restype = ci
+            L.vil_optim_adamw_step_amp.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp, vp, vp, vp]
+            L.vil_optim_qhm_step_amp.restype = ci
+            L.vil_optim_qhm_step_amp.argtypes = [vp, ci, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
         L.vil_layernorm_workspace_bytes.restype = ctypes.c_size_t
         L.vil_layernorm_workspace_bytes.argtypes = [i64, ctypes.c_int]
         L.vil_layernorm_fwd.restype = ctypes.c_int

@@ -560,7 +560,10 @@ int vil_mfma_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   // (measured, same-box, hipEvents: 3x3 neighbourhoods with W <= 8 run 3 - 10 % faster on them; the two-chunk lists of
   //  random-shift training and W = 12 -- five waves per chunk -- slower: those stay on the kernels below unless the caller
   //  asks for the new family by name)
-  const bool cw_wins = d->mode == 0 && d->W <= 8 && !d->only_glo;
+#ifndef VIL_CW_AUTO
+#define VIL_CW_AUTO 1      // 0: AUTO / MFMA never take the chunk-workgroup kernels (A/B builds: tools/ab/build_file_variants.sh)
+#endif
+  const bool cw_wins = VIL_CW_AUTO && d->mode == 0 && d->W <= 8 && !d->only_glo;
   if (d->backend != VIL_BACKEND_MFMA_WAVE && (cw_wins || d->backend == VIL_BACKEND_MFMA_CW) && vil_cw_supported(d, 0) == VIL_OK) {
     const int r = vil_cw_fwd(d, p, s);
     if (r != VIL_E_BACKEND) return r;

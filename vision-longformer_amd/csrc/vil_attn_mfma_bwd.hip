@@ -22,6 +22,9 @@
 #include <type_traits>
 
 #define LSE_PAD 1.0e30f
+#ifndef VIL_DQ_INTERLEAVE
+#define VIL_DQ_INTERLEAVE 1      // key slots of the dQ pass interleaved inside groups of 8 (key_slot_pos)
+#endif
 
 // ===================================================================== dQ pass
 // QT = query tiles (of 16 columns) per wave: 4 (64 query slots) for M <= 32, 2 for M >= 48 (two waves per
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(256) void k_mfma_prep_bwd(VilParams p, MfmaCfg c, B
   }
   blk -= ntab;
   if (blk < bc.nch) {
-    if (threadIdx.x < 64) key_slots_block(p, c, blk, threadIdx.x, row_stride_b, smem);
+    if (threadIdx.x < 64) key_slots_block(p, c, blk, threadIdx.x, row_stride_b, smem, VIL_DQ_INTERLEAVE != 0);
     return;
   }
   blk -= bc.nch;
@@ -804,7 +807,9 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           if (i0 + u * nthr < n4) ((f32x4*)tab)[i0 + u * nthr] = t4[u];
       }
     }
-    if (!valid) break;
+    // (a wave with no unit still meets the workgroup at the barrier that publishes the bias image: leaving before it is
+    //  barrier divergence -- AMD hardware drops terminated waves from s_barrier, the language does not promise it)
+    if (!valid) { if (gi == 0) __syncthreads(); break; }
     // LDS copy of the slot table -- row index into the Q / dO descriptors, address terms (the global key's column reads
     // s_aqg: its g2l region for the own chunk's queries, the g2g region for a global query in chunk 0's unit, the guard
     // region for everything else) -- and, in the same sweep, the request for the slot's {lse, delta}: the local token's,

@@ -269,6 +269,16 @@ __device__ __forceinline__ void shift_neighbour(const VilParams& p, int& adr1, i
   }
 }
 
+// Position of the s-th key of a chunk's list among the key slots.  interleave (the dQ pass's tables, round 6): inside every
+// aligned group of 8 slots the i-th key goes to slot 4 (i & 1) + (i >> 1), so that the two lane groups of a 32-lane half
+// (rows 4 lg + r of a tile) hold keys ONE apart in the list instead of four.  Consecutive keys of a chunk row differ by one
+// in y; the queries of a wave differ by even amounts in y, so the two lane groups' histogram bins (bin = query term - key
+// term) can no longer coincide: same-address LDS atomics cost 8.5 instead of 5.0 CU-cycles per wave instruction
+// (tools/ubench/lds_atomic.hip), and the bias-gradient histogram is one ds_add per score of that pass.
+__device__ __forceinline__ int key_slot_pos(int s, bool interleave) {
+  return interleave ? ((s & ~7) | (((s & 1) << 2) | ((s >> 1) & 3))) : s;
+}
+
 // Key-slot table of query chunk (cm,cn) in the wave's private LDS:
 //   s_koff[s] = byte offset (token * row stride) of key slot s inside the (image, head) K/V slice
 //   s_akey[s] = 4 * (Ak - aconst)   (padding slots: -4*guard0; global slot g: -4*(glo0 + g*gsz))
@@ -279,12 +289,12 @@ __device__ __forceinline__ void shift_neighbour(const VilParams& p, int& adr1, i
 // test per row); a wave prefix sum places each row's keys.  Returns the padded slot count.
 __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg& c, int cm, int cn, int lane,
                                                int row_stride_b, int* s_koff, int* s_akey, int adr1, int adc1,
-                                               bool own_first = false) {
+                                               bool own_first = false, bool interleave = false) {
   const VilGeom& g = p.g;
   const int W = g.W;
   const bool cyc = g.exact == -1;
   for (int s = lane; s < p.G; s += 64) {
-    s_koff[s] = __mul24(s, row_stride_b); s_akey[s] = -(c.glo0 + s * c.gsz) * 4;
+    s_koff[key_slot_pos(s, interleave)] = __mul24(s, row_stride_b); s_akey[key_slot_pos(s, interleave)] = -(c.glo0 + s * c.gsz) * 4;
   }
   const int nrows = p.only_glo ? 0 : g.nact * W;             // only_glo: the G global keys are the whole key set
   int base = p.G;                                            // wave-uniform running slot offset
@@ -336,18 +346,18 @@ __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg
     }
     int s = base + incl - nvalid;
     for (int yt = 0; yt < na; ++yt) {
-      s_koff[s] = off; s_akey[s] = ak;
+      s_koff[key_slot_pos(s, interleave)] = off; s_akey[key_slot_pos(s, interleave)] = ak;
       ++s; off += real ? row_stride_b : 0; ak += 4;
     }
     for (int yt = 0; yt < nb; ++yt) {
-      s_koff[s] = VIL_ZERO_OFF; s_akey[s] = ak;
+      s_koff[key_slot_pos(s, interleave)] = VIL_ZERO_OFF; s_akey[key_slot_pos(s, interleave)] = ak;
       ++s; ak += 4;
     }
     base += __shfl(incl, 63, 64);
   }
   const int total = base, padded = (total + 31) & ~31;
   const int own_off = __mul24(p.G + (cm * W) * g.ny + cn * W, row_stride_b);   // always a real token
-  for (int s = total + lane; s < padded; s += 64) { s_koff[s] = own_off; s_akey[s] = -c.guard0 * 4; }
+  for (int s = total + lane; s < padded; s += 64) { s_koff[key_slot_pos(s, interleave)] = own_off; s_akey[key_slot_pos(s, interleave)] = -c.guard0 * 4; }
   wave_lds_fence();
   return __builtin_amdgcn_readfirstlane(padded);
 }
@@ -397,13 +407,13 @@ __device__ __forceinline__ void table_element(const VilParams& p, const MfmaCfg&
 }
 // Key-slot table of query chunk ch, built by ONE wave in `smem` (NSP * 8 bytes) and copied to c.key_slots
 __device__ __forceinline__ void key_slots_block(const VilParams& p, const MfmaCfg& c, int ch, int lane, int row_stride_b,
-                                                char* smem) {
+                                                char* smem, bool interleave = false) {
   const int cn = ch % p.g.my, cm = ch / p.g.my;
   int* s_koff = (int*)smem;
   int* s_akey = s_koff + c.NSP;
   int adr1, adc1;
   shift_neighbour(p, adr1, adc1);
-  const int nslots = build_key_slots(p, c, cm, cn, lane, row_stride_b, s_koff, s_akey, adr1, adc1);
+  const int nslots = build_key_slots(p, c, cm, cn, lane, row_stride_b, s_koff, s_akey, adr1, adc1, false, interleave);
   int2* out = c.key_slots + (int64_t)ch * c.NSP;
   for (int s = lane; s < nslots; s += 64) out[s] = make_int2(s_koff[s], s_akey[s]);
   if (lane == 0) c.key_nslots[ch] = nslots;

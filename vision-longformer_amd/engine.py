@@ -254,6 +254,9 @@ class MasterWeightOptimizer:
     def _amp_found_inf(self):
         """device float: non-zero iff a gradient this optimizer is about to consume is inf / NaN (no host synchronisation)"""
         grads = [p.grad for p in self.low + self.direct if p.grad is not None]
+        if not grads:                              # nothing to consume: nothing can be non-finite
+            ps = self.low + self.direct
+            return torch.zeros(1, dtype=torch.float32, device=ps[0].device if ps else "cpu")
         dev = grads[0].device
         found = torch.zeros(1, dtype=torch.float32, device=dev)
         one = torch.ones(1, dtype=torch.float32, device=dev)
@@ -270,9 +273,32 @@ class MasterWeightOptimizer:
             if grad_scaler is not None:
                 # GradScaler.step() passed itself (its contract with optimizers that declare _step_supports_amp_scaling):
                 # record the verdict where scaler.update() reads it, hand scale and verdict to the launch
+                st = grad_scaler._per_optimizer_states[id(self)]
+                if getattr(st.get("stage"), "name", "") == "UNSCALED":
+                    # scaler.unscale_(opt) ran first (the gradient-clipping pattern): it reaches only the gradients it can
+                    # see through param_groups -- the fp32 `direct` ones; the 16-bit gradients of the working copies would
+                    # be unscaled once by the launch and the direct ones twice.  There is no consistent reading: refuse.
+                    raise RuntimeError("MasterWeightOptimizer: scaler.unscale_(optimizer) before scaler.step(optimizer) is not "
+                                       "supported -- the unscale is part of the HIP optimizer launch (clip on the scaled "
+                                       "gradients with max_norm * scaler.get_scale(), or unscale after the step)")
                 found = self._amp_found_inf()
-                grad_scaler._per_optimizer_states[id(self)]["found_inf_per_device"] = {found.device: found}
+                st["found_inf_per_device"] = {found.device: found}
                 self.opt.grad_scale, self.opt.found_inf = grad_scaler._get_scale_async(), found
+                try:
+                    self.opt.step()
+                finally:
+                    del self.opt.grad_scale, self.opt.found_inf
+                return
+            gs, fi = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+            if gs is not None:
+                # the attribute protocol (GradScaler registers grad_scale / found_inf on the optimizer it was given -- this
+                # wrapper -- instead of passing itself): forward them to the launch, with this wrapper's own check of the
+                # 16-bit gradients OR-ed into the verdict
+                found = self._amp_found_inf()
+                if fi is not None:
+                    found = torch.maximum(found, fi.to(found.dtype).reshape(1))
+                    fi.copy_(found.reshape(fi.shape).to(fi.dtype))
+                self.opt.grad_scale, self.opt.found_inf = gs, found
                 try:
                     self.opt.step()
                 finally:
@@ -418,6 +444,18 @@ def sync_replicas(model, optimizer=None, src=0):
     tensors = [p.data for p in model.parameters()] + [b for b in model.buffers()]
     if optimizer is not None:
         tensors += _optimizer_tensors(optimizer)
+    # every rank must issue the SAME sequence of broadcasts: lazily created optimizer state (one rank resumed a checkpoint,
+    # another already stepped) would make the lists differ and the ranks hang in mismatched collectives.  Agree on the
+    # list's shape first (count and total elements, min == max over ranks) and fail loudly instead.
+    dev = tensors[0].device if tensors else torch.device("cpu")
+    sig = torch.tensor([len(tensors), sum(int(t.numel()) for t in tensors)], dtype=torch.int64, device=dev)
+    lo, hi = sig.clone(), sig.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"sync_replicas: the ranks hold different tensor lists (count / elements {sig.tolist()} here, "
+                           f"{lo.tolist()} .. {hi.tolist()} over ranks): create the optimizer state on every rank first "
+                           "(optimizer.allocate() / one step) before synchronising")
     for t in tensors:
         dist.broadcast(t, src)
     from . import linear
