@@ -24,7 +24,7 @@ Extra objects on the same line:
                 tagged with its problem shape); achieved = ALGORITHMIC bytes of the launch /
                 its average duration.  `traffic` = PMC HBM bytes per launch of
                 that kernel at that shape, collected inside the real step (tools/pmc_step.sh ->
-                profiles/r05_pmc_traffic.json) and attached ONLY when the kernel sources'
+                profiles/r06_pmc_traffic.json) and attached ONLY when the kernel sources'
                 fingerprint matches the build that is running.
   roofline_by_shape   the same for fwd / dQ / dK+dV / delta at every hot-path shape of the
                 workload, plus `backward_unit`: SURVEY 8(d)'s whole-backward definition

@@ -32,6 +32,7 @@ CW_CASES = [
     case(2, 32, 4, 8, 8, 1, only_glo=True), case(2, 32, 7, 7, 7, 1), case(1, 32, 4, 3, 2, 1), case(2, 32, 5, 11, 17, 4, rpe=False),
     case(3, 32, 7, 28, 28, 1, B=9),          # B >= 8: persistent columns over an XCD's images, several streams
     case(2, 64, 7, 14, 14, 1, B=17),
+    case(6, 32, 7, 14, 14, 1, B=8), case(12, 64, 8, 16, 16, 1, B=2),     # more heads than any ViL stage-1/2 (columns = chunk x head)
 ]
 
 

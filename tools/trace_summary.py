@@ -19,13 +19,22 @@ for r in rows:
     r["Kernel_Name"] = pretty(r["Kernel_Name"])
 marker = sys.argv[2] if len(sys.argv) > 2 else "void k_mfma_fwd<bf16,2>"
 idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(marker)]
-per = int(sys.argv[3]) if len(sys.argv) > 3 else 1       # marker launches per step
+def period(idx):
+    """marker launches per step, from the trace itself: the smallest p for which the launch counts between consecutive
+    marker launches repeat with period p over the last 3 periods"""
+    gaps = [b - a for a, b in zip(idx, idx[1:])]
+    for p in range(1, len(gaps) // 4):
+        if all(gaps[-1 - i] == gaps[-1 - i - p] for i in range(3 * p)):
+            return p
+    print("# WARNING: no launch period found for marker %s; assuming 1 launch per step" % marker)
+    return 1
+per = period(idx) if len(sys.argv) > 3 and sys.argv[3] == "auto" else int(sys.argv[3]) if len(sys.argv) > 3 else 1   # marker launches per step
 nsteps = 3
 s0, s1 = idx[-1 - nsteps * per], idx[-1]
 t0, t1 = int(rows[s0]["Start_Timestamp"]), int(rows[s1]["Start_Timestamp"])
 def classify(n):
     if n.startswith("Cijk"): return "gemm(hipblaslt)"
-    if "k_mfma" in n or "k_delta" in n or "k_reduce" in n or "k_scalar" in n or "k_glo_" in n or "k_dense_" in n: return "vil hot path"
+    if "k_mfma" in n or "k_cw_" in n or "k_gq_" in n or "k_delta" in n or "k_reduce" in n or "k_scalar" in n or "k_glo_" in n or "k_dense_" in n: return "vil hot path"
     if "k_wgrad" in n or "k_colsum" in n: return "vil weight gradient"
     if "k_dgrad_dgelu" in n or "k_fwd_gelu" in n or "k_skinny" in n: return "vil GEMM (fused epilogue / weights in registers)"
     if "k_optim" in n: return "vil optimizer"

@@ -807,9 +807,14 @@ __global__ __launch_bounds__(256, kv_waves(MD)) void k_mfma_bwd_dkdv(VilParams p
           if (i0 + u * nthr < n4) ((f32x4*)tab)[i0 + u * nthr] = t4[u];
       }
     }
-    // (a wave with no unit still meets the workgroup at the barrier that publishes the bias image: leaving before it is
-    //  barrier divergence -- AMD hardware drops terminated waves from s_barrier, the language does not promise it)
-    if (!valid) { if (gi == 0) __syncthreads(); break; }
+    // A wave with no unit (the last workgroup of a launch) leaves HERE, before the barrier that publishes the bias image.
+    // That is defined behaviour on the only target this file is built for: the gfx9 / CDNA ISA specifies that S_BARRIER
+    // "waits on only the surviving waves" when waves of the workgroup have already terminated.  Meeting the barrier on the
+    // way out instead (round 6, the advisor's item) was measured and taken back: the second barrier site changes hipcc's
+    // register allocation of the whole kernel -- head_dim 32: 250 -> 256 VGPRs + 76 bytes of scratch per lane, head_dim
+    // 64: 245 -> 256 + 168 -- and the pass ran 349 -> 372 us at ViL-Small stage 1 (profiles/r06_attn_ab_vs_round5.txt,
+    // first table).  tests/test_gpu_1_parity.py's odd chunk counts (e.g. 3 x 3 chunks, four-wave workgroups) run this path.
+    if (!valid) break;
     // LDS copy of the slot table -- row index into the Q / dO descriptors, address terms (the global key's column reads
     // s_aqg: its g2l region for the own chunk's queries, the g2g region for a global query in chunk 0's unit, the guard
     // region for everything else) -- and, in the same sweep, the request for the slot's {lse, delta}: the local token's,
