@@ -139,9 +139,11 @@ int vil_glo_attn_bwd(const VilAttnDesc* d, const void* q_g, const void* k, const
                      const float* g2g, const float* g2l0, void* dq_g, void* dk, void* dv,
                      float* dg2g, float* dg2l0, void* stream);
 
-/* ---- tuning hook of the chunk-workgroup kernels (round 6; tools/ only): K / V ring depth (2..4) and chunks per workgroup
- * of the following launches, 0 = the library's own choice. */
-int vil_attn_cw_set_shape(int ring_depth, int chunks_per_wg);
+/* ---- launch-shape hook of the chunk-workgroup kernels (round 6; tools/cw_check.py and the launch-shape invariance test only;
+ * process-global, the product never calls it).  streams: image streams per column and XCD (0 = the library's cost model);
+ * shape_code = chunks per workgroup (1..4) + 10 * query tiles per wave (1, 2) + 100 * heads per workgroup, any digit 0 = the
+ * library's own choice.  Results do not depend on either (tests/test_gpu_1_cw.py); VIL_E_SHAPE for values out of range. */
+int vil_attn_cw_set_shape(int streams, int shape_code);
 
 /* ---- whole-layer forward (round 5): local rows AND the global token's query row from ONE pass over K / V.  The global
  * query rides in the forward kernel as a spare query column of every chunk, live against the chunk's own keys; a small

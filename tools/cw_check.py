@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--bwd", action="store_true")
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--cw", default="", help="ring depth, chunks per workgroup: D,NCH[;D,NCH...] (vil_attn_cw_set_shape)")
+    ap.add_argument("--cw", default="", help="launch shapes to try: streams,shape_code[,ablation bits][;...] (vil_attn_cw_set_shape: code = chunks per workgroup + 10 * query tiles per wave + 100 * heads per workgroup)")
     a = ap.parse_args()
     names = ["out", "dq", "dkv", "dtable", "dg2l", "dg2g"]
     for name in a.shapes.split(","):

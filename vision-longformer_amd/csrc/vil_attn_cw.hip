@@ -9,10 +9,12 @@
 //   * the chunk's K and V step tiles are brought into LDS ONCE per chunk by LDS-DMA (buffer_load ... lds: no registers,
 //     no ds_write pass), into a two-slot ring, and read by all of the chunk's waves -- the wave-per-chunk family loaded K
 //     fragments per wave straight from L2 and staged V through registers;
-//   * a workgroup is NCH chunks of one (image, head) walking their key steps in lockstep (one bare s_barrier per 32-key
-//     step; chunks are grouped by rank of work so that the steps of a workgroup's chunks are equal in number);
-//   * slot tables are never copied to LDS: the DMA row offsets and the bias address terms of the NEXT step are fetched
-//     from the (L2-resident) per-chunk-position tables into registers while the current step computes;
+//   * a workgroup is a COLUMN: NCH chunks of one head walking their key steps in lockstep (one bare s_barrier per 32-key
+//     step; chunks are grouped by rank of work so that the steps of a workgroup's chunks are equal in number), bound to the
+//     XCD it is dispatched to (blockIdx % 8) and PERSISTENT over that XCD's images: the head's bias image and the chunk
+//     positions' slot tables are brought into LDS once per workgroup, not once per (image, chunk);
+//   * slot tables are per chunk POSITION (k_cw_prep): DMA row offsets (int32) and the bias address terms as biased 16-bit
+//     values in the order a lane reads them; the request cursor runs one tile ahead of the compute and reads them from LDS;
 //   * bf16: the softmax is shift-free.  Q is pre-multiplied by scale * log2(e) (one bf16 rounding, like the reference's own
 //     `q * scale` under autocast), the bias image is in log2 units, so the MFMA result IS the exponent: p = exp2(s), no
 //     running maximum, no subtract, no rescale branch -- 2 VALU instructions per score (v_exp, half a v_cvt_pk) instead
@@ -39,8 +41,11 @@
 #ifndef VIL_CW_NCH
 #define VIL_CW_NCH 2         // chunks per workgroup (lockstep)
 #endif
+#ifndef VIL_CW_PAIR_ORDER
+#define VIL_CW_PAIR_ORDER 1  // a workgroup's two chunks list their shared neighbours at the same positions (k_cw_prep)
+#endif
 // timing ablations (tools only; the results are wrong): built with -DVIL_CW_ABLATE, selected at run time through
-// vil_attn_cw_set_shape's third argument (CwCfg::abl) -- 1 no wait + barrier in the loop, 2 no LDS-DMA in the loop, 4 no bias
+// vil_attn_cw_set_ablation (CwCfg::abl) -- 1 no wait + barrier in the loop, 2 no LDS-DMA in the loop, 4 no bias
 // gather, 8 no exponentials, 16 no P V (transposed reads + MFMAs), 32 no K reads / S MFMAs, 64 no step at all
 #ifdef VIL_CW_ABLATE
 #define CW_ABL(bit) (w.abl & (bit))
@@ -67,14 +72,31 @@ __global__ __launch_bounds__(256) void k_cw_prep(VilParams p, MfmaCfg c, CwCfg w
     return;
   }
   if (threadIdx.x >= 64) return;
-  const int ch = blk - ntab, lane = threadIdx.x;
+  const int rank = blk - ntab, lane = threadIdx.x;
   const VilGeom& g = p.g;
+  const int ch = w.lpt ? chunk_of_rank(rank, g.mx, g.my) : rank;
   const int cn = ch % g.my, cm = ch / g.my;
   int* s_koff = (int*)smem;
   int* s_akey = s_koff + c.NSP;
   int adr1, adc1;
   shift_neighbour(p, adr1, adc1);
-  const int nslots = build_key_slots(p, c, cm, cn, lane, row_stride_b, s_koff, s_akey, adr1, adc1, true);
+  // Order of the neighbours in the list: the own chunk first (the global query column is live there).  With two chunks per
+  // workgroup the pair is usually adjacent and shares six of its nine neighbours: those go to the SAME list positions in
+  // both chunks -- [own, partner | the four other shared ones | the three private ones] -- so that the two chunks' waves,
+  // which walk their lists in lockstep, request the same K / V rows in the same step and the second request finds the
+  // lines in the CU's L1 instead of crossing the L2 -> CU path again (VIL_CW_PAIR_ORDER=0: plain own-first order).
+  unsigned long long perm = 0ull;
+#if VIL_CW_PAIR_ORDER
+  if (g.nact == 9 && (rank ^ 1) < w.nch) {      // (whatever NCH is: the result must not depend on the launch shape)
+    const int pch = w.lpt ? chunk_of_rank(rank ^ 1, g.mx, g.my) : (rank ^ 1);
+    const int dr = pch / g.my - cm, dc = pch % g.my - cn;
+    if (dr == 0 && dc == 1) perm = 0x630872154ull;        // positions 0..8 = 4,5,1,2,7,8,0,3,6
+    else if (dr == 0 && dc == -1) perm = 0x852761034ull;  // 4,3,0,1,6,7,2,5,8
+    else if (dr == 1 && dc == 0) perm = 0x210865374ull;   // 4,7,3,5,6,8,0,1,2
+    else if (dr == -1 && dc == 0) perm = 0x876532014ull;  // 4,1,0,2,3,5,6,7,8
+  }
+#endif
+  const int nslots = build_key_slots(p, c, cm, cn, lane, row_stride_b, s_koff, s_akey, adr1, adc1, true, false, perm);
   // akey: 16 bits per slot, biased by w.akb so that every term is non-negative, in the order a lane reads them: the
   // eight keys of lane group lg in step st (tile hf, row r) are the contiguous halfwords st * 32 + lg * 8 + hf * 4 + r
   unsigned short* ak16 = (unsigned short*)w.akey + (int64_t)ch * c.NSP;
@@ -540,10 +562,10 @@ __global__ __launch_bounds__(512, cw_occ(MD, QT)) void k_cw_fwd(VilParams p, Mfm
 // launch-shape override (tools/cw_check.py: image streams per column of the next launches; 0 = the library's own choice).
 // Process-global like the other tuning hooks of the library; the product never calls it.
 static int g_cw_streams = 0, g_cw_qt = 0, g_cw_nch = 0, g_cw_hpw = 0, g_cw_abl = 0;
-extern "C" int vil_attn_cw_set_shape(int streams, int chunks_per_wg) {
-  // chunks_per_wg: chunks per workgroup + 10 * query tiles per wave + 100 * heads per workgroup (0: the library's choice)
-  const int nch = chunks_per_wg % 10, qt = (chunks_per_wg / 10) % 10, hpw = chunks_per_wg / 100;
-  if (streams < 0 || chunks_per_wg < 0 || nch > 4 || (qt != 0 && qt != 1 && qt != 2) || hpw > 8) return VIL_E_SHAPE;
+extern "C" int vil_attn_cw_set_shape(int streams, int shape_code) {
+  // shape_code: chunks per workgroup + 10 * query tiles per wave + 100 * heads per workgroup (0: the library's choice)
+  const int nch = shape_code % 10, qt = (shape_code / 10) % 10, hpw = shape_code / 100;
+  if (streams < 0 || shape_code < 0 || nch > 4 || (qt != 0 && qt != 1 && qt != 2) || hpw > 8) return VIL_E_SHAPE;
   g_cw_streams = streams; g_cw_nch = nch; g_cw_qt = qt; g_cw_hpw = hpw;
   return VIL_OK;
 }

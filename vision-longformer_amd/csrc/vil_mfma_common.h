@@ -289,7 +289,8 @@ __device__ __forceinline__ int key_slot_pos(int s, bool interleave) {
 // test per row); a wave prefix sum places each row's keys.  Returns the padded slot count.
 __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg& c, int cm, int cn, int lane,
                                                int row_stride_b, int* s_koff, int* s_akey, int adr1, int adc1,
-                                               bool own_first = false, bool interleave = false) {
+                                               bool own_first = false, bool interleave = false,
+                                               unsigned long long perm = 0ull) {
   const VilGeom& g = p.g;
   const int W = g.W;
   const bool cyc = g.exact == -1;
@@ -308,7 +309,10 @@ __device__ __forceinline__ int build_key_slots(const VilParams& p, const MfmaCfg
       const int a_ = fdiv(rid, c.magicW), xt = rid - a_ * W;
       // own_first (chunk-workgroup family): the query chunk's own keys lead the list (neighbour 4 of the 3x3 order), so
       // that the global query column riding in the pass is live in the first steps only
-      const int a = (own_first && g.nact == 9) ? (a_ == 0 ? 4 : (a_ <= 4 ? a_ - 1 : a_)) : a_;
+      // perm (chunk-workgroup family, two chunks per workgroup): nibble i = the 3x3 neighbour at list position i, chosen so
+      // that the neighbours the two chunks share sit at the SAME positions of both lists (k_cw_prep)
+      const int a = g.nact != 9 ? a_ : perm ? (int)((perm >> (4 * a_)) & 15ull)
+                                     : own_first ? (a_ == 0 ? 4 : (a_ <= 4 ? a_ - 1 : a_)) : a_;
       const int a3 = (a * 11) >> 5;                           // a / 3 for a in [0, 9)
       const int dr = g.nact == 9 ? a3 - 1 : (a == 0 ? 0 : adr1);
       const int dc = g.nact == 9 ? a - 3 * a3 - 1 : (a == 0 ? 0 : adc1);
