@@ -144,6 +144,12 @@ int vil_glo_attn_bwd(const VilAttnDesc* d, const void* q_g, const void* k, const
  * shape_code = chunks per workgroup (1..4) + 10 * query tiles per wave (1, 2) + 100 * heads per workgroup, any digit 0 = the
  * library's own choice.  Results do not depend on either (tests/test_gpu_1_cw.py); VIL_E_SHAPE for values out of range. */
 int vil_attn_cw_set_shape(int streams, int shape_code);
+/* The launch plan the chunk-workgroup forward would use for *d (host only: no launch, no device memory).  out24 = {segments,
+ * workgroups per XCD, largest stream count, chunks per workgroup, head groups, chunk groups, by_image, chunks per (image,
+ * head), then four times (first chunk group, chunk groups, image streams, first workgroup) -- one entry per segment of chunk
+ * groups with equal work per image (interior / edge / corner chunks of the 3x3 neighbourhood)}.  tests/test_cabi_cpu.py
+ * checks that the plan covers every (image, head, chunk) exactly once. */
+int vil_attn_cw_plan(const VilAttnDesc* d, int32_t* out24);
 
 /* ---- whole-layer forward (round 5): local rows AND the global token's query row from ONE pass over K / V.  The global
  * query rides in the forward kernel as a spare query column of every chunk, live against the chunk's own keys; a small

@@ -361,3 +361,50 @@ def test_hot_kernels_stay_inside_their_register_budgets():
         assert v["occupancy"] >= 4 and v["scratch"] <= 40, (k, v)
     for k, v in pick(r"k_dense_(fwd|bwd_dq|bwd_dkdv)IDF16.Li2E").items():
         assert v["occupancy"] >= 3 and v["scratch"] == 0, (k, v)
+
+
+def _cw_plan(B, H, M, nx, ny, W, G=1, mode=0):
+    d = _lib.VilAttnDesc()
+    C, N = H * M, G + nx * ny
+    for k, v in dict(B=B, H=H, M=M, nx=nx, ny=ny, W=W, G=G, mode=mode, exact=0, dtype=_lib.DTYPE_BF16, only_glo=0,
+                     backend=_lib.BACKEND_MFMA_CW, scale=M ** -0.5).items():
+        setattr(d, k, v)
+    for pre, st, rows in (("q", C, nx * ny), ("k", 2 * C, N), ("v", 2 * C, N), ("o", C, nx * ny)):
+        setattr(d, pre + "_st", st); setattr(d, pre + "_sb", st * rows); setattr(d, pre + "_sh", M)
+    out = (ctypes.c_int32 * 24)()
+    L = _lib.lib()
+    L.vil_attn_cw_plan.restype = ctypes.c_int
+    assert L.vil_attn_cw_plan(ctypes.byref(d), out) == 0
+    return list(out)
+
+
+@pytest.mark.parametrize("shape", [(128, 3, 32, 56, 56, 7), (128, 3, 64, 28, 28, 7), (32, 3, 32, 96, 96, 7), (32, 3, 64, 48, 48, 7),
+                                   (32, 3, 32, 96, 96, 8), (9, 2, 32, 21, 20, 7), (17, 2, 64, 14, 14, 7), (8, 6, 32, 14, 14, 7),
+                                   (100, 3, 32, 30, 9, 7), (8, 1, 32, 3, 2, 4)], ids=str)
+def test_cw_launch_plan_covers_every_image_head_and_chunk_group_once(shape):
+    """The chunk-workgroup forward's launch plan (vil_attn_cw_plan: host only) decoded the way the kernel decodes blockIdx
+    (csrc/vil_attn_cw.hip, `by_image` branch): every (image, head group, chunk group) belongs to exactly one workgroup, no
+    workgroup walks more than the 32 images its redo mask can name, and the plan's totals are consistent."""
+    B, H = shape[0], shape[1]
+    o = _cw_plan(*shape)
+    nseg, nwgx, NS, NCH, NHG, ngrp, by_image, nch = o[:8]
+    segs = [o[8 + 4 * k: 12 + 4 * k] for k in range(nseg)]
+    assert by_image == 1 and 1 <= nseg <= 4 and ngrp == -(-nch // NCH) and NHG == H
+    assert sorted(g for g0, ng, ns, wg0 in segs for g in range(g0, g0 + ng)) == list(range(ngrp))       # a partition of the groups
+    assert sum(ng * NHG * ns for g0, ng, ns, wg0 in segs) == nwgx and max(ns for _, _, ns, _ in segs) == NS
+    seen = {}
+    for xcd in range(8):
+        for kblk in range(nwgx):
+            sc = max(k for k in range(nseg) if kblk >= segs[k][3])
+            g0, ng, ns, wg0 = segs[sc]
+            idx = kblk - wg0
+            assert 0 <= idx < ng * NHG * ns
+            strm, col = divmod(idx, ng * NHG)
+            gl, h = divmod(col, NHG)
+            imgs = list(range(xcd + 8 * strm, B, 8 * ns))
+            assert len(imgs) <= 32
+            for b in imgs:
+                key = (b, h, g0 + gl)
+                assert key not in seen, (key, seen[key], (xcd, kblk))
+                seen[key] = (xcd, kblk)
+    assert len(seen) == B * NHG * ngrp

@@ -29,8 +29,11 @@ def base(name):
         n = name[m.end():m.end() + int(m.group(1))]
     else:
         n = name.replace("void ", "").split("(")[0].split("<")[0].strip()
-    if n == "k_cw_fwd" and ("DF16b" in name or "bf16" in name) and ("Lb1E" in name or "true" in name):
-        return None      # the exact kernel's launch behind the fast one (redo_only: returns at once unless a column was flagged)
+    if n == "k_cw_fwd" and "Lb0E" not in name:
+        # the exact kernel's launch behind the fast one (redo_only: returns at once unless a column was flagged).  bench.py runs
+        # bf16, whose fast kernels keep their mangled names (...Lb0EEv...) in rocprofv3's output; the exact twins appear as
+        # ...Lb1EEv... or, mis-demangled, as "void k_cw_fwd<bool _Accum, int, EL, ...>"
+        return None
     return SINK.get(n)
 
 

@@ -40,7 +40,7 @@ EXPORTS = ("vil_attn_abi_version", "vil_attn_strerror", "vil_attn_check", "vil_a
            "vil_resln_fwd", "vil_resln_bwd", "vil_gemm_workspace_bytes", "vil_gemm_bf16", "vil_gemm_tune", "vil_gemm_dgelu_bf16", "vil_gemm_gelu_bf16", "vil_gemm_tile_bf16", "vil_gemm_skinny_bf16", "vil_gemm_skinny_gelu_bf16",
            "vil_sc2d_qk", "vil_sc2d_av", "vil_sc2d_agrad", "vil_sc2d_mask",
            "vil_optim_plan_bytes", "vil_optim_plan_build", "vil_optim_adamw_step", "vil_optim_qhm_step",
-           "vil_optim_adamw_step_amp", "vil_optim_qhm_step_amp", "vil_attn_cw_set_shape")
+           "vil_optim_adamw_step_amp", "vil_optim_qhm_step_amp", "vil_attn_cw_set_shape", "vil_attn_cw_plan")
 
 
 class VilAttnDesc(ctypes.Structure):

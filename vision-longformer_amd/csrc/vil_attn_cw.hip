@@ -28,6 +28,8 @@
 // Reference semantics: src/models/layers/longformer2d.py:134-204, slidingchunk_2d.py:26-130 (see include/vil_attn.h).
 #include "vil_mfma_common.h"
 #include <type_traits>
+#include <queue>
+#include <vector>
 
 #ifndef VIL_CW_OCC32
 #define VIL_CW_OCC32 5       // waves per SIMD the head_dim 32 forward is held to (96 VGPRs)
@@ -40,6 +42,9 @@
 #endif
 #ifndef VIL_CW_NCH
 #define VIL_CW_NCH 2         // chunks per workgroup (lockstep)
+#endif
+#ifndef VIL_CW_CLASS_STREAMS
+#define VIL_CW_CLASS_STREAMS 0   // per-class image stream counts (cw_plan_streams): measured, off
 #endif
 #ifndef VIL_CW_PAIR_ORDER
 #define VIL_CW_PAIR_ORDER 1  // a workgroup's two chunks list their shared neighbours at the same positions (k_cw_prep)
@@ -189,15 +194,24 @@ __global__ __launch_bounds__(512, cw_occ(MD, QT)) void k_cw_fwd(VilParams p, Mfm
 
   // ---- the column and its image stream
   const int xcd = blockIdx.x & 7, kblk = blockIdx.x >> 3;
-  const int strm = fdiv(kblk, w.m_ncolx), col = kblk - strm * w.ncolx;
   int h, grp, b0, bstride, nimg;
   if (w.by_image) {
-    // chunk-group-major, head-group-minor: the workgroups of a chunk group's heads are dispatched back to back
-    grp = fdiv(col, w.m_NHG); h = (col - grp * w.NHG) * w.HPW + hslot;
-    b0 = xcd + 8 * strm; bstride = 8 * w.NS;
+    // the XCD's list: segments of chunk groups of equal work (cw_make_cfg), each stream-major, then chunk-group-major,
+    // head-group-minor: the workgroups of a chunk group's heads are dispatched back to back
+    int sc = 0;
+    if (w.nseg > 1 && kblk >= w.seg_wg0[1]) sc = 1;
+    if (w.nseg > 2 && kblk >= w.seg_wg0[2]) sc = 2;
+    if (w.nseg > 3 && kblk >= w.seg_wg0[3]) sc = 3;
+    const int idx = kblk - w.seg_wg0[sc], ncol_c = w.seg_ng[sc] * w.NHG;
+    const int strm = fdiv(idx, w.seg_m[sc]), col = idx - strm * ncol_c;
+    const int gl = fdiv(col, w.m_NHG);
+    grp = w.seg_g0[sc] + gl; h = (col - gl * w.NHG) * w.HPW + hslot;
+    b0 = xcd + 8 * strm; bstride = 8 * w.seg_ns[sc];
     nimg = b0 < p.B ? (p.B - b0 + bstride - 1) / bstride : 0;
   } else {
     // (image, head group) pairs dealt to the XCDs
+    const int strm = fdiv(kblk, w.m_ncolx), col = kblk - strm * w.ncolx;
+    (void)strm;
     const int pj = fdiv(col, w.m_ngrp); grp = col - pj * w.ngrp;
     const int pi = xcd + 8 * pj;
     b0 = pi / w.NHG; h = (pi - b0 * w.NHG) * w.HPW + hslot; bstride = 0;
@@ -581,6 +595,181 @@ extern "C" int vil_attn_cw_set_debug(void* buf) { g_cw_dbg = buf; return VIL_OK;
 static size_t cw_lds_bytes(const VilAttnDesc* d, const MfmaCfg& c, const CwCfg& w) {
   return (size_t)w.HPW * c.tabsize * 4 + (size_t)w.NCH * (w.HPW * CW_D * 2 * (32 * d->M * 2) + w.koff_lds + w.ak_lds) + 16;
 }
+// key steps per image of the chunk at rank r (host mirror of build_key_slots' count for the zero-padded 3x3 / own-chunk /
+// two-chunk lists; cyclic padding: every chunk sees full neighbours)
+static int cw_steps_of_chunk(const VilAttnDesc* d, const VilGeom& g, int ch) {
+  if (d->only_glo) return (d->G + 31) / 32;
+  const int W = d->W, cm = ch / g.my, cn = ch % g.my;
+  int keys = d->G;
+  if (g.nact == 9 && g.exact != -1) {
+    for (int dr = -1; dr <= 1; ++dr)
+      for (int dc = -1; dc <= 1; ++dc) {
+        const int rm = cm + dr, rn = cn + dc;
+        if (rm < 0 || rm >= g.mx || rn < 0 || rn >= g.my) continue;
+        const int rows = W < d->nx - rm * W ? W : d->nx - rm * W, cols = W < d->ny - rn * W ? W : d->ny - rn * W;
+        keys += rows * cols;
+      }
+  } else {
+    keys += g.nact * W * W;
+  }
+  return (keys + 31) / 32;
+}
+// host mirror of chunk_of_rank (vil_mfma_common.h)
+static int cw_chunk_of_rank(int r, int mx, int my) {
+  if (mx < 3 || my < 3) return r;
+  const int iy = my - 2, ix = mx - 2, ni = ix * iy;
+  if (r < ni) { const int a = r / iy; return (1 + a) * my + 1 + (r - a * iy); }
+  r -= ni;
+  if (r < iy) return 1 + r;
+  r -= iy;
+  if (r < iy) return (mx - 1) * my + 1 + r;
+  r -= iy;
+  if (r < ix) return (1 + r) * my;
+  r -= ix;
+  if (r < ix) return (1 + r) * my + my - 1;
+  r -= ix;
+  return (r >> 1) * (mx - 1) * my + (r & 1) * (my - 1);
+}
+// finishing time of `n` workgroups of `work[i]` (dispatched in order) on `cap` slots: every workgroup goes to the slot that
+// frees first
+static double cw_makespan(const double* work, int n, int cap) {
+  std::priority_queue<double, std::vector<double>, std::greater<double>> slots;
+  double end = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double t0 = 0.0;
+    if ((int)slots.size() >= cap) { t0 = slots.top(); slots.pop(); }
+    const double t1 = t0 + work[i];
+    slots.push(t1);
+    if (t1 > end) end = t1;
+  }
+  return end;
+}
+// Image streams per column (by_image launches).  A column's workgroup walks the images of its stream one after the other, so a
+// column of interior chunks (nine neighbour chunks of keys) takes 9 / 4 of the time of a corner column for the same images,
+// and with ONE stream count for all columns the corner and edge workgroups finish early.  VIL_CW_CLASS_STREAMS=1 gives every
+// class of chunk groups (interior / edge / corner: the segments below) its own stream count -- the fewest streams that bring
+// its workgroups under a common target time, the target chosen by a simulated finishing time on the XCD's slots -- so that
+// all workgroups of the launch finish together.  MEASURED, NOT ADOPTED (profiles/r06_streams_ab.txt): 28 x 28 at head_dim 64
+// 77.6 - 78.0 us against 72.1 - 72.2 us for four streams everywhere (corner columns with two streams instead of four), 56 x 56
+// 202 - 206 against 201 - 207 (four streams) / 211 - 215 (two).  The slot model is wrong for these kernels in the same way
+// round 5's rank-order ablation was: a workgroup that finishes early does not idle a resource, it speeds its CU's other
+// waves up.  The segments stay (dispatch order: heaviest class first); the stream count is one number again.
+static void cw_plan_streams(const VilAttnDesc* d, const VilGeom& g, CwCfg& w, int cap, int nimg_x) {
+  // segments: the groups of interior, edge and corner chunks (rank order = chunk_of_rank's classes; a group that straddles a
+  // class boundary counts with the heavier class); one segment when the chunks are not taken by rank
+  int units[4] = {0, 0, 0, 0};
+  int first_rank[4] = {0, w.nch, w.nch, w.nch};
+  w.nseg = 1;
+  if (w.lpt && g.mx >= 3 && g.my >= 3) {
+    const int ni = (g.mx - 2) * (g.my - 2);
+    first_rank[1] = ni; first_rank[2] = w.nch - 4;
+    w.nseg = 3;
+  }
+  for (int c = 0; c < w.nseg; ++c) {
+    const int g0 = c == 0 ? 0 : (first_rank[c] + w.NCH - 1) / w.NCH;              // first group wholly inside class c or lighter
+    const int g1 = c + 1 < w.nseg ? (first_rank[c + 1] + w.NCH - 1) / w.NCH : w.ngrp;
+    w.seg_g0[c] = g0 < w.ngrp ? g0 : w.ngrp;
+    w.seg_ng[c] = (g1 < w.ngrp ? g1 : w.ngrp) - w.seg_g0[c];
+    if (w.seg_ng[c] < 0) w.seg_ng[c] = 0;
+    for (int gi = w.seg_g0[c]; gi < w.seg_g0[c] + w.seg_ng[c]; ++gi)
+      for (int i = 0; i < w.NCH; ++i) {
+        const int r = gi * w.NCH + i;
+        if (r >= w.nch) break;
+        const int st = cw_steps_of_chunk(d, g, w.lpt ? cw_chunk_of_rank(r, g.mx, g.my) : r);
+        if (st > units[c]) units[c] = st;
+      }
+  }
+  // (empty segments are dropped)
+  {
+    int k = 0;
+    for (int c = 0; c < w.nseg; ++c)
+      if (w.seg_ng[c] > 0) { w.seg_g0[k] = w.seg_g0[c]; w.seg_ng[k] = w.seg_ng[c]; units[k] = units[c]; ++k; }
+    w.nseg = k;
+  }
+  const double pro = 0.35 * units[0];              // a workgroup's prologue in step units of the longest column's image
+  int best_ns[4] = {1, 1, 1, 1};
+  if (g_cw_streams > 0) {
+    int ns = g_cw_streams;
+    if (ns > nimg_x) ns = nimg_x;
+    for (int c = 0; c < w.nseg; ++c) best_ns[c] = ns;
+  } else if (!VIL_CW_CLASS_STREAMS || w.ncolx > cap) {
+    // one stream count for all columns: the fewest streams (longest-lived workgroups: tables and bias image loaded once per
+    // stream) that fill the XCD's workgroup slots in whole rounds.  Also with more columns than slots (96 x 96: 294 columns,
+    // 160 slots): one stream -- every workgroup walks all of its XCD's images -- measured 149 - 151 us against 160 - 167 us
+    // for one image per workgroup (profiles/r06_streams_sweep_96.txt), although an XCD's L2 does not hold one image there.
+    double best = 1e9;
+    int ns = 1;
+    for (int t = 1; t <= nimg_x; ++t) {
+      const int wgs = w.ncolx * t, rounds = (wgs + cap - 1) / cap;
+      const double cost = rounds * ((double)((nimg_x + t - 1) / t) + 0.35);        // rounds x images per workgroup (+ a prologue's worth)
+      if (cost < best - 1e-9) { best = cost; ns = t; }
+    }
+    for (int c = 0; c < w.nseg; ++c) best_ns[c] = ns;
+  } else {
+    // (measured alternative, off: see the comment above)
+    // candidates: every target time "class c split t ways"; per class the fewest streams that meet the target; scored by the
+    // simulated finishing time of the launch in its dispatch order.  Plans of more than 1.25 rounds of workgroups are not
+    // considered: the later rounds walk images the first one has left behind in L2.
+    double best = 1e30;
+    std::vector<double> work;
+    for (int tc = 0; tc < w.nseg; ++tc)
+      for (int t = 1; t <= nimg_x; ++t) {
+        const double target = (double)((nimg_x + t - 1) / t) * units[tc];
+        int ns[4], wgs = 0;
+        for (int c = 0; c < w.nseg; ++c) {
+          ns[c] = 1;
+          while (ns[c] < nimg_x && (double)((nimg_x + ns[c] - 1) / ns[c]) * units[c] > target + 1e-9) ++ns[c];
+          wgs += w.seg_ng[c] * w.NHG * ns[c];
+        }
+        if (wgs * 4 > cap * 5) continue;
+        // dispatch order: segments by decreasing work per workgroup
+        int ord[4] = {0, 1, 2, 3};
+        for (int i = 0; i < w.nseg; ++i)
+          for (int j = i + 1; j < w.nseg; ++j)
+            if ((double)((nimg_x + ns[ord[j]] - 1) / ns[ord[j]]) * units[ord[j]] > (double)((nimg_x + ns[ord[i]] - 1) / ns[ord[i]]) * units[ord[i]]) {
+              const int x = ord[i]; ord[i] = ord[j]; ord[j] = x;
+            }
+        work.clear();
+        for (int i = 0; i < w.nseg; ++i) {
+          const int c = ord[i];
+          for (int s_ = 0; s_ < ns[c]; ++s_) {
+            const int imgs = (nimg_x - s_ + ns[c] - 1) / ns[c];
+            for (int k = 0; k < w.seg_ng[c] * w.NHG; ++k) work.push_back(imgs * (double)units[c] + pro);
+          }
+        }
+        const double cost = cw_makespan(work.data(), (int)work.size(), cap);
+        if (cost < best - 1e-9) { best = cost; for (int c = 0; c < w.nseg; ++c) best_ns[c] = ns[c]; }
+      }
+    if (best > 1e29) {              // (nothing fits: as many columns as slots -- one stream each)
+      for (int c = 0; c < w.nseg; ++c) best_ns[c] = 1;
+    }
+  }
+  for (int c = 0; c < w.nseg; ++c)
+    while ((nimg_x + best_ns[c] - 1) / best_ns[c] > 32) ++best_ns[c];          // (the redo mask of a workgroup holds 32 images)
+  // segments in dispatch order: decreasing work per workgroup
+  for (int i = 0; i < w.nseg; ++i)
+    for (int j = i + 1; j < w.nseg; ++j) {
+      const double wi = (double)((nimg_x + best_ns[i] - 1) / best_ns[i]) * units[i], wj = (double)((nimg_x + best_ns[j] - 1) / best_ns[j]) * units[j];
+      if (wj > wi) {
+        int x;
+        x = best_ns[i]; best_ns[i] = best_ns[j]; best_ns[j] = x;
+        x = units[i]; units[i] = units[j]; units[j] = x;
+        x = w.seg_g0[i]; w.seg_g0[i] = w.seg_g0[j]; w.seg_g0[j] = x;
+        x = w.seg_ng[i]; w.seg_ng[i] = w.seg_ng[j]; w.seg_ng[j] = x;
+      }
+    }
+  int wg0 = 0;
+  w.NS = 1;
+  for (int c = 0; c < w.nseg; ++c) {
+    w.seg_ns[c] = best_ns[c];
+    w.seg_wg0[c] = wg0;
+    w.seg_m[c] = vil_magic((unsigned)(w.seg_ng[c] * w.NHG));
+    wg0 += w.seg_ng[c] * w.NHG * best_ns[c];
+    if (best_ns[c] > w.NS) w.NS = best_ns[c];
+  }
+  for (int c = w.nseg; c < 4; ++c) { w.seg_g0[c] = w.ngrp; w.seg_ng[c] = 0; w.seg_ns[c] = 1; w.seg_wg0[c] = wg0; w.seg_m[c] = vil_magic(1u); }
+  w.nwgx = wg0;
+}
 static bool cw_make_cfg(const VilAttnDesc* d, const MfmaCfg& c, CwCfg& w) {
   memset(&w, 0, sizeof(w));
   VilGeom g; vil_geom_init(g, d->nx, d->ny, d->W, d->exact, d->mode);
@@ -627,26 +816,8 @@ static bool cw_make_cfg(const VilAttnDesc* d, const MfmaCfg& c, CwCfg& w) {
   if (per_cu > (int)((160 * 1024) / lds)) per_cu = (int)((160 * 1024) / lds);
   if (per_cu < 1) per_cu = 1;
   const int cap = per_cu * (vil_cu_count() / 8 > 0 ? vil_cu_count() / 8 : 32);
-  int ns = 1;
-  if (w.by_image) {
-    // image streams per column: the fewest (longest-lived workgroups: tables and bias image loaded once per stream) that
-    // fill the XCD's workgroup slots in whole rounds; with more columns than slots one image per workgroup, dispatched
-    // image-major (the K / V of ONE image per XCD in flight: they fill its L2 at 96 x 96)
-    if (w.ncolx > cap) ns = nimg_x;
-    else {
-      double best = 1e9;
-      for (int t = 1; t <= nimg_x; ++t) {
-        const int wgs = w.ncolx * t, rounds = (wgs + cap - 1) / cap;
-        // time ~ rounds x images per workgroup (+ a prologue's worth per round)
-        const double cost = rounds * ((double)((nimg_x + t - 1) / t) + 0.35);
-        if (cost < best - 1e-9) { best = cost; ns = t; }
-      }
-    }
-    if (g_cw_streams > 0) ns = g_cw_streams;
-    if (ns > nimg_x) ns = nimg_x;
-    while ((nimg_x + ns - 1) / ns > 32) ++ns;          // (the redo mask of a workgroup holds 32 images)
-  }
-  w.NS = ns;
+  w.NS = 1; w.nseg = 0; w.nwgx = w.ncolx;
+  if (w.by_image) cw_plan_streams(d, g, w, cap, nimg_x);
   return true;
 }
 // can the global token's query row ride (vil_attn_fwd_full)?  One global token, local keys attended, an unused column
@@ -670,7 +841,23 @@ int vil_cw_supported(const VilAttnDesc* d, int pass) {
   if (w.NWP * w.NCH * w.HPW > 8) return VIL_E_BACKEND;
   if (cw_lds_bytes(d, c, w) > 160 * 1024) return VIL_E_BACKEND;
   if (w.akb + c.tabsize * 4 >= 65536) return VIL_E_BACKEND;                 // 16-bit address terms
-  if ((uint64_t)w.ncolx * w.NS * 8 >= (1ull << 31) || (uint64_t)w.ncolx * w.NS * (uint64_t)w.ncolx >= (1ull << 32)) return VIL_E_BACKEND;
+  if ((uint64_t)w.nwgx * 8 >= (1ull << 31)) return VIL_E_BACKEND;
+  return VIL_OK;
+}
+
+// the launch plan of a descriptor (tools and tests: no launch, no device): out24 = {nseg, workgroups per XCD, NS, NCH, NHG,
+// chunk groups, by_image, chunks, then per segment (4x): first group, groups, streams, first workgroup}
+extern "C" int vil_attn_cw_plan(const VilAttnDesc* d, int32_t* out24) {
+  if (!d || !out24) return VIL_E_NULL;
+  const int e = vil_cw_supported(d, 0);
+  if (e) return e;
+  MfmaCfg c; vil_mfma_make_cfg(d, c);
+  CwCfg w; cw_make_cfg(d, c, w);
+  const int head[8] = {w.nseg, w.nwgx, w.NS, w.NCH, w.NHG, w.ngrp, w.by_image, w.nch};
+  for (int i = 0; i < 8; ++i) out24[i] = head[i];
+  for (int k = 0; k < 4; ++k) {
+    out24[8 + 4 * k] = w.seg_g0[k]; out24[9 + 4 * k] = w.seg_ng[k]; out24[10 + 4 * k] = w.seg_ns[k]; out24[11 + 4 * k] = w.seg_wg0[k];
+  }
   return VIL_OK;
 }
 
@@ -679,7 +866,7 @@ size_t vil_cw_workspace(const VilAttnDesc* d, int pass) {
   if (pass != 0) return 0;
   MfmaCfg c; vil_mfma_make_cfg(d, c);
   CwCfg w; cw_make_cfg(d, c, w);
-  size_t fl = cw_align4((size_t)d->H * c.tabsize) + 2 * cw_align4((size_t)w.nch * c.NSP) + 2 * cw_align4((size_t)w.nch) + cw_align4((size_t)8 * w.ncolx * w.NS);
+  size_t fl = cw_align4((size_t)d->H * c.tabsize) + 2 * cw_align4((size_t)w.nch * c.NSP) + 2 * cw_align4((size_t)w.nch) + cw_align4((size_t)8 * w.nwgx);
   if (cw_gq_fusable(d, w)) fl += cw_align4((size_t)d->B * d->H * w.nch * (d->M + 4));
   return fl * sizeof(float);
 }
@@ -699,7 +886,7 @@ int vil_cw_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   w.akey = (int*)(ws + off); off += cw_align4((size_t)w.nch * c.NSP);
   w.nslots = (int*)(ws + off); off += cw_align4((size_t)w.nch);
   w.nown = (int*)(ws + off); off += cw_align4((size_t)w.nch);
-  w.redo = (unsigned*)(ws + off); off += cw_align4((size_t)8 * w.ncolx * w.NS);
+  w.redo = (unsigned*)(ws + off); off += cw_align4((size_t)8 * w.nwgx);
   if (p.glo_rows) {
     c.gq_parts = ws + off;
     c.gq_on = 1;
@@ -718,7 +905,7 @@ int vil_cw_fwd(const VilAttnDesc* d, VilParams& p, hipStream_t s) {
   int e = (int)hipGetLastError();
   if (e) return e;
   vil_prof_begin(VIL_K_MFMA_FWD, s, wk.fwd_bytes(), wk.fwd_flops());
-  const unsigned grid = 8u * (unsigned)(w.ncolx * w.NS);
+  const unsigned grid = 8u * (unsigned)w.nwgx;
   const size_t lds = cw_lds_bytes(d, c, w);
   const unsigned nthr = 64u * (unsigned)(w.NWP * w.NCH * w.HPW);
 #define LAUNCH_CW(T_, MD_, QT_, SAFE_, RO_)                                                        \

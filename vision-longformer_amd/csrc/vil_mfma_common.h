@@ -448,7 +448,14 @@ struct CwCfg {
   int NSP;
   int by_image;        // B >= 8: XCD x walks images x, x + 8, ...; else (image, head) pairs are dealt to the XCDs, one image per workgroup
   int ncolx;           // columns of one XCD's list: H * ngrp (by_image) or ceil(B H / 8) * ngrp
-  int NS;              // image streams per column (stream s of XCD x: images x + 8 s, x + 8 (s + NS), ...)
+  int NS;              // image streams per column (stream s of XCD x: images x + 8 s, x + 8 (s + NS), ...): the largest of seg_ns
+  // by_image: an XCD's workgroup list is nseg segments of chunk groups with (about) equal work per image -- interior, edge and
+  // corner chunks of the 3x3 neighbourhood -- each with its own number of image streams, so that every workgroup of the
+  // launch has about the same work whatever its chunks' neighbour count: segment c = groups [seg_g0[c], seg_g0[c] + seg_ng[c])
+  // x NHG head groups x seg_ns[c] streams, workgroups [seg_wg0[c], seg_wg0[c + 1]) of the XCD's nwgx
+  int nseg, nwgx;
+  int seg_g0[4], seg_ng[4], seg_ns[4], seg_wg0[4];
+  unsigned seg_m[4];   // vil_magic(seg_ng[c] * NHG)
   int koff_lds, ak_lds;   // LDS bytes of a chunk's two slot tables (whole 1 KB DMA pieces)
   int abl;             // timing-ablation bits (VIL_CW_ABLATE builds only)
   void* dbg;           // cycle-stamp records (VIL_CW_ABLATE builds only)
