@@ -758,6 +758,15 @@ static void cw_plan_streams(const VilAttnDesc* d, const VilGeom& g, CwCfg& w, in
         x = w.seg_ng[i]; w.seg_ng[i] = w.seg_ng[j]; w.seg_ng[j] = x;
       }
     }
+  // one stream count for every class: ONE segment, i.e. the XCD's list is stream-major over all columns -- all columns of an
+  // image are dispatched next to each other and meet its K / V in L2 together.  (Segment-major order with several rounds of
+  // workgroups walks every image once per class: in-step HBM traffic of the pass 1.83x the algorithmic bytes at 56 x 56
+  // instead of 1.18x, profiles/r06_pmc_traffic.json history in DESIGN.md 4.9.)
+  {
+    bool uniform = true;
+    for (int c = 1; c < w.nseg; ++c) uniform = uniform && best_ns[c] == best_ns[0];
+    if (uniform) { w.nseg = 1; w.seg_g0[0] = 0; w.seg_ng[0] = w.ngrp; }
+  }
   int wg0 = 0;
   w.NS = 1;
   for (int c = 0; c < w.nseg; ++c) {
