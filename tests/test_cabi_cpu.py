@@ -408,3 +408,22 @@ def test_cw_launch_plan_covers_every_image_head_and_chunk_group_once(shape):
                 assert key not in seen, (key, seen[key], (xcd, kblk))
                 seen[key] = (xcd, kblk)
     assert len(seen) == B * NHG * ngrp
+
+
+def test_cw_launch_shape_hook_validates_its_arguments():
+    """vil_attn_cw_set_shape (tools / tests only): out-of-range values are refused with VIL_E_SHAPE and leave the library's own
+    choice in place; (0, 0) restores it."""
+    L = _lib.lib()
+    E_SHAPE = -2
+    assert L.vil_attn_strerror(E_SHAPE) != b"ok"
+    plan0 = _cw_plan(32, 3, 32, 28, 28, 7)
+    for bad in ((-1, 0), (0, -1), (0, 5), (0, 30), (0, 900)):       # streams < 0, code < 0, 5 chunks, 3 query tiles, 9 heads
+        assert L.vil_attn_cw_set_shape(*bad) == E_SHAPE, bad
+        assert _cw_plan(32, 3, 32, 28, 28, 7) == plan0
+    try:
+        assert L.vil_attn_cw_set_shape(2, 1) == 0           # two streams, one chunk per workgroup
+        o = _cw_plan(32, 3, 32, 28, 28, 7)
+        assert o[2] == 2 and o[3] == 1 and o != plan0
+    finally:
+        assert L.vil_attn_cw_set_shape(0, 0) == 0
+    assert _cw_plan(32, 3, 32, 28, 28, 7) == plan0
