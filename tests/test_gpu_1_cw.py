@@ -175,3 +175,21 @@ def test_cw_launch_shapes_agree(dev):
                 assert torch.equal(out, base[0]) and torch.equal(lse, base[1]), (streams, code)
     finally:
         L.vil_attn_cw_set_shape(0, 0)
+
+
+@pytest.mark.parametrize("c,family", [
+    (case(3, 32, 7, 21, 21, 1, B=2), "mfma_cw"), (case(2, 64, 8, 16, 16, 1), "mfma_cw"), (case(2, 32, 7, 14, 14, 1, exact=1), "mfma_cw"),
+    (case(2, 64, 12, 24, 25, 1, B=1), "mfma_wave"), (case(2, 32, 6, 13, 12, 1, mode=3), "mfma_wave"),
+    (case(2, 32, 4, 8, 8, 1, only_glo=True), "mfma_wave"), (case(2, 32, 7, 14, 14, 1, mode=-1), "mfma_wave"),
+], ids=lambda v: v if isinstance(v, str) else cid(v))
+def test_default_backend_takes_the_family_the_dispatch_rule_names(c, family, dev):
+    """desc.backend = MFMA (what the module uses): the chunk-workgroup forward for 3x3 neighbourhoods with W <= 8, the
+    wave-per-chunk kernels for everything else -- observed through the bits of the result, which differ
+    between the families (other rounding points) and are reproducible within one."""
+    q, kv, table, g2l, dout = make_inputs(c, torch.bfloat16)
+    out, lse = _fwd(c, q, kv, table, g2l, torch.bfloat16, "mfma", dev)
+    out_f, lse_f = _fwd(c, q, kv, table, g2l, torch.bfloat16, family, dev)
+    assert torch.equal(out, out_f) and torch.equal(lse, lse_f)
+    other = "mfma_wave" if family == "mfma_cw" else "mfma_cw"
+    out_o, lse_o = _fwd(c, q, kv, table, g2l, torch.bfloat16, other, dev)
+    assert not (torch.equal(out, out_o) and torch.equal(lse, lse_o))
