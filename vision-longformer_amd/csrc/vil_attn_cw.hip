@@ -43,6 +43,9 @@
 #ifndef VIL_CW_NCH
 #define VIL_CW_NCH 2         // chunks per workgroup (lockstep)
 #endif
+#ifndef VIL_CW_LATE_V
+#define VIL_CW_LATE_V 0          // wait for a step's V tile only before P V (second barrier per step): measured alternative
+#endif
 #ifndef VIL_CW_CLASS_STREAMS
 #define VIL_CW_CLASS_STREAMS 0   // per-class image stream counts (cw_plan_streams): measured, off
 #endif
@@ -130,6 +133,8 @@ __device__ __forceinline__ void cw_dma16(__amdgpu_buffer_rsrc_t rs, char* dst, i
 #define CW_WAITCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | 0x0070)
 __device__ __forceinline__ void cw_wait_vm(int n) {
   switch (n) {
+    case 1: CW_WAITCNT(1); break;
+    case 3: CW_WAITCNT(3); break;
     case 2: CW_WAITCNT(2); break;
     case 4: CW_WAITCNT(4); break;
     case 6: CW_WAITCNT(6); break;
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(512, cw_occ(MD, QT)) void k_cw_fwd(VilParams p, Mfm
     }
   };
   // one step = 32 key slots of the tile pair in the ring slot at byte offset sl_b
-  auto step = [&](unsigned sl_b, int st, const u32x4& ak, int b, int j) {
+  auto step = [&](unsigned sl_b, int st, const u32x4& ak, int b, int j, int n_mid) {
     // ---- S^T = K Q'^T + bias (the accumulator starts as the gathered bias)
     f32x4 sc[2][QT];
 #pragma unroll
@@ -426,6 +431,15 @@ __global__ __launch_bounds__(512, cw_occ(MD, QT)) void k_cw_fwd(VilParams p, Mfm
                                                      __builtin_amdgcn_exp2f(sc[hf][qt][2 * r2 + 1])});
       pb[qt] = __builtin_bit_cast(X8, wv);
     }
+#if VIL_CW_LATE_V
+    // the V tile of this step: its requests may still be in flight (only K was waited for at the top of the step)
+    asm volatile("" ::: "memory");
+    cw_wait_vm(n_mid);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#else
+    (void)n_mid;
+#endif
     // ---- O^T += V^T P^T ; row sums via the ones-row.  (Transposed reads as inline assembly: the builtin is modelled as
     // an LDS access that may write, and with the next tile's LDS-DMA in flight the compiler would wait for it first.)
 #pragma unroll
@@ -502,9 +516,27 @@ __global__ __launch_bounds__(512, cw_occ(MD, QT)) void k_cw_fwd(VilParams p, Mfm
     unsigned mdma = mrem;
     __amdgpu_buffer_rsrc_t krs = rsrc_k(b0 + jd * bstride), vrs = rsrc_v(b0 + jd * bstride);
     bool dma_live = nsteps > 0;
-    auto request = [&](unsigned slot_b) {                 // request the cursor's tile into the ring slot, advance the cursor
+    auto request = [&](unsigned slot_b) -> int {          // request the cursor's tile into the ring slot, advance the cursor;
+      int issued = 0;                                     // returns the pieces requested per matrix
       if (dma_live) {
         if (sd < nsteps) {
+#if VIL_CW_LATE_V
+          int kfv_[PPM];
+#pragma unroll
+          for (int k = 0; k < PPM; ++k) {                 // all K pieces first: they are waited for first
+            const int sub = wp + k * w.NWP;
+            if (sub < PPM) {
+              kfv_[k] = *lds_i32(kfaddr + (sd * 32 + sub * RPP) * 4);
+              cw_dma16(krs, ring + slot_b + sub * 1024, kfv_[k] + dchunk);
+              ++issued;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < PPM; ++k) {
+            const int sub = wp + k * w.NWP;
+            if (sub < PPM) cw_dma16(vrs, ring + slot_b + sub * 1024 + TILE, kfv_[k] + dchunk);
+          }
+#else
 #pragma unroll
           for (int k = 0; k < PPM; ++k) {
             const int sub = wp + k * w.NWP;
@@ -514,8 +546,10 @@ __global__ __launch_bounds__(512, cw_occ(MD, QT)) void k_cw_fwd(VilParams p, Mfm
               char* base = ring + slot_b + sub * 1024;
               cw_dma16(krs, base, kfv + dchunk);
               cw_dma16(vrs, base + TILE, kfv + dchunk);
+              ++issued;
             }
           }
+#endif
         }
         if (++sd == wsteps) {
           sd = 0;
@@ -523,26 +557,47 @@ __global__ __launch_bounds__(512, cw_occ(MD, QT)) void k_cw_fwd(VilParams p, Mfm
           else dma_live = false;
         }
       }
+      return issued;
     };
     // prologue: slot tables / bias image in LDS (first stream), Q of the first image, tile 0
     load_q(b0 + jc * bstride, qf);
     step_sync();
     scale_q(qf);
-    request(0u);
+    int cur_np = request(0u);
+    (void)cur_np;
     u32x4 akc = *(const u32x4 __attribute__((address_space(3)))*)(size_t)(akaddr);
     X8 qn[MK][QT];
     int st = 0;
     unsigned slot_b = 0;
+    bool qprev = true;            // ordinary loads behind the current tile's requests (LATE_V: then the top wait is for everything)
     for (;;) {
       // tile (jc, st) has landed; the other slot is free: request the next tile, fetch the next step's address terms
+#if VIL_CW_LATE_V
+      // ... its K half, that is: the V pieces (requested after the K pieces) may stay in flight until P V needs them
+      asm volatile("" ::: "memory");
+      cw_wait_vm(qprev ? 0 : cur_np);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int next_np = request(slot_b ^ SLOTB);
+#else
       if (!CW_ABL(1)) step_sync();
-      if (!CW_ABL(2)) request(slot_b ^ SLOTB);
+      int next_np = 0;
+      if (!CW_ABL(2)) next_np = request(slot_b ^ SLOTB);
+#endif
       const int sn = st + 1 < nsteps ? st + 1 : 0;
       const u32x4 akn = *(const u32x4 __attribute__((address_space(3)))*)(size_t)(akaddr + sn * 64);
       // one step before the image ends: the next image's Q rows (the wait at the top of the next step covers them)
-      const bool qnow = mrem != 0 && st + 2 == wsteps;
-      if (qnow) load_q(b0 + __builtin_ctz(mrem) * bstride, qn);
-      if (st < nsteps && !CW_ABL(64)) step(slot_b, st, akc, b0 + jc * bstride, jc);
+      const bool qnow = (mrem != 0 && st + 2 == wsteps) || (mrem != 0 && wsteps == 1);
+      if (mrem != 0 && st + 2 == wsteps) load_q(b0 + __builtin_ctz(mrem) * bstride, qn);
+      // (LATE_V) requests younger than this step's V pieces: the next tile's -- unless ordinary loads are in between
+      const int n_mid = (qprev || qnow) ? 0 : 2 * next_np;
+      if (st < nsteps && !CW_ABL(64)) step(slot_b, st, akc, b0 + jc * bstride, jc, n_mid);
+#if VIL_CW_LATE_V
+      else { asm volatile("" ::: "memory"); cw_wait_vm(n_mid); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+      cur_np = next_np; qprev = qnow;
+#else
+      (void)qprev;
+#endif
       akc = akn;
       slot_b ^= SLOTB;
       if (++st == wsteps) {
