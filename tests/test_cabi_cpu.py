@@ -380,7 +380,7 @@ def _cw_plan(B, H, M, nx, ny, W, G=1, mode=0):
 
 @pytest.mark.parametrize("shape", [(128, 3, 32, 56, 56, 7), (128, 3, 64, 28, 28, 7), (32, 3, 32, 96, 96, 7), (32, 3, 64, 48, 48, 7),
                                    (32, 3, 32, 96, 96, 8), (9, 2, 32, 21, 20, 7), (17, 2, 64, 14, 14, 7), (8, 6, 32, 14, 14, 7),
-                                   (100, 3, 32, 30, 9, 7), (8, 1, 32, 3, 2, 4)], ids=str)
+                                   (100, 3, 32, 30, 9, 7), (8, 1, 32, 3, 2, 4), (600, 1, 32, 14, 14, 7), (2048, 1, 64, 7, 7, 7)], ids=str)
 def test_cw_launch_plan_covers_every_image_head_and_chunk_group_once(shape):
     """The chunk-workgroup forward's launch plan (vil_attn_cw_plan: host only) decoded the way the kernel decodes blockIdx
     (csrc/vil_attn_cw.hip, `by_image` branch): every (image, head group, chunk group) belongs to exactly one workgroup, no
